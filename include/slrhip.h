@@ -1,0 +1,266 @@
+/*
+ * slrhip.h — C ABI of the MI355X-native unidirectional path-tracing integrator.
+ *
+ * This is the drop-in boundary for ONE hot path of goofoo/SLR:
+ *     SLR::PathTracingRenderer::render(const Scene&, const RenderSettings&) const
+ *     (reference: libSLR/Renderers/PathTracingRenderer.cpp:27-98, entered from
+ *      HostProgram/main.cpp:59 through the Renderer vtable libSLR/Core/Renderer.h:15-19).
+ *
+ * The reference's Scene is an opaque pointer graph with no accessor for its nodes,
+ * triangles or materials (libSLR/Core/SurfaceObject.h:187-204,239-260), so the host
+ * layer owns a FLAT scene description and hands it across this ABI.  Every struct
+ * below names the reference type it flattens.  Plain pointers and sizes only; no
+ * C++ or torch types; every entry point returns an int status (0 = OK) and never
+ * throws.  One context per GPU; a context is single-caller (not re-entrant), like
+ * the reference's render() (PathTracingRenderer.cpp:27, called once from main).
+ */
+#ifndef SLRHIP_H
+#define SLRHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SLRHIP_VERSION 1
+
+/* ---- status codes -------------------------------------------------------------- */
+enum {
+    SLRHIP_OK = 0,
+    SLRHIP_ERR_INVALID_ARGUMENT = 1,
+    SLRHIP_ERR_NO_DEVICE = 2,      /* no HIP device / HIP runtime failure at create      */
+    SLRHIP_ERR_HIP = 3,            /* a HIP call failed; see slrhip_last_error_string    */
+    SLRHIP_ERR_NO_SCENE = 4,       /* render before upload_scene                         */
+    SLRHIP_ERR_UNSUPPORTED = 5,    /* scene uses a feature outside the hot path          */
+    SLRHIP_ERR_OUT_OF_MEMORY = 6
+};
+
+/* ---- colour representation ------------------------------------------------------- */
+/* The reference selects RGB vs 16-sample spectral rendering at COMPILE time
+ * (libSLR/defines.h:160 -> typedefs in libSLR/references.h:39-59).  Here it is a
+ * per-context run-time mode.                                                         */
+enum {
+    SLRHIP_MODE_RGB = 0,           /* SampledSpectrum = RGBTemplate<float>, 3 components  */
+    SLRHIP_MODE_SPECTRAL = 1       /* SampledSpectrumTemplate<float,16>, 16-bin storage   */
+};
+#define SLRHIP_RGB_COMPONENTS 3
+#define SLRHIP_SPECTRAL_COMPONENTS 16   /* NumSpectralSamples / NumStrataForStorage, references.h:39-40 */
+
+/* ---- geometry -------------------------------------------------------------------- */
+/* SLR::Vertex, libSLR/Core/geometry.h:147-155 (44 bytes, same field order). */
+typedef struct slrhip_vertex {
+    float position[3];
+    float normal[3];
+    float tangent[3];
+    float texcoord[2];
+} slrhip_vertex;
+
+/* One SLR::Triangle (libSLR/Surface/TriangleMesh.h:16-36) wrapped in its
+ * SingleSurfaceObject (libSLR/Core/SurfaceObject.h:115-153): three vertex indices and
+ * the material of the owning object.  The order of this array is the order in which
+ * the reference would receive the objects (it defines light indices and the tie-break
+ * among equal-distance hits).                                          */
+typedef struct slrhip_triangle {
+    uint32_t v[3];
+    uint32_t material;
+} slrhip_triangle;
+
+/* ---- spectra --------------------------------------------------------------------- */
+/* A scene-constant input spectrum (reference InputSpectrum, references.h:51,57).
+ * RGB mode reads only `rgb` (RGBTemplate, libSLR/BasicTypes/RGBTypes.h:51-143).
+ * Spectral mode evaluates at the path's wavelengths per hit like
+ * ConstantSpectrumTexture::evaluate (libSLR/Textures/constant_textures.h:16-31):
+ *   kind UPSAMPLED : UpsampledContinuousSpectrum(u, v, scale)  SpectrumTypes.h:180-339
+ *   kind REGULAR   : RegularContinuousSpectrum(min,max,values) SpectrumTypes.h:70-118
+ *   kind IRREGULAR : IrregularContinuousSpectrum(lambdas,values) SpectrumTypes.h:121-170
+ * Sample tables live in slrhip_scene_desc::spectrum_data at [data_offset, +num_samples)
+ * (IRREGULAR: num_samples wavelengths followed by num_samples values).                 */
+enum {
+    SLRHIP_SPECTRUM_RGB_ONLY = 0,
+    SLRHIP_SPECTRUM_UPSAMPLED = 1,
+    SLRHIP_SPECTRUM_REGULAR = 2,
+    SLRHIP_SPECTRUM_IRREGULAR = 3
+};
+typedef struct slrhip_spectrum {
+    uint32_t kind;
+    float rgb[3];
+    float u, v, scale;          /* UPSAMPLED */
+    float lambda_min, lambda_max; /* REGULAR */
+    uint32_t num_samples;
+    uint32_t data_offset;
+    uint32_t reserved;
+} slrhip_spectrum;
+
+/* ---- materials ------------------------------------------------------------------- */
+/* Material -> BSDF factories evaluated per hit in the reference
+ * (SurfacePoint::createBSDF, libSLR/Core/geometry.cpp:56-58).                        */
+enum {
+    /* DiffuseReflection basic_SurfaceMaterials.cpp:15-25: sigma < 0 -> LambertianBRDF
+     * (basic_BSDFs.cpp:12-57), sigma >= 0 -> OrenNayerBRDF (OrenNayerBRDF.cpp:12-73).
+     * spectrum[0] = reflectance, param = sigma.                                       */
+    SLRHIP_MATERIAL_MATTE = 0,
+    /* SpecularReflection basic_SurfaceMaterials.cpp:29-34 -> SpecularBRDF + FresnelConductor.
+     * spectrum = {coeffR, eta, k}.                                                    */
+    SLRHIP_MATERIAL_METAL = 1,
+    /* SpecularScattering basic_SurfaceMaterials.cpp:38-43 -> SpecularBSDF + FresnelDielectric.
+     * spectrum = {coeff, etaExt, etaInt}.                                             */
+    SLRHIP_MATERIAL_GLASS = 2,
+    /* MicrofacetReflection MicrofacetSurfaceMaterial.cpp:14-19 -> MicrofacetBRDF(GGX, conductor).
+     * spectrum = {-, eta, k}, param = alpha_g.                                        */
+    SLRHIP_MATERIAL_MICROFACET_METAL = 3,
+    /* MicrofacetScattering MicrofacetSurfaceMaterial.cpp:23-28 -> MicrofacetBSDF(GGX, dielectric).
+     * spectrum = {-, etaExt, etaInt}, param = alpha_g.                                */
+    SLRHIP_MATERIAL_MICROFACET_GLASS = 4
+};
+typedef struct slrhip_material {
+    uint32_t type;
+    int32_t spectrum[3];   /* indices into slrhip_scene_desc::spectra, -1 = unused          */
+    float param;
+    /* EmitterSurfaceMaterial(mat, DiffuseEmission(emittance)) surface_material.h:55-69,
+     * DiffuseEmission.cpp:15-21: index of the emittance spectrum, or -1 if not emitting. */
+    int32_t emittance;
+} slrhip_material;
+
+/* ---- camera ---------------------------------------------------------------------- */
+/* SLR::PerspectiveCamera (libSLR/Cameras/PerspectiveCamera.cpp:15-24) with its
+ * StaticTransform (libSLR/Core/Transform.h:38-87).  Matrices are column-major
+ * (Matrix4x4Template: m[c*4+r], libSLR/BasicTypes/Matrix4x4.h:22-45); both the
+ * matrix and its inverse are given because StaticTransform stores both.
+ * sensitivity <= 0 selects 1/(pi r^2) as PerspectiveCamera.cpp:23 does.               */
+typedef struct slrhip_camera {
+    float local_to_world[16];
+    float world_to_local[16];
+    float aspect;
+    float fov_y;
+    float lens_radius;
+    float img_plane_distance;
+    float obj_plane_distance;
+    float sensitivity;
+} slrhip_camera;
+
+/* ---- environment light ------------------------------------------------------------ */
+/* InfiniteSphereSurfaceObject + IBLEmission (SurfaceObject.cpp:137-222,
+ * SurfaceMaterials/IBLEmission.cpp:15-25): a lat-long radiance map, `scale`, and the
+ * importance map the reference derives from it (image_textures.cpp:81-134) is rebuilt
+ * by the library.  rgb: width*height*3 floats, row-major, row 0 = theta 0 (+Y).
+ * In spectral mode `uvs` (width*height*3: u, v, scale per texel) replaces rgb.        */
+typedef struct slrhip_envmap {
+    uint32_t width, height;
+    const float* texels;
+    float scale;
+} slrhip_envmap;
+
+/* ---- scene ----------------------------------------------------------------------- */
+typedef struct slrhip_scene_desc {
+    const slrhip_vertex* vertices;
+    uint32_t num_vertices;
+    const slrhip_triangle* triangles;
+    uint32_t num_triangles;
+    const slrhip_material* materials;
+    uint32_t num_materials;
+    const slrhip_spectrum* spectra;
+    uint32_t num_spectra;
+    const float* spectrum_data;
+    uint32_t num_spectrum_data;
+    slrhip_camera camera;
+    const slrhip_envmap* env;     /* NULL = no environment sphere (Scene::build envSphere = nullptr) */
+} slrhip_scene_desc;
+
+/* ---- render settings -------------------------------------------------------------- */
+/* SLR::RenderSettings as read by the path tracer (libSLR/Core/RenderSettings.h:15-22;
+ * read at PathTracingRenderer.cpp:33,54-59,88).                                       */
+typedef struct slrhip_render_settings {
+    int32_t image_width;
+    int32_t image_height;
+    float time_start;
+    float time_end;
+    float brightness;
+    int32_t rng_seed;
+} slrhip_render_settings;
+
+/* ---- image-plane shard ------------------------------------------------------------ */
+/* The tile partition of PathTracingRenderer.cpp:74-79 (8x8 tiles, ImageSensor.cpp:12-14)
+ * generalised to N devices: this context renders the tiles whose row-major index t
+ * satisfies t % shard_count == shard_index.  {0,1} = whole image.                     */
+typedef struct slrhip_shard {
+    uint32_t shard_index;
+    uint32_t shard_count;
+} slrhip_shard;
+
+/* ---- context configuration -------------------------------------------------------- */
+typedef struct slrhip_config {
+    int32_t device;            /* HIP device ordinal                                         */
+    int32_t mode;              /* SLRHIP_MODE_*                                              */
+    uint32_t stripes;          /* sample stripes per pixel kept in flight (0 = auto)         */
+    uint32_t flags;            /* reserved, 0                                                */
+} slrhip_config;
+
+/* ---- counters --------------------------------------------------------------------- */
+typedef struct slrhip_counters {
+    uint64_t samples;            /* finished (pixel, sample) pairs                           */
+    uint64_t extension_rays;     /* Scene::intersect calls         PathTracingRenderer.cpp:147,225 */
+    uint64_t shadow_rays;        /* Scene::testVisibility calls    PathTracingRenderer.cpp:180     */
+    uint64_t iterations;         /* wavefront iterations launched                            */
+    uint64_t bvh_nodes;          /* 4-wide nodes in the flattened tree                       */
+    uint64_t bvh_depth;
+    double   build_seconds;      /* host BVH build + upload                                  */
+} slrhip_counters;
+
+typedef struct slrhip_ctx slrhip_ctx;
+
+/* Replaces: `new PathTracingRenderer(spp)` libSLRSceneGraph/API.cpp:1015-1020 (device side). */
+int slrhip_create(const slrhip_config* config, slrhip_ctx** out_ctx);
+int slrhip_destroy(slrhip_ctx* ctx);
+
+/* Replaces: the Scene pointer graph handed to render() (SurfaceObjectAggregate ctor
+ * SurfaceObject.cpp:226-250 builds the accelerator and light list; Scene::build :396-406).
+ * Copies everything; the caller keeps ownership of the host arrays.                       */
+int slrhip_upload_scene(slrhip_ctx* ctx, const slrhip_scene_desc* scene);
+
+/* Replaces: sensor->init(W,H) PathTracingRenderer.cpp:67 (ImageSensor.cpp:35-51) plus the
+ * per-render setup :33-61.  Clears the accumulation state of this context's shard.        */
+int slrhip_render_begin(slrhip_ctx* ctx, const slrhip_render_settings* settings, slrhip_shard shard);
+
+/* Replaces: the pass loop PathTracingRenderer.cpp:72-81 for passes
+ * [spp_begin, spp_begin+spp_count).  Sample s of pixel (x,y) draws from the xorshift128
+ * stream seeded with slrhip_sample_seed(rng_seed, x, y, s), so the image does not depend
+ * on the shard layout or on scheduling.  Asynchronous on `stream` (a hipStream_t, or NULL
+ * for the default stream).                                                                */
+int slrhip_render(slrhip_ctx* ctx, uint32_t spp_begin, uint32_t spp_count, void* stream);
+
+/* Resolve the accumulated radiance into a linear float framebuffer
+ * [height][width][components] = un-normalised SUM over samples of weight*C, exactly what
+ * ImageSensor holds (ImageSensor.cpp:124-129; spectral bins already carry the 16/470
+ * factor of SpectrumTypes.h:826-835).  Pixels outside the shard are written as 0, so a
+ * sum-reduce over shards equals the full image.  `device_dst` is a DEVICE pointer
+ * (e.g. a torch tensor's data_ptr, which is how bench.py feeds RCCL).                     */
+int slrhip_resolve_framebuffer(slrhip_ctx* ctx, float* device_dst, size_t num_floats, void* stream);
+
+/* Same, to HOST memory (synchronises).  Replaces reading camera->getSensor()->pixel(x,y)
+ * (ImageSensor.cpp:88-95).                                                                */
+int slrhip_read_framebuffer(slrhip_ctx* ctx, float* host_dst, size_t num_floats);
+
+int slrhip_synchronize(slrhip_ctx* ctx);
+int slrhip_get_counters(slrhip_ctx* ctx, slrhip_counters* out);
+int slrhip_components(const slrhip_ctx* ctx);   /* 3 or 16 */
+
+/* The per-(pixel, sample) seeding contract (pure function, also used by the oracle).      */
+int32_t slrhip_sample_seed(int32_t rng_seed, uint32_t pixel_x, uint32_t pixel_y, uint32_t pass);
+
+/* Host-side helpers on the float framebuffer.
+ * slrhip_tonemap_bgr8: ImageSensor::saveImage (ImageSensor.cpp:138-186) pixel pipeline:
+ * scale*sensitivity -> (spectral: XYZ->sRGB) -> 1-exp(-Y) tone map -> sRGB gamma -> 8-bit BGR,
+ * bottom-up rows as the BMP writer stores them.                                            */
+int slrhip_tonemap_bgr8(const float* framebuffer, int32_t width, int32_t height, int32_t components,
+                        float scale, uint8_t* dst_bgr, size_t dst_bytes);
+int slrhip_save_bmp(const char* path, const uint8_t* bgr_bottom_up, int32_t width, int32_t height);
+
+const char* slrhip_last_error_string(void);
+int slrhip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLRHIP_H */

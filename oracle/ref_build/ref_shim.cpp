@@ -1,0 +1,366 @@
+/*
+ * ref_shim.cpp — drives the COMPILED REFERENCE (goofoo/SLR libSLR, built from its own
+ * sources where they lie under /root/reference, see Makefile) through its C++ API and
+ * exposes it behind the oracle interface of oracle/slr_oracle.h (prefix slr_ref_).
+ *
+ * This file is ours (test infrastructure); it contains no reference code.  It only
+ *   - constructs libSLR objects from the flat slrhip scene, following the pattern of
+ *     libSLRSceneGraph/TriangleMeshNode.cpp:80-112 (one SingleSurfaceObject per Triangle),
+ *   - calls the reference's own PathTracingRenderer::Job::kernel for ONE pixel at a time
+ *     with its IndependentLightPathSampler re-seeded per (pixel, sample) — the seeding
+ *     contract of include/slrhip.h — which needs access to the private nested Job struct
+ *     (PathTracingRenderer.h:17-37), hence -fno-access-control in the Makefile,
+ *   - calls the unmodified PathTracingRenderer::render() with hardware_concurrency()
+ *     overridden to 1 (below) for the reference's own deterministic serial mode.
+ * The output goes only into oracle/_ref/ and is never committed.
+ */
+#include "../slr_oracle.h"
+
+#include <unistd.h>
+
+#include <atomic>
+#include <map>
+#include <thread>
+#include <vector>
+
+#include "BSDFs/basic_BSDFs.h"
+#include "BasicTypes/Spectrum.h"
+#include "Cameras/PerspectiveCamera.h"
+#include "Core/ImageSensor.h"
+#include "Core/RenderSettings.h"
+#include "Core/SurfaceObject.h"
+#include "Core/Transform.h"
+#include "Core/light_path_samplers.h"
+#include "Core/surface_material.h"
+#include "Memory/ArenaAllocator.h"
+#include "RNGs/XORShiftRNG.h"
+#include "Renderers/PathTracingRenderer.h"
+#include "Surface/TriangleMesh.h"
+#include "SurfaceMaterials/DiffuseEmission.h"
+#include "SurfaceMaterials/MicrofacetSurfaceMaterial.h"
+#include "SurfaceMaterials/basic_SurfaceMaterials.h"
+#include "Textures/constant_textures.h"
+
+using namespace SLR;
+
+// PathTracingRenderer::render sizes its pool from std::thread::hardware_concurrency()
+// (PathTracingRenderer.cpp:31).  This library is linked with -Bsymbolic-functions, so the
+// reference objects inside it bind to THIS definition; slr_ref_render_serial sets the
+// override to 1 to obtain the reference's deterministic single-worker mode without touching
+// its source.  Everywhere else it reports the online CPU count as libstdc++ does.
+static unsigned g_hwConcurrencyOverride = 0;
+unsigned int std::thread::hardware_concurrency() noexcept {
+    if (g_hwConcurrencyOverride) return g_hwConcurrencyOverride;
+    long n = sysconf(_SC_NPROCESSORS_ONLN);
+    return n > 0 ? (unsigned)n : 1u;
+}
+
+struct slr_oracle_scene {
+    std::vector<Vertex> vertices;
+    std::vector<Triangle> triangles;
+    std::vector<SurfaceObject*> objs;
+    std::map<const SurfaceObject*, uint32_t> objIndex;
+    std::vector<InputSpectrum*> spectra;
+    std::vector<SpectrumTexture*> spectrumTextures;
+    std::vector<FloatTexture*> floatTextures;
+    std::vector<SurfaceMaterial*> materials;
+    std::vector<SurfaceMaterial*> ownedMaterials;
+    std::vector<EmitterSurfaceProperty*> emitters;
+    std::vector<SVFresnel*> fresnels;
+    std::vector<SVMicrofacetDistribution*> mfDists;
+    SurfaceObjectAggregate* aggregate = nullptr;
+    PerspectiveCamera* camera = nullptr;
+    StaticTransform* cameraTF = nullptr;
+    Scene scene;
+};
+
+static int32_t sampleSeed(int32_t rngSeed, uint32_t px, uint32_t py, uint32_t pass) {
+    auto fmix = [](uint32_t h) { h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16; return h; };
+    uint32_t h = (uint32_t)rngSeed;
+    h = fmix(h ^ (pass * 0x9E3779B1u));
+    h = fmix(h ^ (py * 0x85EBCA77u + 0x165667B1u));
+    h = fmix(h ^ (px * 0xC2B2AE3Du + 0x27D4EB2Fu));
+    return (int32_t)h;
+}
+
+#ifdef Use_Spectral_Representation
+static const int kComponents = 16;
+#else
+static const int kComponents = 3;
+#endif
+
+static InputSpectrum* makeSpectrum(const slrhip_scene_desc* d, const slrhip_spectrum& sp) {
+#ifdef Use_Spectral_Representation
+    switch (sp.kind) {
+    case SLRHIP_SPECTRUM_UPSAMPLED:
+        return new UpsampledContinuousSpectrum(sp.u, sp.v, sp.scale);
+    case SLRHIP_SPECTRUM_REGULAR:
+        return new RegularContinuousSpectrum(sp.lambda_min, sp.lambda_max, d->spectrum_data + sp.data_offset, sp.num_samples);
+    case SLRHIP_SPECTRUM_IRREGULAR:
+        return new IrregularContinuousSpectrum(d->spectrum_data + sp.data_offset, d->spectrum_data + sp.data_offset + sp.num_samples,
+                                               sp.num_samples);
+    default:
+        return nullptr;
+    }
+#else
+    (void)d;
+    return new RGBInputSpectrum(sp.rgb[0], sp.rgb[1], sp.rgb[2]);
+#endif
+}
+
+extern "C" {
+
+slr_oracle_scene* slr_ref_create(const slrhip_scene_desc* d, int mode) {
+    if (!d || d->num_triangles == 0) return nullptr;
+    if ((mode == SLRHIP_MODE_SPECTRAL) != (kComponents == 16)) return nullptr;
+    static bool inited = false;
+    if (!inited) { initSpectrum(); inited = true; }        // HostProgram/main.cpp:27
+
+    slr_oracle_scene* s = new slr_oracle_scene();
+    s->vertices.resize(d->num_vertices);
+    for (uint32_t i = 0; i < d->num_vertices; ++i) {
+        const slrhip_vertex& v = d->vertices[i];
+        s->vertices[i] = Vertex(Point3D(v.position[0], v.position[1], v.position[2]), Normal3D(v.normal[0], v.normal[1], v.normal[2]),
+                                Tangent3D(v.tangent[0], v.tangent[1], v.tangent[2]), TexCoord2D(v.texcoord[0], v.texcoord[1]));
+    }
+    for (uint32_t i = 0; i < d->num_spectra; ++i) {
+        InputSpectrum* sp = makeSpectrum(d, d->spectra[i]);
+        s->spectra.push_back(sp);
+        s->spectrumTextures.push_back(sp ? new ConstantSpectrumTexture(sp) : nullptr);
+    }
+    auto tex = [&](int32_t idx) -> const SpectrumTexture* { return idx >= 0 ? s->spectrumTextures[idx] : nullptr; };
+    for (uint32_t i = 0; i < d->num_materials; ++i) {
+        const slrhip_material& m = d->materials[i];
+        SurfaceMaterial* base = nullptr;
+        switch (m.type) {
+        case SLRHIP_MATERIAL_MATTE: {
+            FloatTexture* sigma = nullptr;
+            if (m.param >= 0.0f) { sigma = new ConstantFloatTexture(m.param); s->floatTextures.push_back(sigma); }
+            base = new DiffuseReflection(tex(m.spectrum[0]), sigma);
+            break;
+        }
+        case SLRHIP_MATERIAL_METAL:
+            base = new SpecularReflection(tex(m.spectrum[0]), tex(m.spectrum[1]), tex(m.spectrum[2]));
+            break;
+        case SLRHIP_MATERIAL_GLASS:
+            base = new SpecularScattering(tex(m.spectrum[0]), tex(m.spectrum[1]), tex(m.spectrum[2]));
+            break;
+        case SLRHIP_MATERIAL_MICROFACET_METAL: {
+            FloatTexture* a = new ConstantFloatTexture(m.param); s->floatTextures.push_back(a);
+            SVFresnel* fr = new SVFresnelConductor(tex(m.spectrum[1]), tex(m.spectrum[2])); s->fresnels.push_back(fr);
+            SVMicrofacetDistribution* dist = new SVGGX(a); s->mfDists.push_back(dist);
+            base = new MicrofacetReflection(tex(m.spectrum[1]), tex(m.spectrum[2]), dist);
+            break;
+        }
+        case SLRHIP_MATERIAL_MICROFACET_GLASS: {
+            FloatTexture* a = new ConstantFloatTexture(m.param); s->floatTextures.push_back(a);
+            SVMicrofacetDistribution* dist = new SVGGX(a); s->mfDists.push_back(dist);
+            base = new MicrofacetScattering(tex(m.spectrum[1]), tex(m.spectrum[2]), dist);
+            break;
+        }
+        default:
+            delete s;
+            return nullptr;
+        }
+        s->ownedMaterials.push_back(base);
+        if (m.emittance >= 0) {
+            EmitterSurfaceProperty* e = new DiffuseEmission(tex(m.emittance));
+            s->emitters.push_back(e);
+            SurfaceMaterial* em = new EmitterSurfaceMaterial(base, e);
+            s->ownedMaterials.push_back(em);
+            s->materials.push_back(em);
+        }
+        else {
+            s->materials.push_back(base);
+        }
+    }
+    s->triangles.resize(d->num_triangles);
+    for (uint32_t i = 0; i < d->num_triangles; ++i) {
+        const slrhip_triangle& t = d->triangles[i];
+        new (&s->triangles[i]) Triangle(&s->vertices[t.v[0]], &s->vertices[t.v[1]], &s->vertices[t.v[2]], nullptr);
+    }
+    for (uint32_t i = 0; i < d->num_triangles; ++i) {
+        SurfaceObject* o = new SingleSurfaceObject(&s->triangles[i], s->materials[d->triangles[i].material]);
+        s->objs.push_back(o);
+        s->objIndex[o] = i;
+    }
+    s->aggregate = new SurfaceObjectAggregate(s->objs);
+
+    const slrhip_camera& c = d->camera;
+    s->camera = new PerspectiveCamera(c.sensitivity, c.aspect, c.fov_y, c.lens_radius, c.img_plane_distance, c.obj_plane_distance);
+    float m[16], mi[16];
+    for (int i = 0; i < 16; ++i) { m[i] = c.local_to_world[i]; mi[i] = c.world_to_local[i]; }
+    s->cameraTF = new StaticTransform(Matrix4x4(m), Matrix4x4(mi));
+    s->camera->setTransform(s->cameraTF);
+    s->scene.build(s->aggregate, nullptr, s->camera);
+    return s;
+}
+
+void slr_ref_destroy(slr_oracle_scene* s) {
+    if (!s) return;
+    delete s->camera;
+    delete s->cameraTF;
+    delete s->aggregate;
+    for (auto* o : s->objs) delete o;
+    for (auto* m : s->ownedMaterials) delete m;
+    for (auto* e : s->emitters) delete e;
+    for (auto* t : s->spectrumTextures) delete t;
+    for (auto* t : s->floatTextures) delete t;
+    for (auto* f : s->fresnels) delete f;
+    for (auto* f : s->mfDists) delete f;
+    delete s;
+}
+
+int slr_ref_components(const slr_oracle_scene*) { return kComponents; }
+
+static void fillJob(PathTracingRenderer::Job& job, slr_oracle_scene* s, const slrhip_render_settings* st, ArenaAllocator* mem,
+                    IndependentLightPathSampler** samplerRef) {
+    job.scene = &s->scene;
+    job.mems = mem;
+    job.pathSamplers = samplerRef;
+    job.camera = s->camera;
+    job.timeStart = st->time_start;
+    job.timeEnd = st->time_end;
+    job.sensor = s->camera->getSensor();
+    job.imageWidth = (uint32_t)st->image_width;
+    job.imageHeight = (uint32_t)st->image_height;
+    job.numPixelX = 1;
+    job.numPixelY = 1;
+}
+
+int slr_ref_render(slr_oracle_scene* s, const slrhip_render_settings* st, slrhip_shard shard, uint32_t sppBegin, uint32_t sppCount,
+                   int threads, float* fbSum, float* fbComp, slr_oracle_counters* counters) {
+    if (!s || !st || !fbSum || !fbComp || shard.shard_count == 0) return 1;
+    const uint32_t W = (uint32_t)st->image_width, H = (uint32_t)st->image_height;
+    ImageSensor* sensor = s->camera->getSensor();
+    sensor->init(W, H);
+    const uint32_t tilesX = sensor->numTileX();
+    if (threads <= 0) threads = (int)std::thread::hardware_concurrency();
+    if (threads <= 0) threads = 1;
+    std::atomic<uint32_t> nextRow(0);
+    std::atomic<uint64_t> samples(0);
+    auto worker = [&]() {
+        ArenaAllocator mem;
+        IndependentLightPathSampler sampler(0);
+        IndependentLightPathSampler* samplerRef = &sampler;
+        PathTracingRenderer::Job job;
+        fillJob(job, s, st, &mem, &samplerRef);
+        uint64_t n = 0;
+        for (;;) {
+            uint32_t y = nextRow.fetch_add(1);
+            if (y >= H) break;
+            for (uint32_t x = 0; x < W; ++x) {
+                uint32_t tile = (y >> 3) * tilesX + (x >> 3);
+                if (tile % shard.shard_count != shard.shard_index) continue;
+                SpectrumStorage& px = sensor->pixel(x, y);
+                size_t o = ((size_t)y * W + x) * kComponents;
+                for (int k = 0; k < kComponents; ++k) { px.value.result[k] = fbSum[o + k]; px.value.comp[k] = fbComp[o + k]; }
+                job.basePixelX = x;
+                job.basePixelY = y;
+                for (uint32_t p = sppBegin; p < sppBegin + sppCount; ++p) {
+                    new (&sampler) IndependentLightPathSampler(sampleSeed(st->rng_seed, x, y, p));
+                    job.kernel(0);                         // PathTracingRenderer.cpp:100-135, reference code
+                    ++n;
+                }
+                for (int k = 0; k < kComponents; ++k) { fbSum[o + k] = px.value.result[k]; fbComp[o + k] = px.value.comp[k]; }
+            }
+        }
+        samples += n;
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < threads; ++t) pool.emplace_back(worker);
+    worker();
+    for (auto& t : pool) t.join();
+    if (counters) counters->samples += samples.load();
+    return 0;
+}
+
+int slr_ref_sample(slr_oracle_scene* s, const slrhip_render_settings* st, uint32_t px, uint32_t py, uint32_t pass, float* out) {
+    if (!s || !st || !out) return 1;
+    ImageSensor* sensor = s->camera->getSensor();
+    sensor->init((uint32_t)st->image_width, (uint32_t)st->image_height);
+    ArenaAllocator mem;
+    int32_t seed = sampleSeed(st->rng_seed, px, py, pass);
+    IndependentLightPathSampler sampler(seed);
+    IndependentLightPathSampler* samplerRef = &sampler;
+    PathTracingRenderer::Job job;
+    fillJob(job, s, st, &mem, &samplerRef);
+    job.basePixelX = px;
+    job.basePixelY = py;
+    job.kernel(0);
+    const ImageSensor* cs = sensor;
+    DiscretizedSpectrum v = cs->pixel(px, py);
+    for (int k = 0; k < kComponents; ++k) out[k] = v[k];
+    // the jittered position is internal to Job::kernel; reproduce its two draws (draw 2 and 3 of the stream)
+    XORShiftRNG rng(seed);
+    rng.getFloat0cTo1o();
+    out[kComponents] = px + rng.getFloat0cTo1o();
+    out[kComponents + 1] = py + rng.getFloat0cTo1o();
+    return 0;
+}
+
+int slr_ref_trace(slr_oracle_scene* s, const slr_oracle_ray* rays, uint32_t n, slr_oracle_hit* hits) {
+    if (!s || !rays || !hits) return 1;
+    for (uint32_t i = 0; i < n; ++i) {
+        Ray r(Point3D(rays[i].org[0], rays[i].org[1], rays[i].org[2]), Vector3D(rays[i].dir[0], rays[i].dir[1], rays[i].dir[2]), 0.0f,
+              rays[i].dist_min, rays[i].dist_max);
+        Intersection isect;
+        const SurfaceObject* agg = s->aggregate;
+        if (agg->intersect(r, &isect)) {
+            hits[i].triangle = s->objIndex.at(isect.obj.top());
+            hits[i].dist = isect.dist;
+            hits[i].b0 = isect.u;
+            hits[i].b1 = isect.v;
+        }
+        else {
+            hits[i].triangle = 0xFFFFFFFFu; hits[i].dist = INFINITY; hits[i].b0 = 0; hits[i].b1 = 0;
+        }
+    }
+    return 0;
+}
+
+void slr_ref_rng(int32_t seed, uint32_t n, uint32_t* uints, float* floats) {
+    XORShiftRNG a(seed);
+    for (uint32_t i = 0; i < n; ++i) uints[i] = a.getUInt();
+    XORShiftRNG b(seed);
+    for (uint32_t i = 0; i < n; ++i) floats[i] = b.getFloat0cTo1o();
+}
+
+// The UNMODIFIED PathTracingRenderer::render (PathTracingRenderer.cpp:27-98) with
+// hardware_concurrency() == 1 (see the override above): one worker, one xorshift stream,
+// bit-deterministic.  render() writes NNN.bmp into the
+// cwd (:83-93), so it runs inside a scratch directory.
+int slr_ref_render_serial(slr_oracle_scene* s, const slrhip_render_settings* st, uint32_t spp, float* fbSum,
+                          slr_oracle_counters* counters) {
+    if (!s || !st || !fbSum) return 1;
+    int rc = 0;
+    g_hwConcurrencyOverride = 1;
+    char cwd[4096];
+    char tmpl[] = "/tmp/slr_ref_serial_XXXXXX";
+    if (!rc && (!getcwd(cwd, sizeof(cwd)) || !mkdtemp(tmpl) || chdir(tmpl) != 0)) rc = 4;
+    if (!rc) {
+        RenderSettings settings;
+        settings.addItem(RenderSettingItem::ImageWidth, (int32_t)st->image_width);
+        settings.addItem(RenderSettingItem::ImageHeight, (int32_t)st->image_height);
+        settings.addItem(RenderSettingItem::TimeStart, st->time_start);
+        settings.addItem(RenderSettingItem::TimeEnd, st->time_end);
+        settings.addItem(RenderSettingItem::Brightness, st->brightness);
+        settings.addItem(RenderSettingItem::RNGSeed, (int32_t)st->rng_seed);
+        PathTracingRenderer renderer(spp);
+        renderer.render(s->scene, settings);
+        const ImageSensor* cs = s->camera->getSensor();
+        for (uint32_t y = 0; y < (uint32_t)st->image_height; ++y)
+            for (uint32_t x = 0; x < (uint32_t)st->image_width; ++x) {
+                DiscretizedSpectrum v = cs->pixel(x, y);
+                for (int k = 0; k < kComponents; ++k) fbSum[((size_t)y * st->image_width + x) * kComponents + k] = v[k];
+            }
+        if (chdir(cwd) != 0) rc = 4;
+        std::string cmd = std::string("rm -rf ") + tmpl;
+        if (system(cmd.c_str()) != 0) { /* scratch dir left behind */ }
+        if (counters) counters->samples += (uint64_t)st->image_width * st->image_height * spp;
+    }
+    g_hwConcurrencyOverride = 0;
+    return rc;
+}
+
+} // extern "C"

@@ -1,0 +1,1075 @@
+/*
+ * slr_oracle.cpp — CPU ORACLE: a scalar restatement of the reference's unidirectional
+ * path tracer (goofoo/SLR, libSLR).  TEST INFRASTRUCTURE ONLY: the product never
+ * includes, links or calls this file (see oracle/slr_oracle.h).
+ *
+ * Parity status: PINNED.  oracle/ref_build builds the reference's own sources (in place,
+ * unmodified) into oracle/_ref/ and tests/test_oracle_vs_reference.py checks this file
+ * against it bit for bit (whole frames with per-(pixel,sample) seeding, single samples,
+ * closest-hit batches, RNG known answers, and the reference's own serial render()).
+ * The golden vectors under tests/golden/ were produced by that build
+ * (tests/golden/make_golden.py) and pin this file where /root/reference is absent.
+ *
+ * Every function cites the reference file:line it follows (paths relative to
+ * /root/reference/libSLR).  Arithmetic is reproduced operation by operation, including
+ * the float/double mixing the reference gets from M_PI and unsuffixed literals, and
+ * "x / s" implemented as "x * (1.0f / s)" (BasicTypes/Vector3.h:31, RGBTypes.h:67).
+ * Build with -ffp-contract=off and without -ffast-math (oracle/Makefile).
+ *
+ * Deliberate differences (documented in DESIGN.md):
+ *   - accelerator: own binary BVH; the reference result does not depend on the tree
+ *      except among hits at exactly equal distance, where the reference
+ *     keeps the last one tested (TriangleMesh.cpp:158).  Here: larger triangle index wins.
+ *   - one xorshift128 stream per (pixel, sample), seeded by slrhip_sample_seed
+ *     (the reference has one stream per worker thread, PathTracingRenderer.cpp:33-38).
+ */
+#include "slr_oracle.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// BasicTypes/Vector3.h:17-147, Point3.h, Normal3.h (float instantiations)
+// ------------------------------------------------------------------------------------------
+struct V3 {
+    float x, y, z;
+    V3() : x(0), y(0), z(0) {}
+    V3(float xx, float yy, float zz) : x(xx), y(yy), z(zz) {}
+    float operator[](int i) const { return (&x)[i]; }
+    float& operator[](int i) { return (&x)[i]; }
+};
+inline V3 operator+(V3 a, V3 b) { return V3(a.x + b.x, a.y + b.y, a.z + b.z); }
+inline V3 operator-(V3 a, V3 b) { return V3(a.x - b.x, a.y - b.y, a.z - b.z); }
+inline V3 operator-(V3 a) { return V3(-a.x, -a.y, -a.z); }
+inline V3 operator*(V3 a, float s) { return V3(a.x * s, a.y * s, a.z * s); }
+inline V3 operator*(float s, V3 a) { return V3(s * a.x, s * a.y, s * a.z); }
+// Vector3.h:31: operator/(s) is a reciprocal multiply
+inline V3 operator/(V3 a, float s) { float r = 1.0f / s; return V3(a.x * r, a.y * r, a.z * r); }
+inline float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }            // Vector3.h:108-110
+inline float absDot(V3 a, V3 b) { return std::fabs(a.x * b.x + a.y * b.y + a.z * b.z); } // Vector3.h:120-122
+inline V3 cross(V3 a, V3 b) {                                                          // Vector3.h:113-117
+    return V3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+inline float length(V3 a) { return std::sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }     // Vector3.h:55
+inline float sqLength(V3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+inline V3 normalize(V3 a) { float l = length(a); return a / l; }                       // Vector3.h:102-105
+
+// Core/geometry.h:225-235
+struct Frame {
+    V3 x, y, z;
+    V3 toLocal(V3 v) const { return V3(dot(x, v), dot(y, v), dot(z, v)); }
+    V3 fromLocal(V3 v) const {
+        return V3(dot(V3(x.x, y.x, z.x), v), dot(V3(x.y, y.y, z.y), v), dot(V3(x.z, y.z, z.z), v));
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// Spectrum value types.  N = 3: RGBTemplate<float> (BasicTypes/RGBTypes.h:51-143).
+// ------------------------------------------------------------------------------------------
+template <int N>
+struct Spec {
+    float c[N];
+    Spec() { for (int i = 0; i < N; ++i) c[i] = 0.0f; }
+    explicit Spec(float v) { for (int i = 0; i < N; ++i) c[i] = v; }
+    float operator[](int i) const { return c[i]; }
+    float& operator[](int i) { return c[i]; }
+    bool isZero() const { for (int i = 0; i < N; ++i) if (c[i] != 0.0f) return false; return true; }
+};
+template <int N> inline Spec<N> operator+(Spec<N> a, Spec<N> b) { Spec<N> r; for (int i = 0; i < N; ++i) r.c[i] = a.c[i] + b.c[i]; return r; }
+template <int N> inline Spec<N> operator-(Spec<N> a, Spec<N> b) { Spec<N> r; for (int i = 0; i < N; ++i) r.c[i] = a.c[i] - b.c[i]; return r; }
+template <int N> inline Spec<N> operator*(Spec<N> a, Spec<N> b) { Spec<N> r; for (int i = 0; i < N; ++i) r.c[i] = a.c[i] * b.c[i]; return r; }
+template <int N> inline Spec<N> operator/(Spec<N> a, Spec<N> b) { Spec<N> r; for (int i = 0; i < N; ++i) r.c[i] = a.c[i] / b.c[i]; return r; }
+template <int N> inline Spec<N> operator*(Spec<N> a, float s) { Spec<N> r; for (int i = 0; i < N; ++i) r.c[i] = a.c[i] * s; return r; }
+template <int N> inline Spec<N> operator*(float s, Spec<N> a) { Spec<N> r; for (int i = 0; i < N; ++i) r.c[i] = s * a.c[i]; return r; }
+// RGBTypes.h:67 / SpectrumTypes.h:393-399: reciprocal multiply
+template <int N> inline Spec<N> operator/(Spec<N> a, float s) { float rc = 1.0f / s; Spec<N> r; for (int i = 0; i < N; ++i) r.c[i] = a.c[i] * rc; return r; }
+template <int N> inline Spec<N> operator+(Spec<N> a, float s) { return a + Spec<N>(s); } // implicit ctor from scalar
+template <int N> inline Spec<N> operator-(Spec<N> a, float s) { return a - Spec<N>(s); }
+
+// RGBTypes.h:103-108  importance(): 0.9-primary weighting
+inline float importance(const Spec<3>& s, uint16_t selectedLambda) {
+    float sum = s.c[0] + s.c[1] + s.c[2];
+    const float primary = 0.9f;
+    const float marginal = (1 - primary) / 2;
+    return sum * marginal + s.c[selectedLambda] * (primary - marginal);
+}
+
+// BasicTypes/CompensatedSum.h:15-32
+template <typename T>
+struct Kahan {
+    T result, comp;
+    Kahan() : result(), comp() {}
+    void add(const T& value) {
+        T cInput = value - comp;
+        T sumTemp = result + cInput;
+        comp = (sumTemp - result) - cInput;
+        result = sumTemp;
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// RNGs/XORShiftRNG.cpp:21-36, Core/RandomNumberGenerator.cpp:12-15
+// ------------------------------------------------------------------------------------------
+struct XorShift {
+    uint32_t s[4];
+    uint64_t* drawCounter;
+    explicit XorShift(int32_t seed, uint64_t* counter = nullptr) : drawCounter(counter) {
+        for (int i = 0; i < 4; ++i) {
+            // `seed` is SIGNED: the shift is arithmetic; the product is computed in unsigned.
+            uint32_t v = 1812433253U * ((uint32_t)seed ^ (uint32_t)(seed >> 30)) + (uint32_t)i;
+            s[i] = v;
+            seed = (int32_t)v;
+        }
+        for (int i = 0; i < 50; ++i) getUInt();
+    }
+    uint32_t getUInt() {
+        uint32_t t = s[0] ^ (s[0] << 11);
+        s[0] = s[1]; s[1] = s[2]; s[2] = s[3];
+        return s[3] = (s[3] ^ (s[3] >> 19)) ^ (t ^ (t >> 8));
+    }
+    float getFloat0cTo1o() {
+        if (drawCounter) ++*drawCounter;
+        uint32_t fractionBits = (getUInt() >> 9) | 0x3f800000;
+        float f;
+        std::memcpy(&f, &fractionBits, 4);
+        return f - 1.0f;
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// Core/distributions.cpp:37-70 (float instantiation).  `theta *= M_PI_4` is a double
+// multiply rounded to float; `cos(theta)` is the double ::cos (unqualified call in namespace
+// SLR resolves to the C function), `r * cos(theta)` is a double product rounded to float.
+// ------------------------------------------------------------------------------------------
+inline void concentricSampleDisk(float u0, float u1, float* dx, float* dy) {
+    float r, theta;
+    float sx = 2 * u0 - 1;
+    float sy = 2 * u1 - 1;
+    if (sx == 0 && sy == 0) { *dx = 0; *dy = 0; return; }
+    if (sx >= -sy) {
+        if (sx > sy) { r = sx; theta = sy / sx; }
+        else { r = sy; theta = 2 - sx / sy; }
+    }
+    else {
+        if (sx > sy) { r = -sy; theta = 6 + sx / sy; }
+        else { r = -sx; theta = 4 + sy / sx; }
+    }
+    theta = (float)((double)theta * M_PI_4);
+    *dx = (float)((double)r * ::cos((double)theta));
+    *dy = (float)((double)r * ::sin((double)theta));
+}
+// Core/distributions.h:26-33
+inline V3 cosineSampleHemisphere(float u0, float u1) {
+    float x, y;
+    concentricSampleDisk(u0, u1, &x, &y);
+    return V3(x, y, std::sqrt(std::fmax(0.0f, 1.0f - x * x - y * y)));
+}
+// Core/distributions.h:59-64
+inline void uniformSampleTriangle(float u0, float u1, float* b0, float* b1) {
+    float su1 = std::sqrt(u0);
+    *b0 = 1.0f - su1;
+    *b1 = u1 * su1;
+}
+
+inline uint32_t prevPowerOf2(uint32_t x) {   // defines.h:136-143
+    x |= x >> 1; x |= x >> 2; x |= x >> 4; x |= x >> 8; x |= x >> 16;
+    return x - (x >> 1);
+}
+
+// Core/distributions.cpp:76-119  RegularConstantDiscrete1D
+struct Discrete1D {
+    std::vector<float> PMF, CDF;
+    float integral = 0.0f;
+    void build(const std::vector<float>& values) {
+        size_t n = values.size();
+        PMF = values;
+        CDF.assign(n + 1, 0.0f);
+        Kahan<float> sum;
+        for (size_t i = 0; i < n; ++i) { sum.add(PMF[i]); CDF[i + 1] = sum.result; }
+        integral = sum.result;
+        for (size_t i = 0; i < n; ++i) { PMF[i] /= integral; CDF[i + 1] /= integral; }
+    }
+    uint32_t sample(float u, float* prob) const {
+        uint32_t n = (uint32_t)PMF.size();
+        int idx = (int)n;
+        for (int d = (int)prevPowerOf2(n); d > 0; d >>= 1)
+            if (idx - d > 0 && CDF[idx - d] >= u) idx -= d;
+        --idx;
+        *prob = PMF[idx];
+        return (uint32_t)idx;
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// Scene data
+// ------------------------------------------------------------------------------------------
+struct Tri {
+    uint32_t v[3];
+    uint32_t material;
+    int32_t lightIndex;   // index in the aggregate's light list, -1 if not emitting
+};
+
+struct Ray {
+    V3 org, dir;
+    float distMin, distMax;
+};
+
+struct Isect {             // Core/geometry.h:206-221 (fields the path uses)
+    float dist;
+    V3 p;
+    V3 gNormal;
+    float u, v;
+    uint32_t tri;
+    bool atInfinity;
+    Isect() : dist(INFINITY), u(0), v(0), tri(0xFFFFFFFFu), atInfinity(false) {}
+};
+
+struct SurfPt {            // Core/geometry.h:239-258
+    V3 p;
+    bool atInfinity;
+    V3 gNormal;
+    float u, v;
+    Frame frame;
+    uint32_t tri;          // obj
+};
+
+struct BVHNode {
+    float bmin[3], bmax[3];
+    uint32_t left;         // inner: left child (right = left + 1); leaf: first triangle slot
+    uint32_t count;        // 0 = inner
+};
+
+struct Camera {            // Cameras/PerspectiveCamera.h:17-29 + its StaticTransform
+    float mat[16], matInv[16];    // column-major
+    float aspect, fovY, lensRadius, imgPlaneDistance, objPlaneDistance;
+    float opWidth, opHeight, imgPlaneArea;
+    float sensitivity;
+};
+
+} // namespace
+
+struct slr_oracle_scene {
+    int mode;
+    std::vector<slrhip_vertex> vertices;
+    std::vector<Tri> tris;
+    std::vector<slrhip_material> materials;
+    std::vector<slrhip_spectrum> spectra;
+    std::vector<float> spectrumData;
+    Camera camera;
+    std::vector<uint32_t> lightTris;   // SurfaceObjectAggregate::m_lightList (SurfaceObject.cpp:232-249)
+    Discrete1D lightDist;              // m_lightDist1D
+    std::vector<BVHNode> nodes;
+    std::vector<uint32_t> triOrder;
+    bool hasEnv;
+};
+
+namespace {
+
+typedef slr_oracle_scene Scene;
+
+inline V3 vpos(const Scene& s, uint32_t vi) { const float* p = s.vertices[vi].position; return V3(p[0], p[1], p[2]); }
+inline V3 vnrm(const Scene& s, uint32_t vi) { const float* p = s.vertices[vi].normal; return V3(p[0], p[1], p[2]); }
+inline V3 vtan(const Scene& s, uint32_t vi) { const float* p = s.vertices[vi].tangent; return V3(p[0], p[1], p[2]); }
+
+// ------------------------------------------------------------------------------------------
+// Accelerator (oracle's own): binary BVH, median split on the widest centroid axis.
+// ------------------------------------------------------------------------------------------
+void buildBVH(Scene& s) {
+    uint32_t n = (uint32_t)s.tris.size();
+    s.triOrder.resize(n);
+    std::vector<float> cen(3 * (size_t)n), bmin(3 * (size_t)n), bmax(3 * (size_t)n);
+    for (uint32_t i = 0; i < n; ++i) {
+        s.triOrder[i] = i;
+        for (int a = 0; a < 3; ++a) {
+            float p0 = vpos(s, s.tris[i].v[0])[a], p1 = vpos(s, s.tris[i].v[1])[a], p2 = vpos(s, s.tris[i].v[2])[a];
+            float lo = std::fmin(p0, std::fmin(p1, p2)), hi = std::fmax(p0, std::fmax(p1, p2));
+            bmin[3 * (size_t)i + a] = lo; bmax[3 * (size_t)i + a] = hi; cen[3 * (size_t)i + a] = 0.5f * (lo + hi);
+        }
+    }
+    s.nodes.clear();
+    s.nodes.reserve(2 * (size_t)n);
+    struct Job { uint32_t node, begin, end; };
+    std::vector<Job> stack;
+    s.nodes.push_back(BVHNode());
+    stack.push_back({0, 0, n});
+    while (!stack.empty()) {
+        Job j = stack.back(); stack.pop_back();
+        BVHNode nd;
+        float cmin[3] = {INFINITY, INFINITY, INFINITY}, cmax[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int a = 0; a < 3; ++a) { nd.bmin[a] = INFINITY; nd.bmax[a] = -INFINITY; }
+        for (uint32_t k = j.begin; k < j.end; ++k) {
+            uint32_t t = s.triOrder[k];
+            for (int a = 0; a < 3; ++a) {
+                nd.bmin[a] = std::fmin(nd.bmin[a], bmin[3 * (size_t)t + a]);
+                nd.bmax[a] = std::fmax(nd.bmax[a], bmax[3 * (size_t)t + a]);
+                cmin[a] = std::fmin(cmin[a], cen[3 * (size_t)t + a]);
+                cmax[a] = std::fmax(cmax[a], cen[3 * (size_t)t + a]);
+            }
+        }
+        uint32_t cnt = j.end - j.begin;
+        int axis = 0;
+        float ext = cmax[0] - cmin[0];
+        for (int a = 1; a < 3; ++a) if (cmax[a] - cmin[a] > ext) { ext = cmax[a] - cmin[a]; axis = a; }
+        if (cnt <= 4 || !(ext > 0.0f)) {
+            nd.left = j.begin; nd.count = cnt;
+            s.nodes[j.node] = nd;
+            continue;
+        }
+        uint32_t mid = j.begin + cnt / 2;
+        std::nth_element(s.triOrder.begin() + j.begin, s.triOrder.begin() + mid, s.triOrder.begin() + j.end,
+                         [&](uint32_t a, uint32_t b) {
+                             float ca = cen[3 * (size_t)a + axis], cb = cen[3 * (size_t)b + axis];
+                             return ca < cb || (ca == cb && a < b);
+                         });
+        nd.left = (uint32_t)s.nodes.size(); nd.count = 0;
+        s.nodes[j.node] = nd;
+        s.nodes.push_back(BVHNode()); s.nodes.push_back(BVHNode());
+        stack.push_back({nd.left, j.begin, mid});
+        stack.push_back({nd.left + 1, mid, j.end});
+    }
+}
+
+// Core/geometry.h:112-126 BoundingBox3D::intersect (slab test)
+inline bool boxHit(const BVHNode& nd, const Ray& r, V3 invDir) {
+    float dist0 = r.distMin, dist1 = r.distMax;
+    for (int i = 0; i < 3; ++i) {
+        float tNear = (nd.bmin[i] - r.org[i]) * invDir[i];
+        float tFar = (nd.bmax[i] - r.org[i]) * invDir[i];
+        if (tNear > tFar) std::swap(tNear, tFar);
+        dist0 = tNear > dist0 ? tNear : dist0;
+        dist1 = tFar < dist1 ? tFar : dist1;
+        if (dist0 > dist1) return false;
+    }
+    return true;
+}
+
+// Surface/TriangleMesh.cpp:131-178  Triangle::intersect (Moller-Trumbore, no culling).
+// Returns true and fills *isect when the hit is accepted under the closest-hit rule;
+// ties at equal distance: larger triangle index wins (see file header).
+inline bool triIntersect(const Scene& s, uint32_t ti, const Ray& ray, Isect* isect) {
+    const Tri& tri = s.tris[ti];
+    V3 p0 = vpos(s, tri.v[0]), p1 = vpos(s, tri.v[1]), p2 = vpos(s, tri.v[2]);
+    V3 edge01 = p1 - p0;
+    V3 edge02 = p2 - p0;
+    V3 p = cross(ray.dir, edge02);
+    float det = dot(edge01, p);
+    if (det == 0.0f) return false;
+    float invDet = 1.0f / det;
+    V3 d = ray.org - p0;
+    float b1 = dot(d, p) * invDet;
+    if (b1 < 0.0f || b1 > 1.0f) return false;
+    V3 q = cross(d, edge01);
+    float b2 = dot(ray.dir, q) * invDet;
+    if (b2 < 0.0f || b1 + b2 > 1.0f) return false;
+    float tt = dot(edge02, q) * invDet;
+    if (tt < ray.distMin || tt > ray.distMax) return false;
+    if (tt == ray.distMax && isect->tri != 0xFFFFFFFFu && ti < isect->tri) return false;  // tie rule
+    float b0 = 1.0f - b1 - b2;
+    isect->dist = tt;
+    isect->p = ray.org + ray.dir * tt;
+    isect->gNormal = normalize(cross(edge01, edge02));
+    isect->u = b0;
+    isect->v = b1;
+    isect->tri = ti;
+    isect->atInfinity = false;
+    return true;
+}
+
+// SurfaceObjectAggregate::intersect -> Accelerator::intersect (Core/SurfaceObject.cpp:267-269).
+// On every accepted hit ray.distMax = isect->dist (SBVH.h:417-442 / QBVH.h:334-336).
+bool aggregateIntersect(const Scene& s, Ray& ray, Isect* isect, slr_oracle_counters* ctr) {
+    V3 invDir(1.0f / ray.dir.x, 1.0f / ray.dir.y, 1.0f / ray.dir.z);   // Vector3.h:60 reciprocal()
+    uint32_t stack[128];
+    int sp = 0;
+    stack[sp++] = 0;
+    bool any = false;
+    while (sp > 0) {
+        const BVHNode& nd = s.nodes[stack[--sp]];
+        if (ctr) ++ctr->nodes_visited;
+        if (!boxHit(nd, ray, invDir)) continue;
+        if (nd.count) {
+            for (uint32_t k = 0; k < nd.count; ++k) {
+                if (ctr) ++ctr->tris_tested;
+                if (triIntersect(s, s.triOrder[nd.left + k], ray, isect)) { ray.distMax = isect->dist; any = true; }
+            }
+        }
+        else {
+            stack[sp++] = nd.left;
+            stack[sp++] = nd.left + 1;
+        }
+    }
+    return any;
+}
+
+// Surface/InfiniteSphere.cpp:34-46 is added with the environment light (SLRHIP env, later row).
+
+// Core/SurfaceObject.cpp:408-416  Scene::intersect
+bool sceneIntersect(const Scene& s, Ray& ray, Isect* isect, slr_oracle_counters* ctr) {
+    if (ctr) ++ctr->extension_rays;
+    if (aggregateIntersect(s, ray, isect, ctr)) return true;
+    return false;
+}
+
+// Surface/TriangleMesh.cpp:180-215  Triangle::getSurfacePoint (+ SingleSurfaceObject :60-63).
+// texCoord / texCoord0Dir are not restated: no texture or anisotropic lobe on this path reads them.
+void getSurfacePoint(const Scene& s, const Isect& isect, SurfPt* sp) {
+    sp->p = isect.p;
+    sp->atInfinity = false;
+    sp->gNormal = isect.gNormal;
+    sp->u = isect.u;
+    sp->v = isect.v;
+    const Tri& tri = s.tris[isect.tri];
+    float b0 = isect.u, b1 = isect.v;
+    float b2 = 1.0f - b0 - b1;
+    sp->frame.z = normalize(b0 * vnrm(s, tri.v[0]) + b1 * vnrm(s, tri.v[1]) + b2 * vnrm(s, tri.v[2]));
+    sp->frame.x = normalize(b0 * vtan(s, tri.v[0]) + b1 * vtan(s, tri.v[1]) + b2 * vtan(s, tri.v[2]));
+    float dotNT = dot(sp->frame.z, sp->frame.x);
+    if (std::fabs(dotNT) >= 0.01f)
+        sp->frame.x = normalize(sp->frame.x - dotNT * sp->frame.z);
+    sp->frame.y = cross(sp->frame.z, sp->frame.x);
+    sp->tri = isect.tri;
+}
+
+// Surface/TriangleMesh.cpp:217-222  Triangle::area
+inline float triArea(const Scene& s, uint32_t ti) {
+    const Tri& tri = s.tris[ti];
+    V3 p0 = vpos(s, tri.v[0]), p1 = vpos(s, tri.v[1]), p2 = vpos(s, tri.v[2]);
+    return 0.5f * length(cross(p1 - p0, p2 - p0));
+}
+
+// Surface/TriangleMesh.cpp:224-255  Triangle::sample
+void triSample(const Scene& s, uint32_t ti, float u0, float u1, SurfPt* sp, float* areaPDF) {
+    float b0, b1, b2;
+    uniformSampleTriangle(u0, u1, &b0, &b1);
+    b2 = 1.0f - b0 - b1;
+    const Tri& tri = s.tris[ti];
+    V3 p0 = vpos(s, tri.v[0]), p1 = vpos(s, tri.v[1]), p2 = vpos(s, tri.v[2]);
+    sp->p = b0 * p0 + b1 * p1 + b2 * p2;
+    sp->atInfinity = false;
+    sp->gNormal = normalize(cross(p1 - p0, p2 - p0));    // Vector3::normalize(): same reciprocal multiply
+    sp->u = b0;
+    sp->v = b1;
+    sp->frame.z = normalize(b0 * vnrm(s, tri.v[0]) + b1 * vnrm(s, tri.v[1]) + b2 * vnrm(s, tri.v[2]));
+    sp->frame.x = normalize(b0 * vtan(s, tri.v[0]) + b1 * vtan(s, tri.v[1]) + b2 * vtan(s, tri.v[2]));
+    sp->frame.y = cross(sp->frame.z, sp->frame.x);
+    sp->tri = ti;
+    *areaPDF = 1.0f / triArea(s, ti);
+}
+
+// Core/SurfaceObject.cpp:418-430  Scene::testVisibility (finite light point)
+bool testVisibility(const Scene& s, const SurfPt& shdP, const SurfPt& lightP, slr_oracle_counters* ctr) {
+    if (ctr) ++ctr->shadow_rays;
+    Ray ray;
+    if (lightP.atInfinity) {
+        ray.org = shdP.p; ray.dir = normalize(lightP.p); ray.distMin = 0.0001f; ray.distMax = FLT_MAX;
+    }
+    else {
+        float dist = length(shdP.p - lightP.p);                          // distance(lightP.p, shdP.p) Point3.h:99-101
+        ray.org = shdP.p;
+        ray.dir = (lightP.p - shdP.p) / dist;
+        ray.distMin = 0.0001f;
+        ray.distMax = dist * (1 - 0.0001f);
+    }
+    Isect isect;
+    return !aggregateIntersect(s, ray, &isect, ctr);
+}
+
+// ------------------------------------------------------------------------------------------
+// Spectra / materials (RGB mode: InputSpectrum = RGBTemplate, evaluate() returns itself,
+// RGBTypes.h:124-126; ConstantSpectrumTexture constant_textures.h:16-31)
+// ------------------------------------------------------------------------------------------
+inline Spec<3> evalSpectrumRGB(const Scene& s, int32_t idx) {
+    Spec<3> r;
+    const slrhip_spectrum& sp = s.spectra[idx];
+    r.c[0] = sp.rgb[0]; r.c[1] = sp.rgb[1]; r.c[2] = sp.rgb[2];
+    return r;
+}
+
+enum : uint32_t {   // Core/directional_distribution_functions.h:18-51
+    DT_LowFreq = 1 << 0, DT_HighFreq = 1 << 1, DT_Delta0D = 1 << 2, DT_Delta1D = 1 << 3,
+    DT_NonDelta = DT_LowFreq | DT_HighFreq, DT_Delta = DT_Delta0D | DT_Delta1D, DT_AllFreq = DT_NonDelta | DT_Delta,
+    DT_Reflection = 1 << 4, DT_Transmission = 1 << 5, DT_WholeSphere = DT_Reflection | DT_Transmission,
+    DT_All = DT_AllFreq | DT_WholeSphere, DT_Dispersive = 1 << 6
+};
+inline bool dtMatches(uint32_t type, uint32_t t) { uint32_t res = type & t; return (res & DT_WholeSphere) && (res & DT_AllFreq); } // :83
+inline bool dtIsDelta(uint32_t v) { return (v & DT_Delta) && !(v & DT_NonDelta); }        // :86
+inline bool dtIsDispersive(uint32_t v) { return (v & DT_Dispersive) != 0; }
+
+template <int N>
+struct BSDFQuery {   // DDF.h:118-126
+    V3 dir_sn, gNormal_sn;
+    int16_t wlHint;
+    uint32_t flags;
+};
+struct BSDFResult {  // DDF.h:140-146
+    V3 dir_sn;
+    float dirPDF;
+    uint32_t dirType;
+};
+
+// Per-hit BSDF (SurfacePoint::createBSDF geometry.cpp:56-58 -> material->getBSDF)
+template <int N>
+struct BSDF {
+    uint32_t kind;      // SLRHIP_MATERIAL_*
+    uint32_t type;      // DirectionType of the lobe
+    Spec<N> a, b, c;    // matte: a = R;  metal: a = coeffR, b = eta, c = k;  glass: a = coeff, b = etaExt, c = etaInt
+    float param;
+};
+
+// Core/directional_distribution_functions.cpp:68-78  FresnelConductor::evaluate
+template <int N>
+Spec<N> fresnelConductor(const Spec<N>& eta, const Spec<N>& k, float cosEnter) {
+    cosEnter = std::fabs(cosEnter);
+    float cosEnter2 = cosEnter * cosEnter;
+    Spec<N> _2EtaCosEnter = 2.0f * eta * cosEnter;
+    Spec<N> tmp_f = eta * eta + k * k;
+    Spec<N> tmp = tmp_f * cosEnter2;
+    Spec<N> Rparl2 = (tmp - _2EtaCosEnter + 1) / (tmp + _2EtaCosEnter + 1);
+    Spec<N> Rperp2 = (tmp_f - _2EtaCosEnter + cosEnter2) / (tmp_f + _2EtaCosEnter + cosEnter2);
+    return (Rparl2 + Rperp2) / 2.0f;
+}
+// DDF.cpp:155-159
+inline float fresnelEvalF(float etaEnter, float etaExit, float cosEnter, float cosExit) {
+    float Rparl = ((etaExit * cosEnter) - (etaEnter * cosExit)) / ((etaExit * cosEnter) + (etaEnter * cosExit));
+    float Rperp = ((etaEnter * cosEnter) - (etaExit * cosExit)) / ((etaEnter * cosEnter) + (etaExit * cosExit));
+    return (Rparl * Rparl + Rperp * Rperp) / 2.0f;
+}
+// DDF.cpp:90-111  FresnelDielectric::evaluate(cosEnter)
+template <int N>
+Spec<N> fresnelDielectric(const Spec<N>& etaExt, const Spec<N>& etaInt, float cosEnter) {
+    cosEnter = std::min(1.0f, std::max(-1.0f, cosEnter));     // std::clamp defines.h:118-121
+    bool entering = cosEnter > 0.0f;
+    const Spec<N>& eEnter = entering ? etaExt : etaInt;
+    const Spec<N>& eExit = entering ? etaInt : etaExt;
+    Spec<N> sinExit = eEnter / eExit * std::sqrt(std::fmax(0.0f, 1.0f - cosEnter * cosEnter));
+    Spec<N> ret;
+    cosEnter = std::fabs(cosEnter);
+    for (int i = 0; i < N; ++i) {
+        if (sinExit[i] >= 1.0f) ret[i] = 1.0f;
+        else {
+            float cosExit = std::sqrt(std::fmax(0.0f, 1.0f - sinExit[i] * sinExit[i]));
+            ret[i] = fresnelEvalF(eEnter[i], eExit[i], cosEnter, cosExit);
+        }
+    }
+    return ret;
+}
+
+// sampleInternal of each lobe.  Returns fs_sn; result->dirPDF == 0 signals failure.
+template <int N>
+Spec<N> bsdfSampleInternal(const BSDF<N>& f, const BSDFQuery<N>& q, float uComponent, const float uDir[2], BSDFResult* result) {
+    switch (f.kind) {
+    case SLRHIP_MATERIAL_MATTE: {
+        // BSDFs/basic_BSDFs.cpp:12-26  LambertianBRDF::sampleInternal
+        result->dir_sn = cosineSampleHemisphere(uDir[0], uDir[1]);
+        result->dirPDF = (float)((double)result->dir_sn.z / M_PI);
+        result->dirType = f.type;
+        result->dir_sn.z *= dot(q.dir_sn, q.gNormal_sn) > 0 ? 1 : -1;
+        return f.a / (float)M_PI;
+    }
+    case SLRHIP_MATERIAL_METAL: {
+        // basic_BSDFs.cpp:61-71  SpecularBRDF::sampleInternal
+        result->dir_sn = V3(-q.dir_sn.x, -q.dir_sn.y, q.dir_sn.z);
+        result->dirPDF = 1.0f;
+        result->dirType = f.type;
+        return f.a * fresnelConductor(f.b, f.c, q.dir_sn.z) / std::fabs(q.dir_sn.z);
+    }
+    case SLRHIP_MATERIAL_GLASS: {
+        // basic_BSDFs.cpp:95-149  SpecularBSDF::sampleInternal (query.flags == All, adjoint == false)
+        Spec<N> F = fresnelDielectric(f.b, f.c, q.dir_sn.z);
+        float reflectProb = importance(F, (uint16_t)q.wlHint);
+        if (uComponent < reflectProb) {
+            if (q.dir_sn.z == 0.0f) { result->dirPDF = 0.0f; return Spec<N>(); }
+            result->dir_sn = V3(-q.dir_sn.x, -q.dir_sn.y, q.dir_sn.z);
+            result->dirPDF = reflectProb;
+            result->dirType = DT_Reflection | DT_Delta0D;
+            return f.a * F / std::fabs(q.dir_sn.z);
+        }
+        else {
+            bool entering = q.dir_sn.z > 0.0f;
+            float eEnter = entering ? f.b[q.wlHint] : f.c[q.wlHint];
+            float eExit = entering ? f.c[q.wlHint] : f.b[q.wlHint];
+            float sinEnter2 = 1.0f - q.dir_sn.z * q.dir_sn.z;
+            float rrEta = eEnter / eExit;
+            float sinExit2 = rrEta * rrEta * sinEnter2;
+            if (sinExit2 >= 1.0f) { result->dirPDF = 0.0f; return Spec<N>(); }
+            float cosExit = std::sqrt(std::fmax(0.0f, 1.0f - sinExit2));
+            if (entering) cosExit = -cosExit;
+            result->dir_sn = V3(rrEta * -q.dir_sn.x, rrEta * -q.dir_sn.y, cosExit);
+            result->dirPDF = 1.0f - reflectProb;
+            result->dirType = DT_Transmission | DT_Delta0D | (dtIsDispersive(f.type) ? (uint32_t)DT_Dispersive : 0u);
+            Spec<N> ret;
+            ret[q.wlHint] = f.a[q.wlHint] * (1.0f - F[q.wlHint]);
+            ret[q.wlHint] *= (eEnter * eEnter) / (eExit * eExit);
+            return ret / std::fabs(cosExit);
+        }
+    }
+    default:
+        result->dirPDF = 0.0f;
+        return Spec<N>();
+    }
+}
+
+// DDF.h:231-246  BSDF::sample (query.flags = All, adjoint = false)
+template <int N>
+Spec<N> bsdfSample(const BSDF<N>& f, const BSDFQuery<N>& q, float uComponent, const float uDir[2], BSDFResult* result) {
+    if (!dtMatches(f.type, q.flags)) { result->dirPDF = 0.0f; result->dirType = 0; return Spec<N>(); }
+    result->dirPDF = 0.0f;
+    Spec<N> fs_sn = bsdfSampleInternal(f, q, uComponent, uDir, result);
+    if (result->dirPDF == 0.0f)   // reference multiplies by a correction of an unset direction; the caller breaks on dirPDF == 0
+        return Spec<N>();
+    float snCorrection = std::fabs(result->dir_sn.z / dot(result->dir_sn, q.gNormal_sn));
+    return fs_sn * snCorrection;
+}
+
+// DDF.h:247-267  BSDF::evaluate
+template <int N>
+Spec<N> bsdfEvaluate(const BSDF<N>& f, const BSDFQuery<N>& q, V3 dir) {
+    bool reflect = dot(q.gNormal_sn, q.dir_sn) * dot(q.gNormal_sn, dir) > 0;      // sideTest DDF.h:213-216
+    uint32_t flags = q.flags & (DT_AllFreq | (reflect ? DT_Reflection : DT_Transmission));
+    if (!dtMatches(f.type, flags)) return Spec<N>();
+    Spec<N> fs_sn;
+    switch (f.kind) {
+    case SLRHIP_MATERIAL_MATTE:
+        // basic_BSDFs.cpp:28-39  LambertianBRDF::evaluateInternal
+        if (q.dir_sn.z * dir.z <= 0.0f) fs_sn = Spec<N>();
+        else fs_sn = f.a / (float)M_PI;
+        break;
+    default:   // SpecularBRDF / SpecularBSDF::evaluateInternal return Zero (basic_BSDFs.cpp:73-77,151-155)
+        fs_sn = Spec<N>();
+        break;
+    }
+    float snCorrection = std::fabs(dir.z / dot(dir, q.gNormal_sn));
+    return fs_sn * snCorrection;
+}
+
+// DDF.h:268-279  BSDF::evaluatePDF
+template <int N>
+float bsdfEvaluatePDF(const BSDF<N>& f, const BSDFQuery<N>& q, V3 dir) {
+    if (!dtMatches(f.type, q.flags)) return 0;
+    switch (f.kind) {
+    case SLRHIP_MATERIAL_MATTE:
+        // basic_BSDFs.cpp:41-50
+        if (q.dir_sn.z * dir.z <= 0.0f) return 0.0f;
+        return (float)((double)std::abs(dir.z) / M_PI);
+    default:
+        return 0.0f;
+    }
+}
+
+// SurfacePoint::createBSDF (geometry.cpp:56-58) -> SurfaceMaterial::getBSDF
+// (basic_SurfaceMaterials.cpp:15-43; EmitterSurfaceMaterial forwards to its base material,
+//  surface_material.h:65).  `scale * spectrum` with scale = 1.0f is an exact multiply.
+BSDF<3> createBSDF(const Scene& s, const SurfPt& sp, uint16_t wlFlags) {
+    const slrhip_material& m = s.materials[s.tris[sp.tri].material];
+    BSDF<3> f;
+    f.kind = m.type;
+    f.param = m.param;
+    switch (m.type) {
+    case SLRHIP_MATERIAL_MATTE:
+        f.type = DT_Reflection | DT_LowFreq;                                   // basic_BSDFs.h:27
+        f.a = 1.0f * evalSpectrumRGB(s, m.spectrum[0]);
+        break;
+    case SLRHIP_MATERIAL_METAL:
+        f.type = DT_Reflection | DT_Delta0D;                                   // basic_BSDFs.h:43
+        f.a = 1.0f * evalSpectrumRGB(s, m.spectrum[0]);
+        f.b = evalSpectrumRGB(s, m.spectrum[1]);
+        f.c = evalSpectrumRGB(s, m.spectrum[2]);
+        break;
+    case SLRHIP_MATERIAL_GLASS:
+        // dispersive = !wls.lambdaSelected()  basic_SurfaceMaterials.cpp:42, basic_BSDFs.h:59-61
+        f.type = DT_Reflection | DT_Transmission | DT_Delta0D | ((wlFlags & 1) ? 0u : (uint32_t)DT_Dispersive);
+        f.a = 1.0f * evalSpectrumRGB(s, m.spectrum[0]);
+        f.b = evalSpectrumRGB(s, m.spectrum[1]);
+        f.c = evalSpectrumRGB(s, m.spectrum[2]);
+        break;
+    default:
+        f.type = 0;
+        break;
+    }
+    return f;
+}
+
+inline bool isEmitting(const Scene& s, uint32_t tri) { return s.materials[s.tris[tri].material].emittance >= 0; }
+inline Spec<3> emittance(const Scene& s, uint32_t tri) { return evalSpectrumRGB(s, s.materials[s.tris[tri].material].emittance); }
+// EDFs/basic_EDFs.cpp:19-23  DiffuseEDF::evaluate: `dir.z > 0 ? 1.0f / M_PI : 0.0f` (double) -> SampledSpectrum(float)
+inline Spec<3> diffuseEDFEvaluate(V3 dir) { return Spec<3>(dir.z > 0.0f ? (float)(1.0f / M_PI) : 0.0f); }
+
+// ------------------------------------------------------------------------------------------
+// Cameras/PerspectiveCamera.cpp
+// ------------------------------------------------------------------------------------------
+void setupCamera(Camera& c, const slrhip_camera& in) {
+    std::memcpy(c.mat, in.local_to_world, sizeof(c.mat));
+    std::memcpy(c.matInv, in.world_to_local, sizeof(c.matInv));
+    c.aspect = in.aspect; c.fovY = in.fov_y; c.lensRadius = in.lens_radius;
+    c.imgPlaneDistance = in.img_plane_distance; c.objPlaneDistance = in.obj_plane_distance;
+    // :15-24
+    c.opHeight = 2.0f * c.objPlaneDistance * std::tan(c.fovY * 0.5f);
+    c.opWidth = c.opHeight * c.aspect;
+    c.imgPlaneArea = (float)((double)(c.opWidth * c.opHeight) * std::pow((double)(c.imgPlaneDistance / c.objPlaneDistance), 2.0));
+    c.sensitivity = in.sensitivity > 0 ? in.sensitivity : (float)(1.0f / (M_PI * (double)c.lensRadius * (double)c.lensRadius));
+}
+
+// Matrix4x4.h:75-81  mat * Point3 (column-major m[c*4+r])
+inline V3 mulPoint(const float* m, V3 p) {
+    float x = m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12] * 1.0f;
+    float y = m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13] * 1.0f;
+    float z = m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14] * 1.0f;
+    float w = m[3] * p.x + m[7] * p.y + m[11] * p.z + m[15] * 1.0f;
+    if (w != 1.0f) { float r = 1.0f / w; x *= r; y *= r; z *= r; }
+    return V3(x, y, z);
+}
+inline V3 mulVector(const float* m, V3 v) {   // Matrix4x4.h:71-73
+    return V3(m[0] * v.x + m[4] * v.y + m[8] * v.z, m[1] * v.x + m[5] * v.y + m[9] * v.z, m[2] * v.x + m[6] * v.y + m[10] * v.z);
+}
+inline V3 mulNormal(const float* mi, V3 n) {  // Transform.h:47-52 (rows of the inverse)
+    return V3(mi[0] * n.x + mi[1] * n.y + mi[2] * n.z, mi[4] * n.x + mi[5] * n.y + mi[6] * n.z, mi[8] * n.x + mi[9] * n.y + mi[10] * n.z);
+}
+
+// ------------------------------------------------------------------------------------------
+// Scene light selection (Core/SurfaceObject.cpp:279-299, 432-466)
+// ------------------------------------------------------------------------------------------
+inline uint32_t selectLight(const Scene& s, float u, float* prob) {
+    uint32_t lIdx = s.lightDist.sample(u, prob);      // remapped u is unused by SingleSurfaceObject::selectLight
+    *prob *= 1.0f;                                    // cProb = 1 (SurfaceObject.cpp:73-76)
+    return s.lightTris[lIdx];
+}
+inline float evaluateLightProb(const Scene& s, uint32_t tri) {
+    int32_t li = s.tris[tri].lightIndex;
+    if (li < 0) return 0.0f;
+    return s.lightDist.PMF[li] * 1.0f;
+}
+
+// ------------------------------------------------------------------------------------------
+// Renderers/PathTracingRenderer.cpp:137-262  Job::contribution
+// ------------------------------------------------------------------------------------------
+Spec<3> contribution(const Scene& scene, uint16_t selectedLambda, uint16_t wlFlagsInit, const Ray& initRay, XorShift& rng,
+                     slr_oracle_counters* ctr) {
+    uint16_t wlFlags = wlFlagsInit;
+    Ray ray = initRay;
+    SurfPt surfPt;
+    Spec<3> alpha(1.0f);
+    float initY = importance(alpha, selectedLambda);
+    Kahan<Spec<3>> sp;
+    uint32_t pathLength = 0;
+
+    Isect isect;
+    if (!sceneIntersect(scene, ray, &isect, ctr)) return Spec<3>();
+    getSurfacePoint(scene, isect, &surfPt);
+
+    V3 dirOut_sn = surfPt.frame.toLocal(-ray.dir);
+    if (isEmitting(scene, surfPt.tri)) {
+        Spec<3> Le = emittance(scene, surfPt.tri) * diffuseEDFEvaluate(dirOut_sn);
+        sp.add(alpha * Le);
+    }
+    if (surfPt.atInfinity) return sp.result;
+
+    while (true) {
+        ++pathLength;
+        if (pathLength >= 100) break;
+        if (ctr) ++ctr->loop_iterations;
+        V3 gNorm_sn = surfPt.frame.toLocal(surfPt.gNormal);
+        BSDF<3> bsdf = createBSDF(scene, surfPt, wlFlags);
+        BSDFQuery<3> fsQuery;
+        fsQuery.dir_sn = dirOut_sn; fsQuery.gNormal_sn = gNorm_sn; fsQuery.wlHint = (int16_t)selectedLambda; fsQuery.flags = DT_All;
+
+        // Next Event Estimation  :169-204
+        if (dtMatches(bsdf.type, DT_WholeSphere | DT_NonDelta)) {
+            float lightProb;
+            uint32_t lightTri = selectLight(scene, rng.getFloat0cTo1o(), &lightProb);
+            float lu0 = rng.getFloat0cTo1o();
+            float lu1 = rng.getFloat0cTo1o();
+            SurfPt lp; float areaPDF;
+            triSample(scene, lightTri, lu0, lu1, &lp, &areaPDF);
+            Spec<3> M = emittance(scene, lightTri);                    // SingleSurfaceObject::sample :82-91
+
+            if (testVisibility(scene, surfPt, lp, ctr)) {
+                // SurfacePoint::getDirectionFrom geometry.cpp:32-43
+                V3 d = lp.p - surfPt.p;
+                float dist2 = sqLength(d);
+                V3 shadowDir = d / std::sqrt(dist2);
+                V3 shadowDir_l = lp.frame.toLocal(-shadowDir);
+                V3 shadowDir_sn = surfPt.frame.toLocal(shadowDir);
+
+                Spec<3> Le = M * diffuseEDFEvaluate(shadowDir_l);
+                float lightPDF = lightProb * areaPDF;
+
+                Spec<3> fs = bsdfEvaluate(bsdf, fsQuery, shadowDir_sn);
+                float cosLight = absDot(-shadowDir, lp.gNormal);
+                float bsdfPDF = bsdfEvaluatePDF(bsdf, fsQuery, shadowDir_sn) * cosLight / dist2;
+
+                float MISWeight = 1.0f;
+                if (!std::isinf(areaPDF))    // posType = LowFreq is never delta (SurfaceObject.cpp:88)
+                    MISWeight = (lightPDF * lightPDF) / (lightPDF * lightPDF + bsdfPDF * bsdfPDF);
+
+                float G = absDot(shadowDir_sn, gNorm_sn) * cosLight / dist2;
+                sp.add(alpha * Le * fs * (G * MISWeight / lightPDF));
+            }
+        }
+
+        // BSDF sampling :206-221
+        BSDFResult fsResult;
+        float uComp = rng.getFloat0cTo1o();
+        float uDir[2];
+        uDir[0] = rng.getFloat0cTo1o();
+        uDir[1] = rng.getFloat0cTo1o();
+        Spec<3> fs = bsdfSample(bsdf, fsQuery, uComp, uDir, &fsResult);
+        if (fs.isZero() || fsResult.dirPDF == 0.0f) break;
+        if (dtIsDispersive(fsResult.dirType)) {
+            fsResult.dirPDF /= 3;                   // WavelengthSamples::NumComponents (RGBTypes.h:47-48)
+            wlFlags |= 1;                           // LambdaIsSelected
+        }
+        alpha = alpha * (fs * absDot(fsResult.dir_sn, gNorm_sn) / fsResult.dirPDF);
+
+        V3 dirIn = surfPt.frame.fromLocal(fsResult.dir_sn);
+        ray.org = surfPt.p; ray.dir = dirIn; ray.distMin = 0.0001f; ray.distMax = INFINITY;
+
+        isect = Isect();
+        if (!sceneIntersect(scene, ray, &isect, ctr)) break;
+        getSurfacePoint(scene, isect, &surfPt);
+
+        dirOut_sn = surfPt.frame.toLocal(-ray.dir);
+
+        // implicit light sampling :232-249
+        if (isEmitting(scene, surfPt.tri)) {
+            float bsdfPDF = fsResult.dirPDF;
+            Spec<3> Le = emittance(scene, surfPt.tri) * diffuseEDFEvaluate(dirOut_sn);
+            float lightProb = evaluateLightProb(scene, surfPt.tri);
+            float dist2 = sqLength(ray.org - surfPt.p);                    // sqDistance(p, shadingPoint)
+            float lightPDF = lightProb * (1.0f / triArea(scene, surfPt.tri)) * dist2 / absDot(ray.dir, surfPt.gNormal);
+            float MISWeight = 1.0f;
+            if (!dtIsDelta(fsResult.dirType))
+                MISWeight = (bsdfPDF * bsdfPDF) / (lightPDF * lightPDF + bsdfPDF * bsdfPDF);
+            sp.add(alpha * Le * MISWeight);
+        }
+        if (surfPt.atInfinity) break;
+
+        // Russian roulette :254-258
+        float continueProb = std::min(importance(alpha, selectedLambda) / initY, 1.0f);
+        if (rng.getFloat0cTo1o() < continueProb) alpha = alpha / continueProb;
+        else break;
+    }
+    return sp.result;
+}
+
+// ------------------------------------------------------------------------------------------
+// Renderers/PathTracingRenderer.cpp:100-135  Job::kernel body for ONE pixel sample.
+// Draw order is left to right (the pinned clang build).
+// ------------------------------------------------------------------------------------------
+void pixelSample(const Scene& scene, const slrhip_render_settings& st, uint32_t basePixelX, uint32_t basePixelY, XorShift& rng,
+                 slr_oracle_counters* ctr, float* px, float* py, Spec<3>* out) {
+    const Camera& cam = scene.camera;
+    float v = rng.getFloat0cTo1o();
+    float time = st.time_start * (1 - v) + st.time_end * v;                 // light_path_samplers.h:50
+    (void)time;
+    float pxx = basePixelX + rng.getFloat0cTo1o();                          // :51 (uint32 + float)
+    float pyy = basePixelY + rng.getFloat0cTo1o();
+
+    // RGBSamplesTemplate::createWithEqualOffsets RGBTypes.h:37-45 (two draws, offset unused)
+    float wlOffset = rng.getFloat0cTo1o(); (void)wlOffset;
+    float uLambda = rng.getFloat0cTo1o();
+    uint16_t selectedLambda = std::min(uint16_t(3 * uLambda), uint16_t(2));
+    float selectWLPDF = 1;
+
+    // camera->sample PerspectiveCamera.cpp:33-57
+    float lu0 = rng.getFloat0cTo1o();
+    float lu1 = rng.getFloat0cTo1o();
+    float lx, ly;
+    concentricSampleDisk(lu0, lu1, &lx, &ly);
+    V3 orgLocal(cam.lensRadius * lx, cam.lensRadius * ly, 0.0f);
+    V3 lensP = mulPoint(cam.mat, orgLocal);
+    V3 lensN = mulNormal(cam.matInv, V3(0, 0, 1));
+    Frame lensFrame;
+    lensFrame.z = lensN;
+    lensFrame.x = mulVector(cam.mat, V3(1, 0, 0));
+    lensFrame.y = cross(lensFrame.z, lensFrame.x);
+    float areaPDF = cam.lensRadius > 0.0f ? (float)(1.0f / (M_PI * (double)cam.lensRadius * (double)cam.lensRadius)) : 1.0f;
+
+    // createIDF :59-61, PerspectiveIDF::sample :63-74 with IDFSample(p.x / W, p.y / H) (PathTracingRenderer.cpp:115)
+    float sx = pxx / (float)(uint32_t)st.image_width;
+    float sy = pyy / (float)(uint32_t)st.image_height;
+    V3 idfOrg(cam.lensRadius * lx, cam.lensRadius * ly, 0.0f);
+    V3 pFocus(cam.opWidth * (0.5f - sx), cam.opHeight * (0.5f - sy), cam.objPlaneDistance);
+    V3 dirLocal = normalize(pFocus - idfOrg);
+    float dirPDF = cam.imgPlaneDistance * cam.imgPlaneDistance / ((dirLocal.z * dirLocal.z * dirLocal.z) * cam.imgPlaneArea);
+
+    Ray ray;
+    ray.org = lensP;
+    ray.dir = lensFrame.fromLocal(dirLocal);
+    ray.distMin = 0.0f;
+    ray.distMax = INFINITY;
+    Spec<3> C = contribution(scene, selectedLambda, 0, ray, rng, ctr);
+
+    // :126  weight = (We0 * We1) * (absDot(ray.dir, gNormal) / (areaPDF * dirPDF * selectWLPDF))
+    Spec<3> weight = (Spec<3>(1.0f) * Spec<3>(1.0f)) * (absDot(ray.dir, lensN) / (areaPDF * dirPDF * selectWLPDF));
+    *out = weight * C;
+    *px = pxx;
+    *py = pyy;
+}
+
+int32_t sampleSeed(int32_t rngSeed, uint32_t px, uint32_t py, uint32_t pass) {
+    auto fmix = [](uint32_t h) { h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16; return h; };
+    uint32_t h = (uint32_t)rngSeed;
+    h = fmix(h ^ (pass * 0x9E3779B1u));
+    h = fmix(h ^ (py * 0x85EBCA77u + 0x165667B1u));
+    h = fmix(h ^ (px * 0xC2B2AE3Du + 0x27D4EB2Fu));
+    return (int32_t)h;
+}
+
+void addCounters(slr_oracle_counters* dst, const slr_oracle_counters& src) {
+    dst->samples += src.samples; dst->extension_rays += src.extension_rays; dst->shadow_rays += src.shadow_rays;
+    dst->loop_iterations += src.loop_iterations; dst->rng_draws += src.rng_draws;
+    dst->nodes_visited += src.nodes_visited; dst->tris_tested += src.tris_tested;
+}
+
+} // namespace
+
+extern "C" {
+
+slr_oracle_scene* slr_oracle_create(const slrhip_scene_desc* d, int mode) {
+    if (!d || !d->vertices || !d->triangles || !d->materials || d->num_triangles == 0) return nullptr;
+    if (mode != SLRHIP_MODE_RGB) return nullptr;   // spectral restatement: later row
+    Scene* s = new Scene();
+    s->mode = mode;
+    s->vertices.assign(d->vertices, d->vertices + d->num_vertices);
+    s->materials.assign(d->materials, d->materials + d->num_materials);
+    if (d->spectra) s->spectra.assign(d->spectra, d->spectra + d->num_spectra);
+    if (d->spectrum_data) s->spectrumData.assign(d->spectrum_data, d->spectrum_data + d->num_spectrum_data);
+    s->tris.resize(d->num_triangles);
+    std::vector<float> importances;
+    for (uint32_t i = 0; i < d->num_triangles; ++i) {
+        Tri& t = s->tris[i];
+        for (int k = 0; k < 3; ++k) t.v[k] = d->triangles[i].v[k];
+        t.material = d->triangles[i].material;
+        t.lightIndex = -1;
+        if (s->materials[t.material].emittance >= 0) {     // SurfaceObject.cpp:232-249
+            t.lightIndex = (int32_t)s->lightTris.size();
+            s->lightTris.push_back(i);
+            importances.push_back(1.0f);                   // SingleSurfaceObject::importance :69-71
+        }
+    }
+    s->lightDist.build(importances);
+    s->hasEnv = d->env != nullptr;
+    setupCamera(s->camera, d->camera);
+    buildBVH(*s);
+    return s;
+}
+
+void slr_oracle_destroy(slr_oracle_scene* s) { delete s; }
+
+int slr_oracle_components(const slr_oracle_scene* s) { return s->mode == SLRHIP_MODE_RGB ? 3 : 16; }
+
+int slr_oracle_render(slr_oracle_scene* s, const slrhip_render_settings* st, slrhip_shard shard, uint32_t sppBegin, uint32_t sppCount,
+                      int threads, float* fbSum, float* fbComp, slr_oracle_counters* counters) {
+    if (!s || !st || !fbSum || !fbComp || shard.shard_count == 0) return 1;
+    const uint32_t W = (uint32_t)st->image_width, H = (uint32_t)st->image_height;
+    const uint32_t tilesX = (W + 7) >> 3;                    // ImageSensor.cpp:43-44
+    if (threads <= 0) threads = (int)std::thread::hardware_concurrency();
+    if (threads <= 0) threads = 1;
+    std::atomic<uint32_t> nextRow(0);
+    std::vector<slr_oracle_counters> ctrs(threads);
+    std::memset(ctrs.data(), 0, sizeof(slr_oracle_counters) * threads);
+    auto worker = [&](int tid) {
+        slr_oracle_counters& c = ctrs[tid];
+        for (;;) {
+            uint32_t y = nextRow.fetch_add(1);
+            if (y >= H) break;
+            for (uint32_t x = 0; x < W; ++x) {
+                uint32_t tile = (y >> 3) * tilesX + (x >> 3);
+                if (tile % shard.shard_count != shard.shard_index) continue;
+                size_t o = ((size_t)y * W + x) * 3;
+                Kahan<Spec<3>> acc;
+                for (int k = 0; k < 3; ++k) { acc.result[k] = fbSum[o + k]; acc.comp[k] = fbComp[o + k]; }
+                for (uint32_t p = sppBegin; p < sppBegin + sppCount; ++p) {
+                    XorShift rng(sampleSeed(st->rng_seed, x, y, p), &c.rng_draws);
+                    float px, py; Spec<3> contrib;
+                    pixelSample(*s, *st, x, y, rng, &c, &px, &py, &contrib);
+                    acc.add(contrib);                                    // RGBStorage::add RGBTypes.h:176-179
+                    ++c.samples;
+                }
+                for (int k = 0; k < 3; ++k) { fbSum[o + k] = acc.result[k]; fbComp[o + k] = acc.comp[k]; }
+            }
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < threads; ++t) pool.emplace_back(worker, t);
+    worker(0);
+    for (auto& t : pool) t.join();
+    if (counters) for (int t = 0; t < threads; ++t) addCounters(counters, ctrs[t]);
+    return 0;
+}
+
+int slr_oracle_sample(slr_oracle_scene* s, const slrhip_render_settings* st, uint32_t px, uint32_t py, uint32_t pass, float* out) {
+    if (!s || !st || !out) return 1;
+    XorShift rng(sampleSeed(st->rng_seed, px, py, pass));
+    float fx, fy; Spec<3> contrib;
+    pixelSample(*s, *st, px, py, rng, nullptr, &fx, &fy, &contrib);
+    for (int k = 0; k < 3; ++k) out[k] = contrib[k];
+    out[3] = fx; out[4] = fy;
+    return 0;
+}
+
+int slr_oracle_trace(slr_oracle_scene* s, const slr_oracle_ray* rays, uint32_t n, slr_oracle_hit* hits) {
+    if (!s || !rays || !hits) return 1;
+    for (uint32_t i = 0; i < n; ++i) {
+        Ray r;
+        r.org = V3(rays[i].org[0], rays[i].org[1], rays[i].org[2]);
+        r.dir = V3(rays[i].dir[0], rays[i].dir[1], rays[i].dir[2]);
+        r.distMin = rays[i].dist_min; r.distMax = rays[i].dist_max;
+        Isect isect;
+        if (aggregateIntersect(*s, r, &isect, nullptr)) {
+            hits[i].triangle = isect.tri; hits[i].dist = isect.dist; hits[i].b0 = isect.u; hits[i].b1 = isect.v;
+        }
+        else {
+            hits[i].triangle = 0xFFFFFFFFu; hits[i].dist = INFINITY; hits[i].b0 = 0; hits[i].b1 = 0;
+        }
+    }
+    return 0;
+}
+
+void slr_oracle_rng(int32_t seed, uint32_t n, uint32_t* uints, float* floats) {
+    XorShift a(seed);
+    for (uint32_t i = 0; i < n; ++i) uints[i] = a.getUInt();
+    XorShift b(seed);
+    for (uint32_t i = 0; i < n; ++i) floats[i] = b.getFloat0cTo1o();
+}
+
+// PathTracingRenderer.cpp:27-98 with numThreads == 1: topRand(seed); sampler(topRand.getUInt());
+// passes outermost, tiles row-major (:74-79), pixels row-major inside a tile (:103-104).
+int slr_oracle_render_serial(slr_oracle_scene* s, const slrhip_render_settings* st, uint32_t spp, float* fbSum,
+                             slr_oracle_counters* counters) {
+    if (!s || !st || !fbSum) return 1;
+    const uint32_t W = (uint32_t)st->image_width, H = (uint32_t)st->image_height;
+    const uint32_t tilesX = (W + 7) >> 3, tilesY = (H + 7) >> 3;
+    XorShift topRand(st->rng_seed);
+    slr_oracle_counters c;
+    std::memset(&c, 0, sizeof(c));
+    XorShift rng((int32_t)topRand.getUInt(), &c.rng_draws);
+    std::vector<Kahan<Spec<3>>> fb((size_t)W * H);
+    for (uint32_t p = 0; p < spp; ++p)
+        for (uint32_t ty = 0; ty < tilesY; ++ty)
+            for (uint32_t tx = 0; tx < tilesX; ++tx)
+                for (uint32_t ly = 0; ly < 8; ++ly)
+                    for (uint32_t lx = 0; lx < 8; ++lx) {
+                        float px, py; Spec<3> contrib;
+                        pixelSample(*s, *st, tx * 8 + lx, ty * 8 + ly, rng, &c, &px, &py, &contrib);
+                        // ImageSensor::add ImageSensor.cpp:124-129
+                        uint32_t ipx = std::min((uint32_t)px, W - 1), ipy = std::min((uint32_t)py, H - 1);
+                        fb[(size_t)ipy * W + ipx].add(contrib);
+                        ++c.samples;
+                    }
+    for (size_t i = 0; i < fb.size(); ++i) for (int k = 0; k < 3; ++k) fbSum[i * 3 + k] = fb[i].result[k];
+    if (counters) addCounters(counters, c);
+    return 0;
+}
+
+} // extern "C"

@@ -1,0 +1,81 @@
+/*
+ * slr_oracle.h — C interface of the CPU ORACLE for the path-tracing hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product (slr_amd/, include/) may include,
+ * link or call this; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg do.  The same interface is implemented twice:
+ *   - oracle/slr_oracle.cpp      a scalar restatement of the reference algorithm
+ *                                (prefix slr_oracle_), travels to the GPU box;
+ *   - oracle/ref_build/ref_shim.cpp  the compiled reference libSLR itself driven through
+ *                                its C++ API (prefix slr_ref_), built into oracle/_ref/
+ *                                only where /root/reference exists.
+ * Both consume the flat scene of include/slrhip.h and the same per-(pixel,sample)
+ * seeding contract (slrhip_sample_seed), so their outputs are comparable bit for bit.
+ */
+#ifndef SLR_ORACLE_H
+#define SLR_ORACLE_H
+
+#include "../include/slrhip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct slr_oracle_scene slr_oracle_scene;
+
+typedef struct slr_oracle_counters {
+    uint64_t samples;
+    uint64_t extension_rays;   /* Scene::intersect calls      */
+    uint64_t shadow_rays;      /* Scene::testVisibility calls */
+    uint64_t loop_iterations;  /* bounce-loop bodies entered  */
+    uint64_t rng_draws;
+    uint64_t nodes_visited;    /* oracle's binary BVH (not comparable with the 4-wide tree) */
+    uint64_t tris_tested;
+} slr_oracle_counters;
+
+/* One ray of a traversal-only parity batch. */
+typedef struct slr_oracle_ray {
+    float org[3];
+    float dir[3];
+    float dist_min;
+    float dist_max;
+} slr_oracle_ray;
+typedef struct slr_oracle_hit {
+    uint32_t triangle;   /* 0xFFFFFFFF = miss */
+    float dist;
+    float b0, b1;        /* Intersection::u, ::v (TriangleMesh.cpp:172-173) */
+} slr_oracle_hit;
+
+#define SLR_ORACLE_DECLARE(P)                                                                      \
+    slr_oracle_scene* P##create(const slrhip_scene_desc* scene, int mode);                         \
+    void P##destroy(slr_oracle_scene* s);                                                          \
+    /* Passes [spp_begin, spp_begin+spp_count) of the shard's pixels, per-(pixel,sample) seeding.  \
+     * fb_sum / fb_comp: [H][W][C] Kahan sum and compensation (in/out; fresh render = zeros).      \
+     * threads <= 0: all hardware threads. Returns 0 on success.                               */ \
+    int P##render(slr_oracle_scene* s, const slrhip_render_settings* settings, slrhip_shard shard, \
+                  uint32_t spp_begin, uint32_t spp_count, int threads, float* fb_sum,              \
+                  float* fb_comp, slr_oracle_counters* counters);                                  \
+    /* One sample: out[0..C) = weight*C, out[C], out[C+1] = pixel position p.x, p.y.            */ \
+    int P##sample(slr_oracle_scene* s, const slrhip_render_settings* settings, uint32_t px,        \
+                  uint32_t py, uint32_t pass, float* out);                                         \
+    /* Closest-hit queries (Scene::intersect on the aggregate only).                           */ \
+    int P##trace(slr_oracle_scene* s, const slr_oracle_ray* rays, uint32_t n, slr_oracle_hit* hits);\
+    /* xorshift128 known answers: n raw uint32 draws then n float draws from `seed`.            */ \
+    void P##rng(int32_t seed, uint32_t n, uint32_t* uints, float* floats);                         \
+    int P##components(const slr_oracle_scene* s);
+
+SLR_ORACLE_DECLARE(slr_oracle_)
+SLR_ORACLE_DECLARE(slr_ref_)
+
+/* The reference's own serial mode (one xorshift stream over all pixels and passes, tiles in
+ * row-major order: PathTracingRenderer.cpp:33-38,72-81 with numThreads = 1).  Implemented by
+ * both so that the restatement can be pinned against the UNMODIFIED reference render().     */
+int slr_oracle_render_serial(slr_oracle_scene* s, const slrhip_render_settings* settings, uint32_t spp,
+                             float* fb_sum, slr_oracle_counters* counters);
+int slr_ref_render_serial(slr_oracle_scene* s, const slrhip_render_settings* settings, uint32_t spp,
+                          float* fb_sum, slr_oracle_counters* counters);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

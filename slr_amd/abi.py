@@ -1,0 +1,130 @@
+"""ctypes mirror of include/slrhip.h (the C ABI of the path-tracing hot path).
+
+Only plumbing lives here: struct layouts, library loading and a thin `Context`
+wrapper.  The same scene structs are consumed by three implementations of one
+interface: the HIP product library (slr_amd/csrc -> libslrhip.so), the CPU oracle
+(oracle/ -> libslr_oracle.so, tests/bench only) and, when built in the container
+that has /root/reference, the compiled reference itself (oracle/_ref).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+MODE_RGB, MODE_SPECTRAL = 0, 1
+MAT_MATTE, MAT_METAL, MAT_GLASS, MAT_MF_METAL, MAT_MF_GLASS = 0, 1, 2, 3, 4
+SPEC_RGB_ONLY, SPEC_UPSAMPLED, SPEC_REGULAR, SPEC_IRREGULAR = 0, 1, 2, 3
+
+# numpy dtypes with the exact layout of the C structs (checked in tests/test_abi.py)
+vertex_dtype = np.dtype([("position", "<f4", 3), ("normal", "<f4", 3), ("tangent", "<f4", 3),
+                         ("texcoord", "<f4", 2)])
+triangle_dtype = np.dtype([("v", "<u4", 3), ("material", "<u4")])
+material_dtype = np.dtype([("type", "<u4"), ("spectrum", "<i4", 3), ("param", "<f4"), ("emittance", "<i4")])
+spectrum_dtype = np.dtype([("kind", "<u4"), ("rgb", "<f4", 3), ("u", "<f4"), ("v", "<f4"), ("scale", "<f4"),
+                           ("lambda_min", "<f4"), ("lambda_max", "<f4"), ("num_samples", "<u4"),
+                           ("data_offset", "<u4"), ("reserved", "<u4")])
+
+
+class Camera(C.Structure):
+    _fields_ = [("local_to_world", C.c_float * 16), ("world_to_local", C.c_float * 16),
+                ("aspect", C.c_float), ("fov_y", C.c_float), ("lens_radius", C.c_float),
+                ("img_plane_distance", C.c_float), ("obj_plane_distance", C.c_float),
+                ("sensitivity", C.c_float)]
+
+
+class EnvMap(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("texels", C.c_void_p), ("scale", C.c_float)]
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [("vertices", C.c_void_p), ("num_vertices", C.c_uint32),
+                ("triangles", C.c_void_p), ("num_triangles", C.c_uint32),
+                ("materials", C.c_void_p), ("num_materials", C.c_uint32),
+                ("spectra", C.c_void_p), ("num_spectra", C.c_uint32),
+                ("spectrum_data", C.c_void_p), ("num_spectrum_data", C.c_uint32),
+                ("camera", Camera),
+                ("env", C.POINTER(EnvMap))]
+
+
+class RenderSettings(C.Structure):
+    _fields_ = [("image_width", C.c_int32), ("image_height", C.c_int32), ("time_start", C.c_float),
+                ("time_end", C.c_float), ("brightness", C.c_float), ("rng_seed", C.c_int32)]
+
+
+class Shard(C.Structure):
+    _fields_ = [("shard_index", C.c_uint32), ("shard_count", C.c_uint32)]
+
+
+class Config(C.Structure):
+    _fields_ = [("device", C.c_int32), ("mode", C.c_int32), ("stripes", C.c_uint32), ("flags", C.c_uint32)]
+
+
+class Counters(C.Structure):
+    _fields_ = [("samples", C.c_uint64), ("extension_rays", C.c_uint64), ("shadow_rays", C.c_uint64),
+                ("iterations", C.c_uint64), ("bvh_nodes", C.c_uint64), ("bvh_depth", C.c_uint64),
+                ("build_seconds", C.c_double)]
+
+
+DEFAULT_SEED = 1509761209  # libSLRSceneGraph/API.cpp:1080
+
+
+class Scene:
+    """Flat scene (numpy arrays) + the ctypes view handed across the ABI."""
+
+    def __init__(self, vertices, triangles, materials, spectra, spectrum_data, camera, env=None, name="scene"):
+        self.vertices = np.ascontiguousarray(vertices, dtype=vertex_dtype)
+        self.triangles = np.ascontiguousarray(triangles, dtype=triangle_dtype)
+        self.materials = np.ascontiguousarray(materials, dtype=material_dtype)
+        self.spectra = np.ascontiguousarray(spectra, dtype=spectrum_dtype)
+        self.spectrum_data = np.ascontiguousarray(spectrum_data, dtype=np.float32)
+        self.camera = camera
+        self.env_texels = None
+        self.env = None
+        if env is not None:
+            texels, scale = env
+            self.env_texels = np.ascontiguousarray(texels, dtype=np.float32)
+            self.env = EnvMap(self.env_texels.shape[1], self.env_texels.shape[0],
+                              self.env_texels.ctypes.data, float(scale))
+        self.name = name
+        self._validate()
+
+    def _validate(self):
+        nv, nm, ns = len(self.vertices), len(self.materials), len(self.spectra)
+        if len(self.triangles) == 0:
+            raise ValueError("scene has no triangles")
+        if self.triangles["v"].max() >= nv:
+            raise ValueError("triangle references a vertex out of range")
+        if self.triangles["material"].max() >= nm:
+            raise ValueError("triangle references a material out of range")
+        if self.materials["spectrum"].max() >= ns or self.materials["emittance"].max() >= ns:
+            raise ValueError("material references a spectrum out of range")
+
+    def desc(self):
+        d = SceneDesc()
+        d.vertices, d.num_vertices = self.vertices.ctypes.data, len(self.vertices)
+        d.triangles, d.num_triangles = self.triangles.ctypes.data, len(self.triangles)
+        d.materials, d.num_materials = self.materials.ctypes.data, len(self.materials)
+        d.spectra, d.num_spectra = self.spectra.ctypes.data, len(self.spectra)
+        d.spectrum_data, d.num_spectrum_data = self.spectrum_data.ctypes.data, len(self.spectrum_data)
+        d.camera = self.camera
+        d.env = C.pointer(self.env) if self.env is not None else None
+        return d
+
+
+def sample_seed(rng_seed, px, py, sample):
+    """Python restatement of slrhip_sample_seed (the per-(pixel,sample) seeding contract)."""
+    def fmix(h):
+        h &= 0xFFFFFFFF
+        h ^= h >> 16
+        h = (h * 0x85EBCA6B) & 0xFFFFFFFF
+        h ^= h >> 13
+        h = (h * 0xC2B2AE35) & 0xFFFFFFFF
+        h ^= h >> 16
+        return h
+    h = rng_seed & 0xFFFFFFFF
+    h = fmix(h ^ ((sample * 0x9E3779B1) & 0xFFFFFFFF))
+    h = fmix(h ^ ((py * 0x85EBCA77 + 0x165667B1) & 0xFFFFFFFF))
+    h = fmix(h ^ ((px * 0xC2B2AE3D + 0x27D4EB2F) & 0xFFFFFFFF))
+    return h - (1 << 32) if h & 0x80000000 else h

@@ -1,0 +1,219 @@
+"""Synthetic scene builders for the path-tracing hot path (numpy -> flat slrhip scene).
+
+Every BASELINE scene of the reference needs assets that are not shipped
+(models/*.assbin, images/*.exr: TestScenes/Cornell_Box_Spheres.txt:114,127), so the
+scenes are synthesised here and the SAME arrays are handed to the HIP library, the
+CPU oracle and the compiled reference (oracle/_ref).  This replaces, for the asset-free
+subset, what libSLRSceneGraph does before render() (createMesh TriangleMeshNode.cpp:68-112,
+static transforms baked into vertices, one SingleSurfaceObject per triangle).
+"""
+import math
+
+import numpy as np
+
+from . import abi
+
+
+def _translate(x, y, z):
+    m = np.eye(4)
+    m[:3, 3] = (x, y, z)
+    return m
+
+
+def _scale(s):
+    m = np.eye(4)
+    m[0, 0] = m[1, 1] = m[2, 2] = s
+    return m
+
+
+def _rotate(angle, axis):
+    # libSLR/BasicTypes/Matrix4x4.cpp:111-135 (right-handed axis-angle)
+    a = np.asarray(axis, dtype=np.float64)
+    a = a / np.linalg.norm(a)
+    c, s = math.cos(angle), math.sin(angle)
+    x, y, z = a
+    m = np.eye(4)
+    m[:3, :3] = [[x * x * (1 - c) + c, x * y * (1 - c) - z * s, z * x * (1 - c) + y * s],
+                 [x * y * (1 - c) + z * s, y * y * (1 - c) + c, y * z * (1 - c) - x * s],
+                 [z * x * (1 - c) - y * s, y * z * (1 - c) + x * s, z * z * (1 - c) + c]]
+    return m
+
+
+def make_camera(local_to_world, aspect, fov_y, lens_radius, img_dist, obj_dist, sensitivity=0.0):
+    cam = abi.Camera()
+    m = np.asarray(local_to_world, dtype=np.float64)
+    mi = np.linalg.inv(m)
+    # column-major storage like Matrix4x4Template (m[c*4+r])
+    cam.local_to_world[:] = m.T.astype(np.float32).reshape(-1).tolist()
+    cam.world_to_local[:] = mi.T.astype(np.float32).reshape(-1).tolist()
+    cam.aspect, cam.fov_y, cam.lens_radius = aspect, fov_y, lens_radius
+    cam.img_plane_distance, cam.obj_plane_distance, cam.sensitivity = img_dist, obj_dist, sensitivity
+    return cam
+
+
+class SceneBuilder:
+    def __init__(self):
+        self.vertices, self.triangles, self.materials, self.spectra, self.spectrum_data = [], [], [], [], []
+
+    # --- spectra --------------------------------------------------------------------
+    def spectrum_rgb(self, r, g, b, uvs=None):
+        """RGB-mode value (+ optional spectral descriptor filled in by slr_amd.spectra)."""
+        rec = np.zeros((), dtype=abi.spectrum_dtype)
+        rec["kind"] = abi.SPEC_RGB_ONLY
+        rec["rgb"] = (r, g, b)
+        self.spectra.append(rec)
+        return len(self.spectra) - 1
+
+    def spectrum_srgb_nonlinear(self, r, g, b):
+        """Spectrum(r, g, b) of the scene language: non-linear sRGB reflectance
+        (libSLRSceneGraph/API.cpp:62-63,295-296 -> sRGB_degamma, Spectrum.cpp:24-30)."""
+        def degamma(v):
+            v = np.float32(v)
+            if v <= 0.04045:
+                return np.float32(np.float64(v) / 12.92)
+            return np.float32(math.pow((np.float64(v) + 0.055) / 1.055, 2.4))
+        return self.spectrum_rgb(degamma(r), degamma(g), degamma(b))
+
+    # --- materials -----------------------------------------------------------------
+    def material(self, mtype, spectra=(-1, -1, -1), param=-1.0, emittance=-1):
+        rec = np.zeros((), dtype=abi.material_dtype)
+        rec["type"], rec["spectrum"], rec["param"], rec["emittance"] = mtype, spectra, param, emittance
+        self.materials.append(rec)
+        return len(self.materials) - 1
+
+    def matte(self, refl, sigma=-1.0, emittance=-1):
+        return self.material(abi.MAT_MATTE, (refl, -1, -1), sigma, emittance)
+
+    def metal(self, coeff, eta, k):
+        return self.material(abi.MAT_METAL, (coeff, eta, k))
+
+    def glass(self, coeff, eta_ext, eta_int):
+        return self.material(abi.MAT_GLASS, (coeff, eta_ext, eta_int))
+
+    def microfacet_metal(self, eta, k, alpha):
+        return self.material(abi.MAT_MF_METAL, (-1, eta, k), alpha)
+
+    def microfacet_glass(self, eta_ext, eta_int, alpha):
+        return self.material(abi.MAT_MF_GLASS, (-1, eta_ext, eta_int), alpha)
+
+    # --- geometry ------------------------------------------------------------------
+    def add_mesh(self, positions, normals, tangents, texcoords, faces, material, transform=None):
+        """createMesh + static transform baked into the vertices (TriangleMeshNode.cpp:68-78)."""
+        p = np.asarray(positions, dtype=np.float64)
+        n = np.asarray(normals, dtype=np.float64)
+        t = np.asarray(tangents, dtype=np.float64)
+        if transform is not None:
+            m = np.asarray(transform, dtype=np.float64)
+            p = p @ m[:3, :3].T + m[:3, 3]
+            n = n @ np.linalg.inv(m[:3, :3])          # normals: inverse transpose
+            n = n / np.linalg.norm(n, axis=1, keepdims=True)
+            t = t @ m[:3, :3].T
+            t = t / np.linalg.norm(t, axis=1, keepdims=True)
+        base = len(self.vertices)
+        for i in range(len(p)):
+            rec = np.zeros((), dtype=abi.vertex_dtype)
+            rec["position"], rec["normal"], rec["tangent"], rec["texcoord"] = p[i], n[i], t[i], texcoords[i]
+            self.vertices.append(rec)
+        for f in faces:
+            rec = np.zeros((), dtype=abi.triangle_dtype)
+            rec["v"] = (base + f[0], base + f[1], base + f[2])
+            rec["material"] = material
+            self.triangles.append(rec)
+
+    def add_quad(self, corners, normal, tangent, material, transform=None):
+        uv = [(0, 0), (1, 0), (1, 1), (0, 1)]
+        self.add_mesh(corners, [normal] * 4, [tangent] * 4, uv, [(0, 1, 2), (0, 2, 3)], material, transform)
+
+    def add_uv_sphere(self, segments, rings, material, transform=None):
+        """Unit sphere at the origin, y up; stands in for models/sphere.assbin."""
+        pos, nrm, tan, uv, faces = [], [], [], [], []
+        for r in range(rings + 1):
+            theta = math.pi * r / rings
+            for s in range(segments + 1):
+                phi = 2 * math.pi * s / segments
+                d = (math.sin(theta) * math.cos(phi), math.cos(theta), math.sin(theta) * math.sin(phi))
+                pos.append(d)
+                nrm.append(d)
+                tan.append((-math.sin(phi), 0.0, math.cos(phi)))
+                uv.append((s / segments, r / rings))
+        w = segments + 1
+        for r in range(rings):
+            for s in range(segments):
+                a, b, c, d = r * w + s, r * w + s + 1, (r + 1) * w + s + 1, (r + 1) * w + s
+                if r != 0:
+                    faces.append((a, b, c))
+                if r != rings - 1:
+                    faces.append((a, c, d))
+        self.add_mesh(pos, nrm, tan, uv, faces, material, transform)
+
+    def add_box(self, material, transform=None):
+        """Unit cube [-0.5,0.5]^3 as 6 quads (stands in for models/box.assbin)."""
+        faces = [((0, 0, 1), (1, 0, 0)), ((0, 0, -1), (-1, 0, 0)), ((1, 0, 0), (0, 0, -1)),
+                 ((-1, 0, 0), (0, 0, 1)), ((0, 1, 0), (1, 0, 0)), ((0, -1, 0), (1, 0, 0))]
+        for n, t in faces:
+            n, t = np.array(n, float), np.array(t, float)
+            b = np.cross(n, t)
+            c = [0.5 * n - 0.5 * t - 0.5 * b, 0.5 * n + 0.5 * t - 0.5 * b,
+                 0.5 * n + 0.5 * t + 0.5 * b, 0.5 * n - 0.5 * t + 0.5 * b]
+            self.add_quad(c, n, t, material, transform)
+
+    def build(self, camera, env=None, name="scene"):
+        return abi.Scene(np.array(self.vertices, dtype=abi.vertex_dtype),
+                         np.array(self.triangles, dtype=abi.triangle_dtype),
+                         np.array(self.materials, dtype=abi.material_dtype),
+                         np.array(self.spectra, dtype=abi.spectrum_dtype),
+                         np.array(self.spectrum_data, dtype=np.float32), camera, env, name)
+
+
+# RGB-mode constants of the scene's named spectra.  In the reference these come from
+# Spectrum::create's RGB branch (libSLRSceneGraph/API.cpp:1326-1347: integrate the table
+# against the CMFs, XYZ -> sRGB, clamp).  Values below are fixed scene INPUTS of the
+# synthetic scene (the same numbers go to oracle, reference and GPU).
+D65_TIMES_4_RGB = (400.0, 400.0, 400.0)
+ALUMINIUM_ETA_RGB = (1.657, 0.880, 0.521)
+ALUMINIUM_K_RGB = (9.224, 6.270, 4.837)
+AIR_ETA_RGB = (1.000277, 1.000277, 1.000277)
+BK7_ETA_RGB = (1.5140, 1.5187, 1.5264)
+
+
+def cornell_walls(b):
+    """Walls, light of TestScenes/Cornell_Box_Spheres.txt:8-107 (verbatim coordinates)."""
+    red = b.matte(b.spectrum_srgb_nonlinear(0.75, 0.25, 0.25))
+    blue = b.matte(b.spectrum_srgb_nonlinear(0.25, 0.25, 0.75))
+    white = b.matte(b.spectrum_srgb_nonlinear(0.75, 0.75, 0.75))
+    b.add_quad([(-1.5, 0, 2.55), (-1.5, 0, -2.55), (-1.5, 2.5, -2.55), (-1.5, 2.5, 2.55)], (1, 0, 0), (0, 0, -1), red)
+    b.add_quad([(1.5, 0, -2.55), (1.5, 0, 2.55), (1.5, 2.5, 2.55), (1.5, 2.5, -2.55)], (-1, 0, 0), (0, 0, 1), blue)
+    b.add_quad([(-1.5, 0, 2.55), (1.5, 0, 2.55), (1.5, 0, -2.55), (-1.5, 0, -2.55)], (0, 1, 0), (1, 0, 0), white)
+    b.add_quad([(-1.5, 0, -2.55), (1.5, 0, -2.55), (1.5, 2.5, -2.55), (-1.5, 2.5, -2.55)], (0, 0, 1), (1, 0, 0), white)
+    b.add_quad([(-1.5, 2.5, -2.55), (1.5, 2.5, -2.55), (1.5, 2.5, 2.55), (-1.5, 2.5, 2.55)], (0, -1, 0), (1, 0, 0), white)
+    light = b.matte(b.spectrum_srgb_nonlinear(0.9, 0.9, 0.9), emittance=b.spectrum_rgb(*D65_TIMES_4_RGB))
+    b.add_quad([(-0.5, 2.499, -0.5), (0.5, 2.499, -0.5), (0.5, 2.499, 0.5), (-0.5, 2.499, 0.5)], (0, -1, 0), (1, 0, 0), light)
+
+
+def cornell_camera(aspect):
+    # Cornell_Box_Spheres.txt:132-138
+    m = _translate(0.0, 1.689714, 6.70284) @ _rotate(3.1415926536, (0, 1, 0)) @ _rotate(0.0563936, (1, 0, 0))
+    return make_camera(m, aspect, 0.4807705238, 0.025, 1.0, 6.3)
+
+
+def cornell_box_spheres(aspect=4.0 / 3.0, segments=48, rings=24, right="glass"):
+    """Config 1/2 of BASELINE.json: Cornell box + aluminium mirror sphere + a second sphere
+    (BK7 glass as in Cornell_Box_Spheres.txt:120-130, or Lambert for 'Lambert+specular only')."""
+    b = SceneBuilder()
+    cornell_walls(b)
+    one = b.spectrum_rgb(1.0, 1.0, 1.0)  # Spectrum("Reflectance", 1.0): linear grey, API.cpp:327
+    left = b.metal(one, b.spectrum_rgb(*ALUMINIUM_ETA_RGB), b.spectrum_rgb(*ALUMINIUM_K_RGB))
+    b.add_uv_sphere(segments, rings, left, _translate(-0.7, 0, -1.05) @ _scale(0.5) @ _translate(0, 1, 0))
+    if right == "glass":
+        mat = b.glass(b.spectrum_rgb(0.999, 0.999, 0.999), b.spectrum_rgb(*AIR_ETA_RGB), b.spectrum_rgb(*BK7_ETA_RGB))
+    else:
+        mat = b.matte(b.spectrum_srgb_nonlinear(0.75, 0.75, 0.25))
+    b.add_uv_sphere(segments, rings, mat, _translate(0.7, 0, 0) @ _scale(0.5) @ _translate(0, 1, 0))
+    return b.build(cornell_camera(aspect), name="cornell_box_spheres_" + right)
+
+
+def tiny_box(aspect=1.0):
+    """Walls + light only (12 triangles): the smallest closed scene, for fast tests."""
+    b = SceneBuilder()
+    cornell_walls(b)
+    return b.build(cornell_camera(aspect), name="tiny_box")

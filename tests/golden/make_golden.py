@@ -1,0 +1,79 @@
+"""Generates tests/golden/*.npz from the COMPILED REFERENCE (oracle/_ref, built by
+oracle/ref_build from /root/reference).  Run in the container that has the reference:
+
+    python tests/golden/make_golden.py
+
+A fixture is data only: the flat input scene (our own arrays), the render settings and the
+reference's outputs (float framebuffers, single-sample radiance, closest hits, RNG draws).
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import binding as ob  # noqa: E402
+from slr_amd import abi, scenes  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def scene_arrays(sc):
+    cam = sc.camera
+    return dict(vertices=sc.vertices, triangles=sc.triangles, materials=sc.materials, spectra=sc.spectra,
+                spectrum_data=sc.spectrum_data,
+                camera=np.array(list(cam.local_to_world) + list(cam.world_to_local) +
+                                [cam.aspect, cam.fov_y, cam.lens_radius, cam.img_plane_distance,
+                                 cam.obj_plane_distance, cam.sensitivity], dtype=np.float32))
+
+
+def random_rays(rng, n):
+    org = rng.uniform([-1.4, 0.1, -2.4], [1.4, 2.4, 2.4], size=(n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3))
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    rays = np.zeros(n, dtype=ob.ray_dtype)
+    rays["org"], rays["dir"] = org, d
+    rays["dist_min"] = 1e-4
+    rays["dist_max"] = np.inf
+    rays["dist_max"][: n // 4] = rng.uniform(0.2, 3.0, size=n // 4).astype(np.float32)
+    return rays
+
+
+def make(name, sc, lib, width, height, spp, serial_spp):
+    ref = lib.scene(sc)
+    st = ob.settings(width, height)
+    fb, _ = ref.render(st, spp, threads=0)
+    fb_half, _ = ref.render(st, spp // 2, threads=0)
+    rng = np.random.default_rng(1234)
+    picks = np.stack([rng.integers(0, width, 64), rng.integers(0, height, 64), rng.integers(0, 8, 64)], axis=1)
+    samples = np.stack([ref.sample(st, int(x), int(y), int(p)) for x, y, p in picks])
+    rays = random_rays(rng, 512)
+    hits = ref.trace(rays)
+    st_serial = ob.settings(width // 2, height // 2)
+    fb_serial, _ = ref.render_serial(st_serial, serial_spp)
+    out = dict(scene_arrays(sc))
+    out.update(width=width, height=height, spp=spp, seed=st.rng_seed, framebuffer=fb, framebuffer_half=fb_half,
+               sample_picks=picks, sample_values=samples, rays=rays, hits=hits,
+               serial_width=width // 2, serial_height=height // 2, serial_spp=serial_spp, serial_framebuffer=fb_serial)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "framebuffer mean", fb.mean(), "hits", int((hits["triangle"] != 0xFFFFFFFF).sum()), "/", len(hits))
+
+
+def main():
+    lib = ob.load("ref_rgb")
+    if lib is None:
+        raise SystemExit("oracle/_ref is not built: run `make -C oracle ref` where /root/reference exists")
+    u, f = lib.rng(abi.DEFAULT_SEED, 64)
+    seeds = np.array([abi.DEFAULT_SEED, 0, 1, -1, 123456789, -2147483648], dtype=np.int32)
+    kat = {"seeds": seeds}
+    for i, s in enumerate(seeds):
+        kat["uints_%d" % i], kat["floats_%d" % i] = lib.rng(int(s), 64)
+    np.savez_compressed(os.path.join(HERE, "rng_kat.npz"), **kat)
+    make("rgb_tiny_box", scenes.tiny_box(1.0), lib, 32, 32, 8, 2)
+    make("rgb_cornell_glass", scenes.cornell_box_spheres(4.0 / 3.0, 16, 8, "glass"), lib, 48, 36, 8, 2)
+    make("rgb_cornell_matte", scenes.cornell_box_spheres(4.0 / 3.0, 16, 8, "matte"), lib, 48, 36, 8, 2)
+
+
+if __name__ == "__main__":
+    main()
