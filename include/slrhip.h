@@ -246,6 +246,12 @@ int slrhip_synchronize(slrhip_ctx* ctx);
 int slrhip_get_counters(slrhip_ctx* ctx, slrhip_counters* out);
 int slrhip_components(const slrhip_ctx* ctx);   /* 3 or 16 */
 
+/* Diagnostic: closest-hit queries against the uploaded scene, the aggregate part of
+ * Scene::intersect (SurfaceObject.cpp:267-269,408-416).  rays: n x {org[3], dir[3], dist_min,
+ * dist_max}; hits: n x {triangle index as uint32 bits (0xFFFFFFFF = miss), dist, b0, b1}
+ * (Intersection::dist, ::u, ::v; TriangleMesh.cpp:169-173).  Host arrays; synchronises.        */
+int slrhip_trace_rays(slrhip_ctx* ctx, const float* rays, uint32_t n, float* hits);
+
 /* The per-(pixel, sample) seeding contract (pure function, also used by the oracle).      */
 int32_t slrhip_sample_seed(int32_t rng_seed, uint32_t pixel_x, uint32_t pixel_y, uint32_t pass);
 

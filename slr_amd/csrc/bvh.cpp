@@ -1,0 +1,253 @@
+// bvh.cpp — host-side accelerator build for the HIP path tracer.
+//
+// Role in the reference: SurfaceObjectAggregate's constructor builds the accelerator
+// (libSLR/Core/SurfaceObject.cpp:226-230; SBVH by default, QBVH = collapse of it,
+// libSLR/Accelerator/QBVH.h:85-202).  The rendered image does not depend on the tree
+// (closest-hit semantics only), so the tree here is built for the GPU:
+// a binned-SAH binary BVH (16 bins, all three axes) collapsed to 4-wide nodes by repeatedly
+// opening the child with the largest surface area, emitted in breadth-first order so that the
+// first K nodes are the top of the tree (the part the traversal kernel stages in LDS).
+#include "bvh.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <queue>
+
+namespace slrhip {
+namespace {
+
+struct Box {
+    float lo[3], hi[3];
+    void reset() { for (int a = 0; a < 3; ++a) { lo[a] = INFINITY; hi[a] = -INFINITY; } }
+    void grow(const Box& b) { for (int a = 0; a < 3; ++a) { lo[a] = std::fmin(lo[a], b.lo[a]); hi[a] = std::fmax(hi[a], b.hi[a]); } }
+    void grow(const float* p) { for (int a = 0; a < 3; ++a) { lo[a] = std::fmin(lo[a], p[a]); hi[a] = std::fmax(hi[a], p[a]); } }
+    float area() const {
+        float d[3] = {hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]};
+        if (d[0] < 0 || d[1] < 0 || d[2] < 0) return 0.0f;
+        return 2.0f * (d[0] * d[1] + d[1] * d[2] + d[2] * d[0]);
+    }
+};
+
+struct BNode {
+    Box box;
+    uint32_t left, right;    // children (inner)
+    uint32_t first, count;   // primitive range (leaf: count > 0)
+};
+
+struct Builder {
+    const std::vector<Box>& primBox;
+    std::vector<float> cen;          // centroids, 3 per primitive
+    std::vector<uint32_t> prims;
+    std::vector<BNode> nodes;
+
+    explicit Builder(const std::vector<Box>& pb) : primBox(pb) {
+        size_t n = pb.size();
+        cen.resize(3 * n);
+        prims.resize(n);
+        for (size_t i = 0; i < n; ++i) {
+            prims[i] = (uint32_t)i;
+            for (int a = 0; a < 3; ++a) cen[3 * i + a] = 0.5f * (pb[i].lo[a] + pb[i].hi[a]);
+        }
+    }
+
+    void build() {
+        nodes.reserve(2 * prims.size());
+        nodes.push_back(BNode());
+        struct Job { uint32_t node, begin, end; };
+        std::vector<Job> stack;
+        stack.push_back({0, 0, (uint32_t)prims.size()});
+        const int kBins = 16;
+        while (!stack.empty()) {
+            Job j = stack.back();
+            stack.pop_back();
+            Box box, cbox;
+            box.reset(); cbox.reset();
+            for (uint32_t k = j.begin; k < j.end; ++k) {
+                box.grow(primBox[prims[k]]);
+                cbox.grow(&cen[3 * (size_t)prims[k]]);
+            }
+            uint32_t n = j.end - j.begin;
+            BNode nd;
+            nd.box = box;
+            nd.left = nd.right = 0;
+            nd.first = j.begin;
+            nd.count = n;
+            if (n <= kMaxLeafTris) {
+                // SAH says whether splitting a small set still pays; leaves of <= 4 always fit a packet.
+                if (n <= 1) { nodes[j.node] = nd; continue; }
+            }
+            // binned SAH over the three axes
+            float bestCost = INFINITY;
+            int bestAxis = -1, bestSplit = 0;
+            for (int a = 0; a < 3; ++a) {
+                float ext = cbox.hi[a] - cbox.lo[a];
+                if (!(ext > 0.0f)) continue;
+                Box bb[kBins];
+                uint32_t bc[kBins];
+                for (int b = 0; b < kBins; ++b) { bb[b].reset(); bc[b] = 0; }
+                float scale = kBins / ext;
+                for (uint32_t k = j.begin; k < j.end; ++k) {
+                    uint32_t p = prims[k];
+                    int b = std::min(kBins - 1, std::max(0, (int)((cen[3 * (size_t)p + a] - cbox.lo[a]) * scale)));
+                    bb[b].grow(primBox[p]);
+                    ++bc[b];
+                }
+                float rightArea[kBins];
+                uint32_t rightCount[kBins];
+                Box acc; acc.reset();
+                uint32_t cnt = 0;
+                for (int b = kBins - 1; b > 0; --b) {
+                    acc.grow(bb[b]); cnt += bc[b];
+                    rightArea[b] = acc.area(); rightCount[b] = cnt;
+                }
+                acc.reset(); cnt = 0;
+                for (int b = 1; b < kBins; ++b) {
+                    acc.grow(bb[b - 1]); cnt += bc[b - 1];
+                    if (cnt == 0 || rightCount[b] == 0) continue;
+                    float cost = acc.area() * cnt + rightArea[b] * rightCount[b];
+                    if (cost < bestCost) { bestCost = cost; bestAxis = a; bestSplit = b; }
+                }
+            }
+            uint32_t mid;
+            if (bestAxis >= 0) {
+                float leafCost = box.area() * n;
+                if (n <= kMaxLeafTris && bestCost + 0.125f * box.area() >= leafCost) { nodes[j.node] = nd; continue; }
+                float ext = cbox.hi[bestAxis] - cbox.lo[bestAxis];
+                float scale = kBins / ext;
+                float lo = cbox.lo[bestAxis];
+                int axis = bestAxis, split = bestSplit;
+                auto it = std::partition(prims.begin() + j.begin, prims.begin() + j.end, [&](uint32_t p) {
+                    int b = std::min(kBins - 1, std::max(0, (int)((cen[3 * (size_t)p + axis] - lo) * scale)));
+                    return b < split;
+                });
+                mid = (uint32_t)(it - prims.begin());
+            }
+            else {
+                if (n <= kMaxLeafTris) { nodes[j.node] = nd; continue; }
+                mid = j.begin + n / 2;        // identical centroids: split the list
+            }
+            if (mid == j.begin || mid == j.end) mid = j.begin + n / 2;
+            nd.count = 0;
+            nd.left = (uint32_t)nodes.size();
+            nd.right = nd.left + 1;
+            nodes[j.node] = nd;
+            nodes.push_back(BNode());
+            nodes.push_back(BNode());
+            stack.push_back({nd.right, mid, j.end});
+            stack.push_back({nd.left, j.begin, mid});
+        }
+    }
+};
+
+} // namespace
+
+int buildQBVH(const slrhip_vertex* verts, const slrhip_triangle* tris, uint32_t numTris, QBVH* out) {
+    if (!verts || !tris || numTris == 0 || numTris > kLeafIndexMask) return 1;
+    std::vector<Box> primBox(numTris);
+    for (uint32_t i = 0; i < numTris; ++i) {
+        primBox[i].reset();
+        for (int k = 0; k < 3; ++k) primBox[i].grow(verts[tris[i].v[k]].position);
+    }
+    Builder b(primBox);
+    b.build();
+
+    out->nodes.clear();
+    out->leafTris.clear();
+    out->leafTris.reserve(numTris);
+    out->depth = 0;
+
+    auto emitLeaf = [&](const BNode& leaf) -> uint32_t {
+        uint32_t first = (uint32_t)out->leafTris.size();
+        for (uint32_t k = 0; k < leaf.count; ++k) {
+            uint32_t t = b.prims[leaf.first + k];
+            const float* p0 = verts[tris[t].v[0]].position;
+            const float* p1 = verts[tris[t].v[1]].position;
+            const float* p2 = verts[tris[t].v[2]].position;
+            LeafTri lt;
+            std::memset(&lt, 0, sizeof(lt));
+            for (int a = 0; a < 3; ++a) {
+                lt.v0[a] = p0[a];
+                lt.e1[a] = p1[a] - p0[a];      // edge01, TriangleMesh.cpp:136
+                lt.e2[a] = p2[a] - p0[a];      // edge02, TriangleMesh.cpp:137
+            }
+            lt.tri = t;
+            out->leafTris.push_back(lt);
+        }
+        return kLeafFlag | (leaf.count << kLeafCountShift) | first;
+    };
+
+    // breadth-first emission of 4-wide nodes
+    struct Pending { uint32_t bnode; uint32_t qnode; uint32_t depth; };
+    std::queue<Pending> q;
+    const BNode& root = b.nodes[0];
+    out->nodes.push_back(QNode());
+    if (root.count > 0) {
+        // a single leaf: wrap it in one node
+        QNode qn;
+        std::memset(&qn, 0, sizeof(qn));
+        for (int c = 0; c < 4; ++c) {
+            qn.minx[c] = qn.miny[c] = qn.minz[c] = INFINITY;
+            qn.maxx[c] = qn.maxy[c] = qn.maxz[c] = -INFINITY;
+            qn.child[c] = kInvalidChild;
+        }
+        qn.minx[0] = root.box.lo[0]; qn.miny[0] = root.box.lo[1]; qn.minz[0] = root.box.lo[2];
+        qn.maxx[0] = root.box.hi[0]; qn.maxy[0] = root.box.hi[1]; qn.maxz[0] = root.box.hi[2];
+        qn.child[0] = emitLeaf(root);
+        out->nodes[0] = qn;
+        out->depth = 1;
+    }
+    else {
+        q.push({0, 0, 1});
+    }
+    while (!q.empty()) {
+        Pending p = q.front();
+        q.pop();
+        out->depth = std::max(out->depth, p.depth);
+        const BNode& bn = b.nodes[p.bnode];
+        uint32_t kids[4] = {bn.left, bn.right, 0, 0};
+        int nk = 2;
+        while (nk < 4) {
+            int best = -1;
+            float bestArea = -1.0f;
+            for (int i = 0; i < nk; ++i) {
+                const BNode& c = b.nodes[kids[i]];
+                if (c.count > 0) continue;
+                float a = c.box.area();
+                if (a > bestArea) { bestArea = a; best = i; }
+            }
+            if (best < 0) break;
+            const BNode& c = b.nodes[kids[best]];
+            kids[best] = c.left;
+            kids[nk++] = c.right;
+        }
+        QNode qn;
+        std::memset(&qn, 0, sizeof(qn));
+        for (int c = 0; c < 4; ++c) {
+            if (c < nk) {
+                const BNode& cn = b.nodes[kids[c]];
+                qn.minx[c] = cn.box.lo[0]; qn.miny[c] = cn.box.lo[1]; qn.minz[c] = cn.box.lo[2];
+                qn.maxx[c] = cn.box.hi[0]; qn.maxy[c] = cn.box.hi[1]; qn.maxz[c] = cn.box.hi[2];
+                if (cn.count > 0) {
+                    qn.child[c] = emitLeaf(cn);
+                }
+                else {
+                    uint32_t idx = (uint32_t)out->nodes.size();
+                    out->nodes.push_back(QNode());
+                    qn.child[c] = idx;
+                    q.push({kids[c], idx, p.depth + 1});
+                }
+            }
+            else {
+                // empty slot: an inverted box never passes the slab test
+                qn.minx[c] = qn.miny[c] = qn.minz[c] = INFINITY;
+                qn.maxx[c] = qn.maxy[c] = qn.maxz[c] = -INFINITY;
+                qn.child[c] = kInvalidChild;
+            }
+        }
+        out->nodes[p.qnode] = qn;
+    }
+    return 0;
+}
+
+} // namespace slrhip

@@ -1,0 +1,88 @@
+// device_types.h — data layouts shared by the host library and the HIP kernels.
+//
+// Everything the kernels read is a flat, index-based array in HBM; no pointers cross the
+// host/device boundary.  Layouts are chosen for the access pattern of the wavefront kernels:
+//   * QNode   128 B = one L2 line: the 4 child boxes SoA (6 x float4) so one lane tests four
+//             slabs from six 16-byte loads, + 4 child references.  Same information as the
+//             reference's QBVH::Node (libSLR/Accelerator/QBVH.h:42-54); the child reference
+//             packs (leaf flag, count, index) like QBVH::Children (:27-40).
+//   * LeafTri  48 B: v0, e1 = v1-v0, e2 = v2-v0 (the two subtractions Triangle::intersect does
+//             first, TriangleMesh.cpp:136-137, hoisted to build time: same float operations,
+//             same bits) + the triangle's index in scene order.
+//   * ShadeTri 96 B: everything Triangle::getSurfacePoint needs (TriangleMesh.cpp:180-215)
+//             inline, so shading a hit is six 16-byte loads and no vertex indirection.
+#pragma once
+#include <stdint.h>
+
+namespace slrhip {
+
+static const uint32_t kInvalidChild = 0xFFFFFFFFu;
+static const uint32_t kLeafFlag = 0x80000000u;
+static const uint32_t kLeafCountShift = 27;
+static const uint32_t kLeafIndexMask = (1u << 27) - 1;
+static const uint32_t kMaxLeafTris = 4;
+
+struct alignas(16) QNode {
+    float minx[4], miny[4], minz[4];
+    float maxx[4], maxy[4], maxz[4];
+    uint32_t child[4];      // kInvalidChild | inner node index | kLeafFlag | count << 27 | first LeafTri
+    uint32_t pad[4];
+};
+static_assert(sizeof(QNode) == 128, "QNode must be one 128-byte line");
+
+struct alignas(16) LeafTri {
+    float v0[3]; uint32_t tri;
+    float e1[3]; uint32_t pad0;
+    float e2[3]; uint32_t pad1;
+};
+static_assert(sizeof(LeafTri) == 48, "LeafTri is three float4");
+
+struct alignas(16) ShadeTri {
+    float n0[3]; uint32_t material;
+    float n1[3]; int32_t light;          // index into the light table, -1 if not emitting
+    float n2[3]; float areaPDF;          // 1 / Triangle::area() (TriangleMesh.cpp:217-222,257-260)
+    float t0[3]; float gnx;
+    float t1[3]; float gny;
+    float t2[3]; float gnz;              // gNormal = normalize(cross(e01, e02)) (TriangleMesh.cpp:171)
+};
+static_assert(sizeof(ShadeTri) == 96, "ShadeTri is six float4");
+
+// One emitting triangle (a "light" of SurfaceObjectAggregate's light list, SurfaceObject.cpp:232-249):
+// what Triangle::sample needs (TriangleMesh.cpp:224-255).
+struct alignas(16) LightTri {
+    float p0[3]; uint32_t tri;
+    float p1[3]; uint32_t material;
+    float p2[3]; float areaPDF;
+    float n0[3]; float gnx;
+    float n1[3]; float gny;
+    float n2[3]; float gnz;
+    float t0[3]; float pad0;
+    float t1[3]; float pad1;
+    float t2[3]; float pad2;
+};
+static_assert(sizeof(LightTri) == 144, "LightTri is nine float4");
+
+// Per-material constants, RGB mode (BSDF factories of basic_SurfaceMaterials.cpp:15-43 with
+// constant textures evaluated once: RGBTemplate::evaluate returns itself, RGBTypes.h:124-126).
+struct alignas(16) DevMaterial {
+    uint32_t type;          // SLRHIP_MATERIAL_*
+    float param;
+    int32_t emitting;
+    uint32_t pad;
+    float a[4];             // matte: R | metal: coeffR | glass: coeff
+    float b[4];             // metal: eta | glass: etaExt
+    float c[4];             // metal: k   | glass: etaInt
+    float emittance[4];
+};
+static_assert(sizeof(DevMaterial) == 80, "DevMaterial layout");
+
+// PerspectiveCamera constants (PerspectiveCamera.cpp:15-24) computed on the host with the same
+// libm the reference uses, so the device never evaluates tan/pow.
+struct DevCamera {
+    float mat[16];          // local -> world, column-major
+    float matInv[16];
+    float lensRadius, imgPlaneDistance, objPlaneDistance, opWidth;
+    float opHeight, imgPlaneArea, areaPDF, sensitivity;
+};
+
+} // namespace slrhip

@@ -1,0 +1,210 @@
+// pt_device.h — device-side math of the path tracer (HIP, gfx950).
+//
+// Every function states the reference code it replaces (paths relative to
+// /root/reference/libSLR).  The arithmetic follows the reference operation by operation —
+// including its float/double mixing through M_PI and unsuffixed literals and "x / s" as
+// "x * (1.0f / s)" — and the file is compiled with -ffp-contract=off and IEEE-correct
+// division / square root, so a sample's radiance is a pure function of (scene, seed) that
+// the CPU oracle reproduces.  Only libm calls (double-precision cos/sin here) can differ
+// from the host's in the last bit.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/slrhip.h"
+#include "device_types.h"
+
+namespace slrhip {
+
+#define SLR_DEV __device__ __forceinline__
+
+static const double kPi = 3.14159265358979323846;      // M_PI
+static const double kPi4 = 0.78539816339744830962;     // M_PI_4
+static const float kRayEpsilon = 0.0001f;              // Ray::Epsilon, Core/geometry.cpp:15
+
+// ---- BasicTypes/Vector3.h:17-147 ------------------------------------------------------------
+struct V3 {
+    float x, y, z;
+    SLR_DEV V3() : x(0), y(0), z(0) {}
+    SLR_DEV V3(float xx, float yy, float zz) : x(xx), y(yy), z(zz) {}
+};
+SLR_DEV V3 operator+(V3 a, V3 b) { return V3(a.x + b.x, a.y + b.y, a.z + b.z); }
+SLR_DEV V3 operator-(V3 a, V3 b) { return V3(a.x - b.x, a.y - b.y, a.z - b.z); }
+SLR_DEV V3 operator-(V3 a) { return V3(-a.x, -a.y, -a.z); }
+SLR_DEV V3 operator*(V3 a, float s) { return V3(a.x * s, a.y * s, a.z * s); }
+SLR_DEV V3 operator*(float s, V3 a) { return V3(s * a.x, s * a.y, s * a.z); }
+SLR_DEV V3 operator/(V3 a, float s) { float r = 1.0f / s; return V3(a.x * r, a.y * r, a.z * r); }   // Vector3.h:31
+SLR_DEV float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+SLR_DEV float absDot(V3 a, V3 b) { return fabsf(a.x * b.x + a.y * b.y + a.z * b.z); }
+SLR_DEV V3 cross(V3 a, V3 b) { return V3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+SLR_DEV float length(V3 a) { return sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
+SLR_DEV float sqLength(V3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+SLR_DEV V3 normalize(V3 a) { float l = length(a); return a / l; }
+SLR_DEV V3 ld3(const float* p) { return V3(p[0], p[1], p[2]); }
+SLR_DEV V3 xyz(float4 v) { return V3(v.x, v.y, v.z); }
+
+// ---- Core/geometry.h:225-235 ReferenceFrame ---------------------------------------------------
+struct Frame {
+    V3 x, y, z;
+    SLR_DEV V3 toLocal(V3 v) const { return V3(dot(x, v), dot(y, v), dot(z, v)); }
+    SLR_DEV V3 fromLocal(V3 v) const {
+        return V3(dot(V3(x.x, y.x, z.x), v), dot(V3(x.y, y.y, z.y), v), dot(V3(x.z, y.z, z.z), v));
+    }
+};
+
+// ---- RGBTemplate<float>, BasicTypes/RGBTypes.h:51-143 -------------------------------------------
+struct RGB {
+    float r, g, b;
+    SLR_DEV RGB() : r(0), g(0), b(0) {}
+    SLR_DEV explicit RGB(float v) : r(v), g(v), b(v) {}
+    SLR_DEV RGB(float rr, float gg, float bb) : r(rr), g(gg), b(bb) {}
+    SLR_DEV float comp(uint32_t i) const { return i == 0 ? r : (i == 1 ? g : b); }
+    SLR_DEV bool isZero() const { return r == 0.0f && g == 0.0f && b == 0.0f; }
+};
+SLR_DEV RGB operator+(RGB a, RGB b) { return RGB(a.r + b.r, a.g + b.g, a.b + b.b); }
+SLR_DEV RGB operator-(RGB a, RGB b) { return RGB(a.r - b.r, a.g - b.g, a.b - b.b); }
+SLR_DEV RGB operator*(RGB a, RGB b) { return RGB(a.r * b.r, a.g * b.g, a.b * b.b); }
+SLR_DEV RGB operator/(RGB a, RGB b) { return RGB(a.r / b.r, a.g / b.g, a.b / b.b); }
+SLR_DEV RGB operator*(RGB a, float s) { return RGB(a.r * s, a.g * s, a.b * s); }
+SLR_DEV RGB operator*(float s, RGB a) { return RGB(s * a.r, s * a.g, s * a.b); }
+SLR_DEV RGB operator/(RGB a, float s) { float rc = 1.0f / s; return RGB(a.r * rc, a.g * rc, a.b * rc); }   // RGBTypes.h:67
+SLR_DEV RGB operator+(RGB a, float s) { return a + RGB(s); }
+SLR_DEV RGB operator-(RGB a, float s) { return a - RGB(s); }
+SLR_DEV RGB rgb4(const float* p) { return RGB(p[0], p[1], p[2]); }
+
+// RGBTypes.h:103-108
+SLR_DEV float importance(RGB s, uint32_t selectedLambda) {
+    float sum = s.r + s.g + s.b;
+    const float primary = 0.9f;
+    const float marginal = (1 - primary) / 2;
+    return sum * marginal + s.comp(selectedLambda) * (primary - marginal);
+}
+
+// BasicTypes/CompensatedSum.h:24-30
+SLR_DEV void kahanAdd(RGB& result, RGB& comp, RGB value) {
+    RGB cInput = value - comp;
+    RGB sumTemp = result + cInput;
+    comp = (sumTemp - result) - cInput;
+    result = sumTemp;
+}
+
+// ---- RNGs/XORShiftRNG.cpp:21-36, Core/RandomNumberGenerator.cpp:12-15 ----------------------------
+struct Rng {
+    uint32_t s0, s1, s2, s3;
+    SLR_DEV uint32_t next() {
+        uint32_t t = s0 ^ (s0 << 11);
+        s0 = s1; s1 = s2; s2 = s3;
+        return s3 = (s3 ^ (s3 >> 19)) ^ (t ^ (t >> 8));
+    }
+    SLR_DEV float nextFloat() { return __uint_as_float((next() >> 9) | 0x3f800000u) - 1.0f; }
+    SLR_DEV void seed(int32_t seed) {
+        // `seed` is signed in the reference: arithmetic shift, unsigned multiply
+        uint32_t v;
+        v = 1812433253U * ((uint32_t)seed ^ (uint32_t)(seed >> 30)) + 0u; s0 = v; seed = (int32_t)v;
+        v = 1812433253U * ((uint32_t)seed ^ (uint32_t)(seed >> 30)) + 1u; s1 = v; seed = (int32_t)v;
+        v = 1812433253U * ((uint32_t)seed ^ (uint32_t)(seed >> 30)) + 2u; s2 = v; seed = (int32_t)v;
+        v = 1812433253U * ((uint32_t)seed ^ (uint32_t)(seed >> 30)) + 3u; s3 = v;
+        for (int i = 0; i < 50; ++i) next();
+    }
+};
+
+// The per-(pixel, sample) seeding contract (include/slrhip.h: slrhip_sample_seed).
+SLR_DEV uint32_t fmix32(uint32_t h) { h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16; return h; }
+SLR_DEV int32_t sampleSeed(int32_t rngSeed, uint32_t px, uint32_t py, uint32_t pass) {
+    uint32_t h = (uint32_t)rngSeed;
+    h = fmix32(h ^ (pass * 0x9E3779B1u));
+    h = fmix32(h ^ (py * 0x85EBCA77u + 0x165667B1u));
+    h = fmix32(h ^ (px * 0xC2B2AE3Du + 0x27D4EB2Fu));
+    return (int32_t)h;
+}
+
+// ---- Core/distributions.cpp:37-70 (float instantiation) --------------------------------------------
+// theta *= M_PI_4 is a double multiply rounded to float; cos/sin are the double functions and
+// r * cos(theta) a double product rounded to float.
+SLR_DEV void concentricSampleDisk(float u0, float u1, float* dx, float* dy) {
+    float r, theta;
+    float sx = 2 * u0 - 1;
+    float sy = 2 * u1 - 1;
+    if (sx == 0 && sy == 0) { *dx = 0; *dy = 0; return; }
+    if (sx >= -sy) {
+        if (sx > sy) { r = sx; theta = sy / sx; }
+        else { r = sy; theta = 2 - sx / sy; }
+    }
+    else {
+        if (sx > sy) { r = -sy; theta = 6 + sx / sy; }
+        else { r = -sx; theta = 4 + sy / sx; }
+    }
+    theta = (float)((double)theta * kPi4);
+    double s, c;
+    sincos((double)theta, &s, &c);
+    *dx = (float)((double)r * c);
+    *dy = (float)((double)r * s);
+}
+// Core/distributions.h:26-33
+SLR_DEV V3 cosineSampleHemisphere(float u0, float u1) {
+    float x, y;
+    concentricSampleDisk(u0, u1, &x, &y);
+    return V3(x, y, sqrtf(fmaxf(0.0f, 1.0f - x * x - y * y)));
+}
+
+// ---- Fresnel, Core/directional_distribution_functions.cpp:68-159 -------------------------------------
+SLR_DEV RGB fresnelConductor(RGB eta, RGB k, float cosEnter) {   // :68-78
+    cosEnter = fabsf(cosEnter);
+    float cosEnter2 = cosEnter * cosEnter;
+    RGB _2EtaCosEnter = 2.0f * eta * cosEnter;
+    RGB tmp_f = eta * eta + k * k;
+    RGB tmp = tmp_f * cosEnter2;
+    RGB Rparl2 = (tmp - _2EtaCosEnter + 1.0f) / (tmp + _2EtaCosEnter + 1.0f);
+    RGB Rperp2 = (tmp_f - _2EtaCosEnter + cosEnter2) / (tmp_f + _2EtaCosEnter + cosEnter2);
+    return (Rparl2 + Rperp2) / 2.0f;
+}
+SLR_DEV float fresnelEvalF(float etaEnter, float etaExit, float cosEnter, float cosExit) {   // :155-159
+    float Rparl = ((etaExit * cosEnter) - (etaEnter * cosExit)) / ((etaExit * cosEnter) + (etaEnter * cosExit));
+    float Rperp = ((etaEnter * cosEnter) - (etaExit * cosExit)) / ((etaEnter * cosEnter) + (etaExit * cosExit));
+    return (Rparl * Rparl + Rperp * Rperp) / 2.0f;
+}
+SLR_DEV float fresnelDielectric1(float eEnter, float eExit, float sinTerm, float cosEnterAbs) {
+    float sinExit = eEnter / eExit * sinTerm;
+    if (sinExit >= 1.0f) return 1.0f;
+    float cosExit = sqrtf(fmaxf(0.0f, 1.0f - sinExit * sinExit));
+    return fresnelEvalF(eEnter, eExit, cosEnterAbs, cosExit);
+}
+SLR_DEV RGB fresnelDielectric(RGB etaExt, RGB etaInt, float cosEnter) {   // :90-111
+    cosEnter = fminf(1.0f, fmaxf(-1.0f, cosEnter));
+    bool entering = cosEnter > 0.0f;
+    RGB eEnter = entering ? etaExt : etaInt;
+    RGB eExit = entering ? etaInt : etaExt;
+    float sinTerm = sqrtf(fmaxf(0.0f, 1.0f - cosEnter * cosEnter));
+    float c = fabsf(cosEnter);
+    return RGB(fresnelDielectric1(eEnter.r, eExit.r, sinTerm, c), fresnelDielectric1(eEnter.g, eExit.g, sinTerm, c),
+               fresnelDielectric1(eEnter.b, eExit.b, sinTerm, c));
+}
+
+// ---- DirectionType flags, Core/directional_distribution_functions.h:18-91 ------------------------------
+enum : uint32_t {
+    DT_LowFreq = 1 << 0, DT_HighFreq = 1 << 1, DT_Delta0D = 1 << 2, DT_Delta1D = 1 << 3,
+    DT_NonDelta = DT_LowFreq | DT_HighFreq, DT_Delta = DT_Delta0D | DT_Delta1D, DT_AllFreq = DT_NonDelta | DT_Delta,
+    DT_Reflection = 1 << 4, DT_Transmission = 1 << 5, DT_WholeSphere = DT_Reflection | DT_Transmission,
+    DT_All = DT_AllFreq | DT_WholeSphere, DT_Dispersive = 1 << 6
+};
+SLR_DEV bool dtMatches(uint32_t type, uint32_t t) { uint32_t res = type & t; return (res & DT_WholeSphere) && (res & DT_AllFreq); }
+SLR_DEV bool dtIsDelta(uint32_t v) { return (v & DT_Delta) && !(v & DT_NonDelta); }
+
+// ---- Matrix4x4.h:71-81, Transform.h:47-52 (column-major m[c*4+r]) ---------------------------------------
+SLR_DEV V3 mulPoint(const float* m, V3 p) {
+    float x = m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12] * 1.0f;
+    float y = m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13] * 1.0f;
+    float z = m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14] * 1.0f;
+    float w = m[3] * p.x + m[7] * p.y + m[11] * p.z + m[15] * 1.0f;
+    if (w != 1.0f) { float r = 1.0f / w; x *= r; y *= r; z *= r; }
+    return V3(x, y, z);
+}
+SLR_DEV V3 mulVector(const float* m, V3 v) {
+    return V3(m[0] * v.x + m[4] * v.y + m[8] * v.z, m[1] * v.x + m[5] * v.y + m[9] * v.z, m[2] * v.x + m[6] * v.y + m[10] * v.z);
+}
+SLR_DEV V3 mulNormal(const float* mi, V3 n) {
+    return V3(mi[0] * n.x + mi[1] * n.y + mi[2] * n.z, mi[4] * n.x + mi[5] * n.y + mi[6] * n.z, mi[8] * n.x + mi[9] * n.y + mi[10] * n.z);
+}
+
+} // namespace slrhip

@@ -1,0 +1,473 @@
+// slrhip_api.hip — the C ABI of include/slrhip.h over the HIP kernels.
+//
+// Host-side responsibilities that the reference spreads over SurfaceObjectAggregate's
+// constructor (Core/SurfaceObject.cpp:226-250: accelerator + light list), Scene::build
+// (:396-406), PerspectiveCamera's constructor (Cameras/PerspectiveCamera.cpp:15-24) and
+// PathTracingRenderer::render's set-up (Renderers/PathTracingRenderer.cpp:27-70) live here:
+// flatten, build the 4-wide BVH, upload once, then drive the wavefront iterations.
+// There is no CPU fallback: without a HIP device every entry point fails loudly.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/slrhip.h"
+#include "bvh.h"
+#include "pt_kernels.h"
+
+using namespace slrhip;
+
+namespace {
+
+thread_local std::string g_lastError;
+
+int fail(int code, const std::string& msg) {
+    g_lastError = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return fail(SLRHIP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));             \
+    } while (0)
+
+template <typename T>
+struct DevArray {
+    T* ptr = nullptr;
+    size_t count = 0;
+    ~DevArray() { release(); }
+    void release() { if (ptr) { (void)hipFree(ptr); ptr = nullptr; count = 0; } }
+    hipError_t alloc(size_t n) {
+        release();
+        if (n == 0) n = 1;
+        hipError_t e = hipMalloc((void**)&ptr, n * sizeof(T));
+        if (e == hipSuccess) count = n;
+        return e;
+    }
+    hipError_t upload(const std::vector<T>& v) {
+        hipError_t e = alloc(v.size());
+        if (e != hipSuccess || v.empty()) return e;
+        return hipMemcpy(ptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+    }
+};
+
+uint32_t prevPowerOf2(uint32_t x) {   // defines.h:136-143
+    x |= x >> 1; x |= x >> 2; x |= x >> 4; x |= x >> 8; x |= x >> 16;
+    return x - (x >> 1);
+}
+
+// Kahan sum, BasicTypes/CompensatedSum.h:24-30
+struct KahanF {
+    float result = 0.0f, comp = 0.0f;
+    void add(float value) {
+        float cInput = value - comp;
+        float sumTemp = result + cInput;
+        comp = (sumTemp - result) - cInput;
+        result = sumTemp;
+    }
+};
+
+} // namespace
+
+struct slrhip_ctx {
+    slrhip_config config;
+    int device = 0;
+    int numCUs = 256;
+    bool haveScene = false;
+    bool haveRender = false;
+
+    // scene
+    DevArray<QNode> nodes;
+    DevArray<LeafTri> leafTris;
+    DevArray<ShadeTri> shadeTris;
+    DevArray<LightTri> lightTris;
+    DevArray<DevMaterial> materials;
+    DevArray<float> lightPMF, lightCDF;
+    DevScene scene;
+    uint32_t bvhDepth = 0;
+    double buildSeconds = 0.0;
+
+    // render state
+    slrhip_render_settings settings;
+    slrhip_shard shard;
+    RenderParams params;
+    DevArray<uint32_t> pixelXY;
+    DevArray<uint4> rng;
+    DevArray<float4> rayOrg, rayDir, hit, alpha, spR, spC, accR, accC, nee, shadowDir;
+    DevArray<uint32_t> flags, sampleIdx, visible, extQueue, shadowQueue, queueCount, activeSlots;
+    DevArray<uint64_t> totals;
+    DevArray<float> resolveScratch;
+    PathBuffers buffers;
+    uint64_t iterations = 0;
+    bool firstRenderCall = true;
+};
+
+extern "C" {
+
+const char* slrhip_last_error_string(void) { return g_lastError.c_str(); }
+int slrhip_version(void) { return SLRHIP_VERSION; }
+
+int slrhip_create(const slrhip_config* config, slrhip_ctx** out) {
+    if (!config || !out) return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_create: null argument");
+    *out = nullptr;
+    if (config->mode != SLRHIP_MODE_RGB)
+        return fail(SLRHIP_ERR_UNSUPPORTED, "slrhip_create: only SLRHIP_MODE_RGB is implemented in this build");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(SLRHIP_ERR_NO_DEVICE, std::string("slrhip_create: no HIP device (") + hipGetErrorString(e) + ")");
+    if (config->device < 0 || config->device >= n) return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_create: device ordinal out of range");
+    HIP_TRY(hipSetDevice(config->device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, config->device));
+    slrhip_ctx* ctx = new slrhip_ctx();
+    ctx->config = *config;
+    ctx->device = config->device;
+    ctx->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    *out = ctx;
+    return SLRHIP_OK;
+}
+
+int slrhip_destroy(slrhip_ctx* ctx) {
+    if (!ctx) return SLRHIP_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    delete ctx;
+    return SLRHIP_OK;
+}
+
+int slrhip_components(const slrhip_ctx* ctx) { return ctx && ctx->config.mode == SLRHIP_MODE_SPECTRAL ? 16 : 3; }
+
+int slrhip_upload_scene(slrhip_ctx* ctx, const slrhip_scene_desc* d) {
+    if (!ctx || !d) return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: null argument");
+    if (!d->vertices || !d->triangles || !d->materials || !d->spectra || d->num_triangles == 0 || d->num_vertices == 0)
+        return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: empty scene");
+    if (d->env) return fail(SLRHIP_ERR_UNSUPPORTED, "slrhip_upload_scene: environment light not implemented in this build");
+    HIP_TRY(hipSetDevice(ctx->device));
+    auto t0 = std::chrono::steady_clock::now();
+
+    // --- validate indices (a bad index would fault the GPU) --------------------------------------
+    for (uint32_t i = 0; i < d->num_triangles; ++i) {
+        const slrhip_triangle& t = d->triangles[i];
+        if (t.v[0] >= d->num_vertices || t.v[1] >= d->num_vertices || t.v[2] >= d->num_vertices || t.material >= d->num_materials)
+            return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: triangle index out of range");
+    }
+    std::vector<DevMaterial> mats(d->num_materials);
+    for (uint32_t i = 0; i < d->num_materials; ++i) {
+        const slrhip_material& m = d->materials[i];
+        DevMaterial dm;
+        std::memset(&dm, 0, sizeof(dm));
+        dm.type = m.type;
+        dm.param = m.param;
+        if (m.type == SLRHIP_MATERIAL_MATTE && m.param >= 0.0f)
+            return fail(SLRHIP_ERR_UNSUPPORTED, "slrhip_upload_scene: Oren-Nayar (sigma >= 0) not implemented in this build");
+        if (m.type > SLRHIP_MATERIAL_GLASS)
+            return fail(SLRHIP_ERR_UNSUPPORTED, "slrhip_upload_scene: microfacet materials not implemented in this build");
+        auto fetch = [&](int32_t idx, float* dst) -> bool {
+            if (idx < 0) return true;
+            if ((uint32_t)idx >= d->num_spectra) return false;
+            for (int k = 0; k < 3; ++k) dst[k] = d->spectra[idx].rgb[k];   // RGBTemplate::evaluate RGBTypes.h:124-126
+            return true;
+        };
+        // `scale * spectrum` with scale = 1.0f (basic_SurfaceMaterials.cpp:22,33,42) is exact
+        if (!fetch(m.spectrum[0], dm.a) || !fetch(m.spectrum[1], dm.b) || !fetch(m.spectrum[2], dm.c) || !fetch(m.emittance, dm.emittance))
+            return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: spectrum index out of range");
+        if (m.spectrum[0] < 0 && m.type <= SLRHIP_MATERIAL_GLASS)
+            return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: material without its first spectrum");
+        dm.emitting = m.emittance >= 0 ? 1 : 0;
+        mats[i] = dm;
+    }
+
+    // --- accelerator -------------------------------------------------------------------------------
+    QBVH bvh;
+    if (buildQBVH(d->vertices, d->triangles, d->num_triangles, &bvh) != 0)
+        return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: BVH build failed");
+    if (3 * bvh.depth + 1 > 64)
+        return fail(SLRHIP_ERR_UNSUPPORTED, "slrhip_upload_scene: tree deeper than the 64-entry traversal stack (QBVH.h:299)");
+
+    // --- per-triangle shading records and the light list (SurfaceObject.cpp:232-249) ---------------------
+    std::vector<ShadeTri> shade(d->num_triangles);
+    std::vector<LightTri> lights;
+    std::vector<float> importances;
+    for (uint32_t i = 0; i < d->num_triangles; ++i) {
+        const slrhip_triangle& t = d->triangles[i];
+        const slrhip_vertex &v0 = d->vertices[t.v[0]], &v1 = d->vertices[t.v[1]], &v2 = d->vertices[t.v[2]];
+        ShadeTri s;
+        std::memset(&s, 0, sizeof(s));
+        float e1[3], e2[3];
+        for (int a = 0; a < 3; ++a) {
+            s.n0[a] = v0.normal[a]; s.n1[a] = v1.normal[a]; s.n2[a] = v2.normal[a];
+            s.t0[a] = v0.tangent[a]; s.t1[a] = v1.tangent[a]; s.t2[a] = v2.tangent[a];
+            e1[a] = v1.position[a] - v0.position[a];
+            e2[a] = v2.position[a] - v0.position[a];
+        }
+        // normalize(cross(edge01, edge02)) TriangleMesh.cpp:171 — same float ops as the reference, on the host
+        float cx = e1[1] * e2[2] - e1[2] * e2[1], cy = e1[2] * e2[0] - e1[0] * e2[2], cz = e1[0] * e2[1] - e1[1] * e2[0];
+        float len = std::sqrt(cx * cx + cy * cy + cz * cz);
+        float r = 1.0f / len;
+        s.gnx = cx * r; s.gny = cy * r; s.gnz = cz * r;
+        s.areaPDF = 1.0f / (0.5f * len);                    // 1 / Triangle::area() :217-222
+        s.material = t.material;
+        s.light = -1;
+        if (mats[t.material].emitting) {
+            s.light = (int32_t)lights.size();
+            LightTri l;
+            std::memset(&l, 0, sizeof(l));
+            for (int a = 0; a < 3; ++a) {
+                l.p0[a] = v0.position[a]; l.p1[a] = v1.position[a]; l.p2[a] = v2.position[a];
+                l.n0[a] = v0.normal[a]; l.n1[a] = v1.normal[a]; l.n2[a] = v2.normal[a];
+                l.t0[a] = v0.tangent[a]; l.t1[a] = v1.tangent[a]; l.t2[a] = v2.tangent[a];
+            }
+            l.tri = i; l.material = t.material; l.areaPDF = s.areaPDF;
+            l.gnx = s.gnx; l.gny = s.gny; l.gnz = s.gnz;
+            lights.push_back(l);
+            importances.push_back(1.0f);                    // SingleSurfaceObject::importance :69-71
+        }
+        shade[i] = s;
+    }
+    if (lights.empty()) return fail(SLRHIP_ERR_UNSUPPORTED, "slrhip_upload_scene: scene has no emitting triangle");
+
+    // RegularConstantDiscrete1D ctor, Core/distributions.cpp:76-95
+    std::vector<float> pmf = importances, cdf(importances.size() + 1, 0.0f);
+    {
+        KahanF sum;
+        for (size_t i = 0; i < pmf.size(); ++i) { sum.add(pmf[i]); cdf[i + 1] = sum.result; }
+        float integral = sum.result;
+        for (size_t i = 0; i < pmf.size(); ++i) { pmf[i] /= integral; cdf[i + 1] /= integral; }
+    }
+
+    // --- camera constants, PerspectiveCamera.cpp:15-24, :55 -------------------------------------------------
+    DevCamera cam;
+    std::memcpy(cam.mat, d->camera.local_to_world, sizeof(cam.mat));
+    std::memcpy(cam.matInv, d->camera.world_to_local, sizeof(cam.matInv));
+    cam.lensRadius = d->camera.lens_radius;
+    cam.imgPlaneDistance = d->camera.img_plane_distance;
+    cam.objPlaneDistance = d->camera.obj_plane_distance;
+    cam.opHeight = 2.0f * cam.objPlaneDistance * std::tan(d->camera.fov_y * 0.5f);
+    cam.opWidth = cam.opHeight * d->camera.aspect;
+    cam.imgPlaneArea = (float)((double)(cam.opWidth * cam.opHeight) * std::pow((double)(cam.imgPlaneDistance / cam.objPlaneDistance), 2.0));
+    cam.areaPDF = cam.lensRadius > 0.0f ? (float)(1.0f / (M_PI * (double)cam.lensRadius * (double)cam.lensRadius)) : 1.0f;
+    cam.sensitivity = d->camera.sensitivity > 0 ? d->camera.sensitivity
+                                                : (float)(1.0f / (M_PI * (double)cam.lensRadius * (double)cam.lensRadius));
+
+    // --- upload ----------------------------------------------------------------------------------------------
+    HIP_TRY(ctx->nodes.upload(bvh.nodes));
+    HIP_TRY(ctx->leafTris.upload(bvh.leafTris));
+    HIP_TRY(ctx->shadeTris.upload(shade));
+    HIP_TRY(ctx->lightTris.upload(lights));
+    HIP_TRY(ctx->materials.upload(mats));
+    HIP_TRY(ctx->lightPMF.upload(pmf));
+    HIP_TRY(ctx->lightCDF.upload(cdf));
+    DevScene& sc = ctx->scene;
+    sc.nodes = reinterpret_cast<const float4*>(ctx->nodes.ptr);
+    sc.leafTris = reinterpret_cast<const float4*>(ctx->leafTris.ptr);
+    sc.shadeTris = ctx->shadeTris.ptr;
+    sc.lightTris = ctx->lightTris.ptr;
+    sc.materials = ctx->materials.ptr;
+    sc.lightPMF = ctx->lightPMF.ptr;
+    sc.lightCDF = ctx->lightCDF.ptr;
+    sc.numLights = (uint32_t)lights.size();
+    sc.lightPow2 = prevPowerOf2(sc.numLights);
+    sc.camera = cam;
+    ctx->bvhDepth = bvh.depth;
+    ctx->haveScene = true;
+    ctx->haveRender = false;
+    ctx->buildSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return SLRHIP_OK;
+}
+
+int slrhip_render_begin(slrhip_ctx* ctx, const slrhip_render_settings* st, slrhip_shard shard) {
+    if (!ctx || !st) return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_render_begin: null argument");
+    if (!ctx->haveScene) return fail(SLRHIP_ERR_NO_SCENE, "slrhip_render_begin: no scene uploaded");
+    if (st->image_width <= 0 || st->image_height <= 0 || st->image_width > 65535 || st->image_height > 65535)
+        return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_render_begin: image size out of range");
+    if (shard.shard_count == 0 || shard.shard_index >= shard.shard_count)
+        return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_render_begin: bad shard");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const uint32_t W = (uint32_t)st->image_width, H = (uint32_t)st->image_height;
+    const uint32_t tilesX = (W + 7) >> 3, tilesY = (H + 7) >> 3;     // ImageSensor.cpp:43-44, 8x8 tiles
+    // pixel list of this shard: tiles t with t % count == index, row-major inside each tile, so 64
+    // consecutive slots (one wavefront) are one 8x8 tile
+    std::vector<uint32_t> pixels;
+    for (uint32_t t = shard.shard_index; t < tilesX * tilesY; t += shard.shard_count) {
+        uint32_t tx = t % tilesX, ty = t / tilesX;
+        for (uint32_t ly = 0; ly < 8; ++ly)
+            for (uint32_t lx = 0; lx < 8; ++lx) {
+                uint32_t x = tx * 8 + lx, y = ty * 8 + ly;
+                if (x < W && y < H) pixels.push_back(x | (y << 16));
+            }
+    }
+    if (pixels.empty()) pixels.push_back(0xFFFFFFFFu);   // an empty shard keeps the buffers valid; numPixels = 0 below
+    const uint32_t numPixels = pixels[0] == 0xFFFFFFFFu ? 0u : (uint32_t)pixels.size();
+    uint32_t stripes = ctx->config.stripes;
+    if (stripes == 0) {
+        const uint32_t target = 1u << 19;                // keep >= 512 Ki paths in flight
+        stripes = numPixels >= target || numPixels == 0 ? 1u : (target + numPixels - 1) / numPixels;
+        if (stripes > 64) stripes = 64;
+    }
+    const size_t numSlots = (size_t)numPixels * stripes;
+    if (numSlots > 0x7FFFFFFFull) return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_render_begin: too many path slots");
+
+    HIP_TRY(ctx->pixelXY.upload(pixels));
+    HIP_TRY(ctx->rng.alloc(numSlots));
+    HIP_TRY(ctx->rayOrg.alloc(numSlots)); HIP_TRY(ctx->rayDir.alloc(numSlots)); HIP_TRY(ctx->hit.alloc(numSlots));
+    HIP_TRY(ctx->alpha.alloc(numSlots)); HIP_TRY(ctx->spR.alloc(numSlots)); HIP_TRY(ctx->spC.alloc(numSlots));
+    HIP_TRY(ctx->accR.alloc(numSlots)); HIP_TRY(ctx->accC.alloc(numSlots)); HIP_TRY(ctx->nee.alloc(numSlots));
+    HIP_TRY(ctx->shadowDir.alloc(numSlots));
+    HIP_TRY(ctx->flags.alloc(numSlots)); HIP_TRY(ctx->sampleIdx.alloc(numSlots)); HIP_TRY(ctx->visible.alloc(numSlots));
+    HIP_TRY(ctx->extQueue.alloc(numSlots)); HIP_TRY(ctx->shadowQueue.alloc(numSlots));
+    HIP_TRY(ctx->queueCount.alloc(4)); HIP_TRY(ctx->activeSlots.alloc(1)); HIP_TRY(ctx->totals.alloc(4));
+    HIP_TRY(hipMemset(ctx->totals.ptr, 0, 4 * sizeof(uint64_t)));
+    HIP_TRY(hipMemset(ctx->queueCount.ptr, 0, 4 * sizeof(uint32_t)));
+
+    PathBuffers& pb = ctx->buffers;
+    pb.rng = ctx->rng.ptr; pb.rayOrg = ctx->rayOrg.ptr; pb.rayDir = ctx->rayDir.ptr; pb.hit = ctx->hit.ptr;
+    pb.alpha = ctx->alpha.ptr; pb.spR = ctx->spR.ptr; pb.spC = ctx->spC.ptr; pb.accR = ctx->accR.ptr; pb.accC = ctx->accC.ptr;
+    pb.nee = ctx->nee.ptr; pb.shadowDir = ctx->shadowDir.ptr; pb.flags = ctx->flags.ptr; pb.sampleIdx = ctx->sampleIdx.ptr;
+    pb.visible = ctx->visible.ptr; pb.extQueue = ctx->extQueue.ptr; pb.shadowQueue = ctx->shadowQueue.ptr;
+    pb.queueCount = ctx->queueCount.ptr; pb.activeSlots = ctx->activeSlots.ptr; pb.totals = ctx->totals.ptr;
+    pb.pixelXY = ctx->pixelXY.ptr;
+
+    RenderParams& rp = ctx->params;
+    rp.numSlots = (uint32_t)numSlots; rp.numPixels = numPixels; rp.stripes = stripes;
+    rp.sppBegin = 0; rp.sppCount = 0;
+    rp.rngSeed = st->rng_seed; rp.timeStart = st->time_start; rp.timeEnd = st->time_end;
+    rp.imageWidth = W; rp.imageHeight = H;
+    ctx->settings = *st;
+    ctx->shard = shard;
+    ctx->iterations = 0;
+    ctx->firstRenderCall = true;
+    ctx->haveRender = true;
+    return SLRHIP_OK;
+}
+
+int slrhip_render(slrhip_ctx* ctx, uint32_t sppBegin, uint32_t sppCount, void* streamPtr) {
+    if (!ctx) return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_render: null context");
+    if (!ctx->haveRender) return fail(SLRHIP_ERR_NO_SCENE, "slrhip_render: call slrhip_render_begin first");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t stream = (hipStream_t)streamPtr;
+    RenderParams& rp = ctx->params;
+    rp.sppBegin = sppBegin;
+    rp.sppCount = sppCount;
+    if (rp.numSlots == 0 || sppCount == 0) { ctx->firstRenderCall = false; return SLRHIP_OK; }
+
+    launchResetSlots(ctx->buffers, rp, ctx->firstRenderCall, stream);
+    ctx->firstRenderCall = false;
+    // grid-stride traversal kernels sized to fill the chip: 6 waves/SIMD at 78 VGPRs -> 6 blocks of 256 per CU
+    const uint32_t maxBlocks = (rp.numSlots + 255) / 256;
+    uint32_t traceBlocks = (uint32_t)ctx->numCUs * 8;
+    if (traceBlocks > maxBlocks) traceBlocks = maxBlocks;
+    if (traceBlocks == 0) traceBlocks = 1;
+
+    uint32_t parity = 0;
+    bool first = true;
+    uint32_t active = rp.numSlots;
+    // Each check costs one small copy + stream sync; 16 iterations between checks keeps it < 1 %.
+    const int kCheckEvery = 16;
+    const uint64_t maxIterations = (uint64_t)(sppCount / rp.stripes + 2) * 128 + 1024;   // paths are <= 100 vertices long
+    uint64_t it = 0;
+    while (active > 0) {
+        for (int k = 0; k < kCheckEvery; ++k) {
+            launchIteration(ctx->scene, ctx->buffers, rp, parity, first, traceBlocks, stream);
+            first = false;
+            parity ^= 1;
+            ++it;
+        }
+        HIP_TRY(hipMemcpyAsync(&active, ctx->activeSlots.ptr, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (it > maxIterations) return fail(SLRHIP_ERR_HIP, "slrhip_render: iteration bound exceeded (internal error)");
+    }
+    ctx->iterations += it;
+    HIP_TRY(hipGetLastError());
+    return SLRHIP_OK;
+}
+
+int slrhip_resolve_framebuffer(slrhip_ctx* ctx, float* deviceDst, size_t numFloats, void* streamPtr) {
+    if (!ctx || !deviceDst) return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_resolve_framebuffer: null argument");
+    if (!ctx->haveRender) return fail(SLRHIP_ERR_NO_SCENE, "slrhip_resolve_framebuffer: nothing rendered");
+    const RenderParams& rp = ctx->params;
+    const size_t need = (size_t)rp.imageWidth * rp.imageHeight * 3;
+    if (numFloats < need) return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_resolve_framebuffer: destination too small");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t stream = (hipStream_t)streamPtr;
+    HIP_TRY(hipMemsetAsync(deviceDst, 0, need * sizeof(float), stream));
+    if (rp.numPixels) launchResolve(ctx->buffers, rp, deviceDst, stream);
+    HIP_TRY(hipGetLastError());
+    return SLRHIP_OK;
+}
+
+int slrhip_read_framebuffer(slrhip_ctx* ctx, float* hostDst, size_t numFloats) {
+    if (!ctx || !hostDst) return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_read_framebuffer: null argument");
+    if (!ctx->haveRender) return fail(SLRHIP_ERR_NO_SCENE, "slrhip_read_framebuffer: nothing rendered");
+    const RenderParams& rp = ctx->params;
+    const size_t need = (size_t)rp.imageWidth * rp.imageHeight * 3;
+    if (numFloats < need) return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_read_framebuffer: destination too small");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(ctx->resolveScratch.alloc(need));
+    int rc = slrhip_resolve_framebuffer(ctx, ctx->resolveScratch.ptr, need, nullptr);
+    if (rc != SLRHIP_OK) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(hostDst, ctx->resolveScratch.ptr, need * sizeof(float), hipMemcpyDeviceToHost));
+    return SLRHIP_OK;
+}
+
+int slrhip_synchronize(slrhip_ctx* ctx) {
+    if (!ctx) return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_synchronize: null context");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipDeviceSynchronize());
+    return SLRHIP_OK;
+}
+
+int slrhip_get_counters(slrhip_ctx* ctx, slrhip_counters* out) {
+    if (!ctx || !out) return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_get_counters: null argument");
+    std::memset(out, 0, sizeof(*out));
+    out->bvh_nodes = ctx->nodes.count;
+    out->bvh_depth = ctx->bvhDepth;
+    out->build_seconds = ctx->buildSeconds;
+    out->iterations = ctx->iterations;
+    if (ctx->haveRender) {
+        HIP_TRY(hipSetDevice(ctx->device));
+        HIP_TRY(hipDeviceSynchronize());
+        uint64_t t[4] = {0, 0, 0, 0};
+        HIP_TRY(hipMemcpy(t, ctx->totals.ptr, sizeof(t), hipMemcpyDeviceToHost));
+        uint32_t q[4] = {0, 0, 0, 0};
+        HIP_TRY(hipMemcpy(q, ctx->queueCount.ptr, sizeof(q), hipMemcpyDeviceToHost));
+        // rays of the last, not yet folded, iteration are still in the queue counters
+        out->extension_rays = t[0] + q[0] + q[2];
+        out->shadow_rays = t[1] + q[1] + q[3];
+        out->samples = t[2];
+    }
+    return SLRHIP_OK;
+}
+
+// Diagnostic entry point: closest-hit queries against the uploaded scene (host arrays in and out).
+// rays: n x {org[3], dir[3], dist_min, dist_max}; hits: n x {triangle, dist, b0, b1}.
+int slrhip_trace_rays(slrhip_ctx* ctx, const float* rays, uint32_t n, float* hits) {
+    if (!ctx || !rays || !hits) return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_trace_rays: null argument");
+    if (!ctx->haveScene) return fail(SLRHIP_ERR_NO_SCENE, "slrhip_trace_rays: no scene uploaded");
+    if (n == 0) return SLRHIP_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    std::vector<float4> org(n), dir(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        const float* r = rays + (size_t)i * 8;
+        org[i] = make_float4(r[0], r[1], r[2], r[6]);
+        dir[i] = make_float4(r[3], r[4], r[5], r[7]);
+    }
+    DevArray<float4> dOrg, dDir, dOut;
+    HIP_TRY(dOrg.upload(org));
+    HIP_TRY(dDir.upload(dir));
+    HIP_TRY(dOut.alloc(n));
+    launchTraceBatch(ctx->scene, dOrg.ptr, dDir.ptr, dOut.ptr, n, nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(hits, dOut.ptr, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost));
+    return SLRHIP_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,120 @@
+"""GPU (MI355X): the HIP path, called through the C ABI, against the CPU oracle on the same
+seeded inputs, and against the golden fixtures produced by the compiled reference."""
+import numpy as np
+import pytest
+
+from helpers import assert_bit_equal, load_golden, scene_from_golden
+from oracle import binding as ob
+from slr_amd import Context, abi, scenes
+
+pytestmark = pytest.mark.gpu
+
+SCENES = ["rgb_tiny_box", "rgb_cornell_glass", "rgb_cornell_matte"]
+
+
+def frame_stats(a, b):
+    a, b = a.astype(np.float64), b.astype(np.float64)
+    diff = np.abs(a - b)
+    exact = (a.astype(np.float32).view(np.uint32) == b.astype(np.float32).view(np.uint32)) | ((a == 0) & (b == 0))
+    return dict(rmse=float(np.sqrt(np.mean((a - b) ** 2))), max_abs=float(diff.max()), exact_fraction=float(exact.mean()),
+                mean=float(a.mean()))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = Context(device=0, mode=abi.MODE_RGB, stripes=1)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_closest_hits_match_golden(ctx, name):
+    g = load_golden(name)
+    ctx.upload_scene(scene_from_golden(g))
+    rays, want = g["rays"], g["hits"]
+    tri, dist, b0, b1 = ctx.trace_rays(rays["org"], rays["dir"], rays["dist_min"], rays["dist_max"])
+    assert (tri == want["triangle"]).all()
+    hit = want["triangle"] != 0xFFFFFFFF
+    assert_bit_equal(dist[hit], want["dist"][hit], "dist")
+    assert_bit_equal(b0[hit], want["b0"][hit], "b0")
+    assert_bit_equal(b1[hit], want["b1"][hit], "b1")
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_frame_matches_reference_golden(ctx, name):
+    """stripes = 1 keeps the sensor's accumulation order, so the frame is expected bit-exact;
+    the stated tolerance (libm last-bit differences in double cos/sin) is <= 0.1 % of floats."""
+    g = load_golden(name)
+    st = ob.settings(int(g["width"]), int(g["height"]), int(g["seed"]))
+    fb = ctx.render_image(scene_from_golden(g), st, int(g["spp"]))
+    s = frame_stats(fb, g["framebuffer"])
+    assert s["exact_fraction"] >= 0.999, s
+    assert s["rmse"] <= 1e-3 * max(s["mean"], 1e-6), s
+    c = ctx.counters()
+    assert c.samples == int(g["width"]) * int(g["height"]) * int(g["spp"])
+
+
+def test_continued_render_matches_single_render(ctx):
+    g = load_golden("rgb_cornell_glass")
+    st = ob.settings(int(g["width"]), int(g["height"]), int(g["seed"]))
+    ctx.upload_scene(scene_from_golden(g))
+    ctx.render_begin(st)
+    half = int(g["spp"]) // 2
+    ctx.render(0, half)
+    s = frame_stats(ctx.read_framebuffer(), g["framebuffer_half"])
+    assert s["exact_fraction"] >= 0.999, s
+    ctx.render(half, half)
+    s = frame_stats(ctx.read_framebuffer(), g["framebuffer"])
+    assert s["exact_fraction"] >= 0.999, s
+
+
+@pytest.mark.parametrize("right", ["glass", "matte"])
+def test_full_cornell_against_oracle(ctx, oracle_rgb, right):
+    """Config-1/2 geometry (4 428 triangles) at a size the oracle finishes in seconds."""
+    sc = scenes.cornell_box_spheres(4.0 / 3.0, 48, 24, right)
+    st = ob.settings(160, 120, seed=777)
+    want, ctr = oracle_rgb.scene(sc).render(st, 16)
+    fb = ctx.render_image(sc, st, 16)
+    s = frame_stats(fb, want)
+    assert s["exact_fraction"] >= 0.999, s
+    assert s["rmse"] <= 1e-3 * s["mean"], s
+    c = ctx.counters()
+    assert c.samples == ctr.samples
+    assert abs(int(c.extension_rays) - int(ctr.extension_rays)) <= ctr.extension_rays * 1e-4
+    assert abs(int(c.shadow_rays) - int(ctr.shadow_rays)) <= ctr.shadow_rays * 1e-4
+
+
+def test_stripes_do_not_change_the_image(oracle_rgb):
+    """More paths in flight (sample stripes) only reorders the per-pixel float sum."""
+    sc = scenes.cornell_box_spheres(1.0, 24, 12, "glass")
+    st = ob.settings(64, 64, seed=5)
+    want, _ = oracle_rgb.scene(sc).render(st, 32)
+    c = Context(stripes=8)
+    fb = c.render_image(sc, st, 32)
+    c.close()
+    assert np.allclose(fb, want, rtol=2e-6, atol=1e-9)
+
+
+def test_shards_sum_to_full_image(ctx, oracle_rgb):
+    sc = scenes.cornell_box_spheres(4.0 / 3.0, 16, 8, "matte")
+    st = ob.settings(100, 76, seed=11)      # not a multiple of the 8x8 tile
+    want, _ = oracle_rgb.scene(sc).render(st, 4)
+    total = np.zeros_like(want)
+    ctx.upload_scene(sc)
+    for i in range(3):
+        ctx.render_begin(st, shard=(i, 3))
+        ctx.render(0, 4)
+        part = ctx.read_framebuffer()
+        assert ((total != 0) & (part != 0)).sum() == 0
+        total += part
+    s = frame_stats(total, want)
+    assert s["exact_fraction"] >= 0.999, s
+
+
+def test_errors_are_loud(ctx):
+    import ctypes as C
+    from slr_amd.binding import SlrHipError
+    c2 = Context()
+    with pytest.raises(SlrHipError):
+        c2.render_begin(ob.settings(8, 8))          # no scene uploaded
+    c2.close()
