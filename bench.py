@@ -1,0 +1,227 @@
+#!/usr/bin/env python
+"""bench.py — headline benchmark of the path-tracing hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One STEP = one complete render of BASELINE.json's configs[1]: the Cornell-box-spheres scene
+(Lambert + specular only), RGB, 1280x720, 1024 spp, through the C ABI (slrhip_render_begin ->
+slrhip_render -> slrhip_resolve_framebuffer), with the scene already resident in HBM.  With N > 1
+the 8x8 image tiles are dealt round-robin to the ranks (one process per GPU, no exchange while
+rendering) and the step ends with ONE RCCL reduce of the float framebuffer to rank 0 over xGMI;
+the total work is fixed, so the scaling is "strong".  value = Msamples/s of the whole job.
+Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s peak, ~6.3 TB/s achievable)
+
+# Algorithmic bytes ("Kernels and their rooflines")
+NODE_BYTES, TRI_BYTES = 128, 48
+CLOSEST_RAY_BYTES = 4 + 16 + 16 + 16       # queue entry, ray origin, ray direction, hit record written
+SHADOW_RAY_BYTES = 4 + 16 + 16 + 4         # queue entry, origin, direction+distMax, visibility written
+SHADE_SLOT_BYTES = 588                     # state read 200 + state written 180 + ShadeTri 96 + DevMaterial 80 + queues 8 + pixel RMW/... 24
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=1280)
+    ap.add_argument("--height", type=int, default=720)
+    ap.add_argument("--spp", type=int, default=1024)
+    ap.add_argument("--right-sphere", default="matte", choices=["matte", "glass"])
+    ap.add_argument("--stripes", type=int, default=0)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg (0 = skip)")
+    ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    from slr_amd import Context, abi, scenes
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    W, H, spp = args.width, args.height, args.spp
+    scene = scenes.cornell_box_spheres(W / H, 48, 24, args.right_sphere)
+    settings = abi.RenderSettings(W, H, 0.0, 0.0, 1.0, abi.DEFAULT_SEED)
+    flags = 0 if args.no_kernel_timing else abi.FLAG_TIME_KERNELS
+    ctx = Context(device=local_rank, mode=abi.MODE_RGB, stripes=args.stripes, flags=flags)
+    ctx.upload_scene(scene)
+    fb = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        ctx.render_begin(settings, shard=(rank, world))
+        ctx.render(0, spp, stream)
+        ctx.resolve_into(fb.data_ptr(), fb.numel(), stream)
+        if world > 1:
+            dist.reduce(fb, dst=0, op=dist.ReduceOp.SUM)     # disjoint supports: sum == gather
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    prof0 = ctx.profile()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    prof1 = ctx.profile()
+    counters = ctx.counters()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    total_samples = float(W) * H * spp * args.steps
+    value = total_samples / elapsed / 1e6
+
+    out = {
+        "metric": "Msamples/sec @1024spp 1280x720 (unidirectional path tracing, Cornell_Box_Spheres-shaped scene)",
+        "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: Cornell_Box_Spheres walls/light/camera (TestScenes/Cornell_Box_Spheres.txt:8-107,"
+                               "132-138) + two tessellated spheres (aluminium mirror, %s), %d triangles, RGB mode, %dx%d, %d spp, "
+                               "seed %d" % ("Lambert" if args.right_sphere == "matte" else "BK7 glass", len(scene.triangles), W, H, spp,
+                                            abi.DEFAULT_SEED),
+                   "sharding": "8x8 tiles round-robin over %d rank(s), one RCCL reduce of the framebuffer per step" % world,
+                   "stripes": int(args.stripes)},
+    }
+
+    if rank == 0:
+        # ---- per-kernel timing over the timed region (HIP events on the render stream) ------------
+        roof = None
+        kernels = {}
+        if not args.no_kernel_timing:
+            for k, name in enumerate(abi.KERNEL_NAMES):
+                n = prof1.launches[k] - prof0.launches[k]
+                ms = prof1.milliseconds[k] - prof0.milliseconds[k]
+                kernels[name] = {"launches": int(n), "ms_total": round(ms, 3), "avg_us": round(ms / n * 1e3, 3) if n else None}
+            # traversal statistics from an instrumented, untimed pass on this rank's shard
+            cctx = Context(device=local_rank, stripes=args.stripes, flags=abi.FLAG_COUNT_TRAVERSAL)
+            cctx.upload_scene(scene)
+            cctx.render_begin(settings, shard=(rank, world))
+            cctx.render(0, min(spp, 16))
+            cp = cctx.profile()
+            cc = cctx.counters()
+            cctx.close()
+            nodes_c, tris_c = cp.nodes[0] / max(cp.rays[0], 1), cp.triangles[0] / max(cp.rays[0], 1)
+            nodes_s, tris_s = cp.nodes[1] / max(cp.rays[1], 1), cp.triangles[1] / max(cp.rays[1], 1)
+            ext_per_sample = cc.extension_rays / max(cc.samples, 1)
+            shd_per_sample = cc.shadow_rays / max(cc.samples, 1)
+            per_ray = {"trace_closest": nodes_c * NODE_BYTES + tris_c * TRI_BYTES + CLOSEST_RAY_BYTES,
+                       "trace_shadow": nodes_s * NODE_BYTES + tris_s * TRI_BYTES + SHADOW_RAY_BYTES}
+            shard_samples = float(counters.samples) * args.steps     # sample totals restart at every render_begin
+            rays = {"trace_closest": shard_samples * ext_per_sample, "trace_shadow": shard_samples * shd_per_sample}
+            dom = max(kernels, key=lambda n: kernels[n]["ms_total"])
+            if dom == "shade":
+                # every live slot is visited once per iteration = once per extension ray (+ idle tail ignored)
+                units, unit_bytes = rays["trace_closest"], SHADE_SLOT_BYTES
+            else:
+                units, unit_bytes = rays[dom], per_ray[dom]
+            launches = max(kernels[dom]["launches"], 1)
+            bytes_per_launch = units * unit_bytes / launches
+            avg_s = kernels[dom]["ms_total"] / launches * 1e-3
+            achieved = bytes_per_launch / avg_s / 1e9 if avg_s > 0 else 0.0
+            roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "bytes_per_launch": round(bytes_per_launch), "avg_launch_us": kernels[dom]["avg_us"],
+                    "per_ray": {"nodes_closest": round(nodes_c, 3), "tris_closest": round(tris_c, 3), "nodes_shadow": round(nodes_s, 3),
+                                "tris_shadow": round(tris_s, 3), "extension_rays_per_sample": round(ext_per_sample, 4),
+                                "shadow_rays_per_sample": round(shd_per_sample, 4)}}
+            # whole-sample algorithmic bytes (SURVEY 8d formula) for reference
+            sample_bytes = (ext_per_sample * per_ray["trace_closest"] + shd_per_sample * per_ray["trace_shadow"] +
+                            ext_per_sample * SHADE_SLOT_BYTES)
+            roof["bytes_per_sample"] = round(sample_bytes, 1)
+            roof["sample_level_frac"] = round(sample_bytes * value * 1e6 / 1e9 / HBM_PEAK_GBS / world, 5)
+        out["roofline"] = roof
+        out["kernels"] = kernels
+        out["counters"] = {"samples": int(counters.samples), "extension_rays": int(counters.extension_rays),
+                           "shadow_rays": int(counters.shadow_rays), "iterations": int(counters.iterations),
+                           "bvh_nodes": int(counters.bvh_nodes), "bvh_depth": int(counters.bvh_depth),
+                           "build_seconds": round(counters.build_seconds, 4)}
+
+        # ---- CPU baseline and matched-seed parity (N = 1 only; the checker, never the thing measured) ---
+        out["cpu_baseline"] = None
+        if world == 1 and args.cpu_seconds > 0:
+            from oracle import binding as ob
+            # the GPU box gives a 1-GPU job a 16-CPU share; never start more workers than that
+            cores = max(1, min(len(os.sched_getaffinity(0)), os.cpu_count() or 1, 16))
+            ref = ob.load("ref_rgb")
+            if ref is not None:
+                rs = ref.scene(scene)
+                _, sec = ob.render_native(rs, settings, 1, cores)
+                n = int(max(1, min(64, args.cpu_seconds / max(sec, 1e-3))))
+                _, sec = ob.render_native(rs, settings, n, cores)
+                out["cpu_baseline"] = {"value": round(W * H * n / sec / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "reference",
+                                       "sample": "libSLR PathTracingRenderer::render unmodified (RGB build, SBVH), %dx%d x %d spp of the "
+                                                 "same scene, %d worker threads" % (W, H, n, cores)}
+            orc = ob.load("oracle").scene(scene)
+            t = time.perf_counter()
+            want, _ = orc.render(settings, 1, threads=cores)
+            sec1 = time.perf_counter() - t
+            n = int(max(1, min(16, 0.5 * args.cpu_seconds / max(sec1, 1e-3))))
+            t = time.perf_counter()
+            want, octr = orc.render(settings, n, threads=cores)
+            sec = time.perf_counter() - t
+            port = {"value": round(W * H * n / sec / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
+                    "sample": "oracle restatement, %dx%d x %d spp of the same scene, %d threads" % (W, H, n, cores)}
+            if out["cpu_baseline"] is None:
+                out["cpu_baseline"] = port
+            else:
+                out["cpu_baseline_port"] = port
+            if not args.no_parity:
+                pctx = Context(device=local_rank, stripes=1)
+                got = pctx.render_image(scene, settings, n)
+                pctx.close()
+                exact = (got.view(np.uint32) == want.view(np.uint32)) | ((got == 0) & (want == 0))
+                sens = 1.0 / (np.pi * 0.025 ** 2)
+                d = (got.astype(np.float64) - want) / n * sens
+                out["parity"] = {"spp": n, "rmse_vs_cpu_matched_seeds": float(np.sqrt(np.mean(d * d))),
+                                 "bit_exact_fraction": float(exact.mean()), "mean_radiance": float(want.mean() / n * sens)}
+            out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
+        print(json.dumps(out))
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

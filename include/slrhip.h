@@ -194,7 +194,7 @@ typedef struct slrhip_config {
     int32_t device;            /* HIP device ordinal                                         */
     int32_t mode;              /* SLRHIP_MODE_*                                              */
     uint32_t stripes;          /* sample stripes per pixel kept in flight (0 = auto)         */
-    uint32_t flags;            /* reserved, 0                                                */
+    uint32_t flags;            /* SLRHIP_FLAG_*                                              */
 } slrhip_config;
 
 /* ---- counters --------------------------------------------------------------------- */
@@ -207,6 +207,27 @@ typedef struct slrhip_counters {
     uint64_t bvh_depth;
     double   build_seconds;      /* host BVH build + upload                                  */
 } slrhip_counters;
+
+/* ---- per-kernel timing and traversal statistics (measurement) ------------- */
+/* Kernel classes of one wavefront iteration. */
+enum {
+    SLRHIP_KERNEL_TRACE_CLOSEST = 0,   /* Scene::intersect            */
+    SLRHIP_KERNEL_TRACE_SHADOW = 1,    /* Scene::testVisibility       */
+    SLRHIP_KERNEL_SHADE = 2,           /* getSurfacePoint .. bsdf->sample, sensor add, Job::kernel */
+    SLRHIP_KERNEL_COUNT = 3
+};
+typedef struct slrhip_profile {
+    uint64_t launches[SLRHIP_KERNEL_COUNT];
+    double   milliseconds[SLRHIP_KERNEL_COUNT];   /* sum of HIP-event durations on the render stream  */
+    uint64_t rays[2];                             /* rays processed by TRACE_CLOSEST / TRACE_SHADOW    */
+    uint64_t nodes[2];                            /* 4-wide nodes fetched (128 B each)                 */
+    uint64_t triangles[2];                        /* leaf triangles tested (48 B each)                 */
+    uint64_t slot_visits;                         /* slots processed by SHADE                          */
+} slrhip_profile;
+
+/* config.flags */
+#define SLRHIP_FLAG_TIME_KERNELS   1u   /* bracket every launch with HIP events (a few us per launch)        */
+#define SLRHIP_FLAG_COUNT_TRAVERSAL 2u  /* count nodes / triangles per ray (instrumented kernels, slower)    */
 
 typedef struct slrhip_ctx slrhip_ctx;
 
@@ -245,6 +266,9 @@ int slrhip_read_framebuffer(slrhip_ctx* ctx, float* host_dst, size_t num_floats)
 int slrhip_synchronize(slrhip_ctx* ctx);
 int slrhip_get_counters(slrhip_ctx* ctx, slrhip_counters* out);
 int slrhip_components(const slrhip_ctx* ctx);   /* 3 or 16 */
+/* Kernel times accumulate over the life of the context; ray / node / triangle totals restart at
+ * slrhip_render_begin.  Needs the matching config.flags.                                       */
+int slrhip_get_profile(slrhip_ctx* ctx, slrhip_profile* out);
 
 /* Diagnostic: closest-hit queries against the uploaded scene, the aggregate part of
  * Scene::intersect (SurfaceObject.cpp:267-269,408-416).  rays: n x {org[3], dir[3], dist_min,

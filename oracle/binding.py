@@ -53,6 +53,10 @@ class OracleLib:
         f("render_serial").argtypes = [C.c_void_p, C.POINTER(abi.RenderSettings), C.c_uint32, C.c_void_p,
                                        C.POINTER(OracleCounters)]
 
+        if prefix == "slr_ref_":
+            f("render_native").argtypes = [C.c_void_p, C.POINTER(abi.RenderSettings), C.c_uint32, C.c_int, C.c_void_p,
+                                           C.POINTER(C.c_double)]
+
     def _f(self, name):
         return getattr(self.lib, self.prefix + name)
 
@@ -119,6 +123,17 @@ class OracleScene:
         if rc != 0:
             raise RuntimeError("oracle render_serial failed: %d" % rc)
         return fb, ctr
+
+
+def render_native(ref_scene, settings, spp, threads=0):
+    """Times the reference's own unmodified multi-threaded render(); returns (fb, seconds)."""
+    h, w = settings.image_height, settings.image_width
+    fb = np.zeros((h, w, ref_scene.components), np.float32)
+    sec = C.c_double(0.0)
+    rc = ref_scene.lib._f("render_native")(ref_scene.handle, C.byref(settings), spp, threads, fb.ctypes.data, C.byref(sec))
+    if rc != 0:
+        raise RuntimeError("reference render failed: %d" % rc)
+    return fb, sec.value
 
 
 def load(which="oracle", mode=abi.MODE_RGB):

@@ -19,6 +19,7 @@
 #include <unistd.h>
 
 #include <atomic>
+#include <chrono>
 #include <map>
 #include <thread>
 #include <vector>
@@ -330,14 +331,13 @@ void slr_ref_rng(int32_t seed, uint32_t n, uint32_t* uints, float* floats) {
 // hardware_concurrency() == 1 (see the override above): one worker, one xorshift stream,
 // bit-deterministic.  render() writes NNN.bmp into the
 // cwd (:83-93), so it runs inside a scratch directory.
-int slr_ref_render_serial(slr_oracle_scene* s, const slrhip_render_settings* st, uint32_t spp, float* fbSum,
-                          slr_oracle_counters* counters) {
-    if (!s || !st || !fbSum) return 1;
+static int renderUnmodified(slr_oracle_scene* s, const slrhip_render_settings* st, uint32_t spp, unsigned threads, float* fbSum,
+                            double* seconds) {
     int rc = 0;
-    g_hwConcurrencyOverride = 1;
+    g_hwConcurrencyOverride = threads;
     char cwd[4096];
-    char tmpl[] = "/tmp/slr_ref_serial_XXXXXX";
-    if (!rc && (!getcwd(cwd, sizeof(cwd)) || !mkdtemp(tmpl) || chdir(tmpl) != 0)) rc = 4;
+    char tmpl[] = "/tmp/slr_ref_render_XXXXXX";
+    if (!getcwd(cwd, sizeof(cwd)) || !mkdtemp(tmpl) || chdir(tmpl) != 0) rc = 4;
     if (!rc) {
         RenderSettings settings;
         settings.addItem(RenderSettingItem::ImageWidth, (int32_t)st->image_width);
@@ -347,20 +347,38 @@ int slr_ref_render_serial(slr_oracle_scene* s, const slrhip_render_settings* st,
         settings.addItem(RenderSettingItem::Brightness, st->brightness);
         settings.addItem(RenderSettingItem::RNGSeed, (int32_t)st->rng_seed);
         PathTracingRenderer renderer(spp);
+        auto t0 = std::chrono::steady_clock::now();
         renderer.render(s->scene, settings);
+        if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         const ImageSensor* cs = s->camera->getSensor();
-        for (uint32_t y = 0; y < (uint32_t)st->image_height; ++y)
-            for (uint32_t x = 0; x < (uint32_t)st->image_width; ++x) {
-                DiscretizedSpectrum v = cs->pixel(x, y);
-                for (int k = 0; k < kComponents; ++k) fbSum[((size_t)y * st->image_width + x) * kComponents + k] = v[k];
-            }
+        if (fbSum)
+            for (uint32_t y = 0; y < (uint32_t)st->image_height; ++y)
+                for (uint32_t x = 0; x < (uint32_t)st->image_width; ++x) {
+                    DiscretizedSpectrum v = cs->pixel(x, y);
+                    for (int k = 0; k < kComponents; ++k) fbSum[((size_t)y * st->image_width + x) * kComponents + k] = v[k];
+                }
         if (chdir(cwd) != 0) rc = 4;
         std::string cmd = std::string("rm -rf ") + tmpl;
         if (system(cmd.c_str()) != 0) { /* scratch dir left behind */ }
-        if (counters) counters->samples += (uint64_t)st->image_width * st->image_height * spp;
     }
     g_hwConcurrencyOverride = 0;
     return rc;
+}
+
+int slr_ref_render_serial(slr_oracle_scene* s, const slrhip_render_settings* st, uint32_t spp, float* fbSum,
+                          slr_oracle_counters* counters) {
+    if (!s || !st || !fbSum) return 1;
+    int rc = renderUnmodified(s, st, spp, 1, fbSum, nullptr);
+    if (!rc && counters) counters->samples += (uint64_t)st->image_width * st->image_height * spp;
+    return rc;
+}
+
+int slr_ref_render_native(slr_oracle_scene* s, const slrhip_render_settings* st, uint32_t spp, int threads, float* fbSum,
+                          double* seconds) {
+    if (!s || !st) return 1;
+    long online = sysconf(_SC_NPROCESSORS_ONLN);
+    unsigned n = threads > 0 ? (unsigned)threads : (unsigned)(online > 0 ? online : 1);
+    return renderUnmodified(s, st, spp, n, fbSum, seconds);
 }
 
 } // extern "C"

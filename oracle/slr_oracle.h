@@ -75,6 +75,13 @@ int slr_oracle_render_serial(slr_oracle_scene* s, const slrhip_render_settings* 
 int slr_ref_render_serial(slr_oracle_scene* s, const slrhip_render_settings* settings, uint32_t spp,
                           float* fb_sum, slr_oracle_counters* counters);
 
+/* Timing only: the reference's own multi-threaded render() exactly as shipped (one ThreadPool
+ * per pass, 8x8 tile jobs, one xorshift stream per worker: PathTracingRenderer.cpp:27-98) on
+ * `threads` workers (<= 0: all online CPUs).  Not reproducible run to run, so its
+ * image is only sanity-checked.  Reference build only.                                        */
+int slr_ref_render_native(slr_oracle_scene* s, const slrhip_render_settings* settings, uint32_t spp, int threads,
+                          float* fb_sum, double* seconds);
+
 #ifdef __cplusplus
 }
 #endif

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(CSRC, "libslrhip.so")
 
 EXPORTS = ["slrhip_create", "slrhip_destroy", "slrhip_upload_scene", "slrhip_render_begin", "slrhip_render",
            "slrhip_resolve_framebuffer", "slrhip_read_framebuffer", "slrhip_synchronize", "slrhip_get_counters",
-           "slrhip_components", "slrhip_trace_rays", "slrhip_sample_seed", "slrhip_tonemap_bgr8", "slrhip_save_bmp",
+           "slrhip_components", "slrhip_get_profile", "slrhip_trace_rays", "slrhip_sample_seed", "slrhip_tonemap_bgr8", "slrhip_save_bmp",
            "slrhip_last_error_string", "slrhip_version"]
 
 
@@ -49,6 +49,7 @@ def load_library():
     lib.slrhip_synchronize.argtypes = [C.c_void_p]
     lib.slrhip_get_counters.argtypes = [C.c_void_p, C.POINTER(abi.Counters)]
     lib.slrhip_components.argtypes = [C.c_void_p]
+    lib.slrhip_get_profile.argtypes = [C.c_void_p, C.POINTER(abi.Profile)]
     lib.slrhip_trace_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     lib.slrhip_sample_seed.argtypes = [C.c_int32, C.c_uint32, C.c_uint32, C.c_uint32]
     lib.slrhip_sample_seed.restype = C.c_int32
@@ -67,10 +68,10 @@ def _check(lib, rc, what):
 class Context:
     """One rendering context on one GPU (slrhip_ctx)."""
 
-    def __init__(self, device=0, mode=abi.MODE_RGB, stripes=0):
+    def __init__(self, device=0, mode=abi.MODE_RGB, stripes=0, flags=0):
         self.lib = load_library()
         self.handle = C.c_void_p()
-        cfg = abi.Config(device, mode, stripes, 0)
+        cfg = abi.Config(device, mode, stripes, flags)
         _check(self.lib, self.lib.slrhip_create(C.byref(cfg), C.byref(self.handle)), "slrhip_create")
         self.components = self.lib.slrhip_components(self.handle)
         self.settings = None
@@ -113,6 +114,11 @@ class Context:
         c = abi.Counters()
         _check(self.lib, self.lib.slrhip_get_counters(self.handle, C.byref(c)), "slrhip_get_counters")
         return c
+
+    def profile(self):
+        p = abi.Profile()
+        _check(self.lib, self.lib.slrhip_get_profile(self.handle, C.byref(p)), "slrhip_get_profile")
+        return p
 
     def trace_rays(self, org, direction, dist_min, dist_max):
         n = len(org)

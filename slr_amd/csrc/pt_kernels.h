@@ -41,7 +41,8 @@ struct PathBuffers {
     uint32_t* shadowQueue;        // slot indices with a shadow ray this iteration
     uint32_t* queueCount;         // [parity][ext, shadow]
     uint32_t* activeSlots;        // slots that still have samples to do
-    uint64_t* totals;             // [0] extension rays, [1] shadow rays, [2] finished samples
+    uint64_t* totals;             // [0] extension rays, [1] shadow rays, [2] finished samples, [3] live slot visits,
+                                  // [4..7] nodes/tris fetched by closest / shadow traversal (COUNT builds)
     const uint32_t* pixelXY;      // pixel-of-shard -> x | y << 16
 };
 
@@ -51,11 +52,13 @@ struct RenderParams {
     int32_t rngSeed;
     float timeStart, timeEnd;
     uint32_t imageWidth, imageHeight;
+    uint32_t countSlots;          // SLRHIP_FLAG_COUNT_TRAVERSAL: also count live slots per shade launch
 };
 
 void launchResetSlots(const PathBuffers& pb, const RenderParams& rp, bool clearAccumulators, hipStream_t stream);
-void launchIteration(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, bool first, uint32_t traceBlocks,
-                     hipStream_t stream);
+void launchTraceClosest(const DevScene& sc, const PathBuffers& pb, uint32_t parity, uint32_t blocks, bool count, hipStream_t stream);
+void launchTraceShadow(const DevScene& sc, const PathBuffers& pb, uint32_t parity, uint32_t blocks, bool count, hipStream_t stream);
+void launchShade(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, hipStream_t stream);
 void launchResolve(const PathBuffers& pb, const RenderParams& rp, float* dst, hipStream_t stream);
 void launchTraceBatch(const DevScene& sc, const float4* org, const float4* dir, float4* out, uint32_t n, hipStream_t stream);
 

@@ -34,10 +34,14 @@ struct HitRec {
     float t, b0, b1;
 };
 
-template <bool ANY_HIT>
+struct TravCount {
+    uint32_t nodes, tris;
+};
+
+template <bool ANY_HIT, bool COUNT>
 __device__ __forceinline__ bool traverse(const float4* __restrict__ nodes4, const float4* __restrict__ tris4, V3 org, V3 dir, float tmin,
                                          float tmax, HitRec* hit, uint32_t* ldsStack /* [kLdsStack][blockDim] at this lane */,
-                                         uint32_t ldsStride) {
+                                         uint32_t ldsStride, TravCount* cnt) {
     const float idx = 1.0f / dir.x, idy = 1.0f / dir.y, idz = 1.0f / dir.z;      // Vector3.h:60 reciprocal()
     // float4 index inside a node: 0..2 = min xyz, 3..5 = max xyz, 6 = children
     const int nx = idx > 0.0f ? 0 : 3, fx = 3 - nx;
@@ -59,6 +63,7 @@ __device__ __forceinline__ bool traverse(const float4* __restrict__ nodes4, cons
                 float4 a = tp[0], b = tp[1], c = tp[2];
                 V3 v0(a.x, a.y, a.z), e1(b.x, b.y, b.z), e2(c.x, c.y, c.z);
                 uint32_t triIdx = __float_as_uint(a.w);
+                if (COUNT) ++cnt->tris;
                 // Moller-Trumbore exactly as TriangleMesh.cpp:139-160
                 V3 p = cross(dir, e2);
                 float det = dot(e1, p);
@@ -88,6 +93,7 @@ __device__ __forceinline__ bool traverse(const float4* __restrict__ nodes4, cons
             continue;
         }
 
+        if (COUNT) ++cnt->nodes;
         const float4* n = nodes4 + (size_t)cur * 8;
         const float4 nX = n[nx], nY = n[ny], nZ = n[nz];
         const float4 fX = n[fx], fY = n[fy], fZ = n[fz];
@@ -133,10 +139,18 @@ __device__ __forceinline__ bool traverse(const float4* __restrict__ nodes4, cons
     return found;
 }
 
+// One 64-bit atomic per wave for the instrumented (COUNT) builds.
+__device__ __forceinline__ void waveAdd(uint64_t* dst, uint32_t v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    if ((threadIdx.x & 63u) == 0 && v) atomicAdd((unsigned long long*)dst, (unsigned long long)v);
+}
+
 // Extension rays: closest hit.  Grid-stride over the queue the previous shade pass built.
+template <bool COUNT>
 __global__ __launch_bounds__(kTraceBlock) void k_trace_closest(DevScene sc, PathBuffers pb, uint32_t parity) {
     __shared__ uint32_t stack[kLdsStack * kTraceBlock];
     const uint32_t n = pb.queueCount[parity * 2 + 0];
+    TravCount cnt = {0, 0};
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         // fold this iteration's queue sizes into the totals and clear the counters the next shade pass fills
         pb.totals[0] += n;
@@ -149,24 +163,28 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace_closest(DevScene sc, Path
         const float4 o = pb.rayOrg[slot];
         const float4 d = pb.rayDir[slot];
         HitRec hit;
-        traverse<false>(sc.nodes, sc.leafTris, V3(o.x, o.y, o.z), V3(d.x, d.y, d.z), o.w, d.w, &hit, stack + threadIdx.x, kTraceBlock);
+        traverse<false, COUNT>(sc.nodes, sc.leafTris, V3(o.x, o.y, o.z), V3(d.x, d.y, d.z), o.w, d.w, &hit, stack + threadIdx.x, kTraceBlock, &cnt);
         pb.hit[slot] = make_float4(__uint_as_float(hit.tri), hit.t, hit.b0, hit.b1);
     }
+    if (COUNT) { waveAdd(&pb.totals[4], cnt.nodes); waveAdd(&pb.totals[5], cnt.tris); }
 }
 
 // Shadow rays: Scene::testVisibility (SurfaceObject.cpp:418-430) = "no hit in [eps, d(1-eps)]".
+template <bool COUNT>
 __global__ __launch_bounds__(kTraceBlock) void k_trace_shadow(DevScene sc, PathBuffers pb, uint32_t parity) {
     __shared__ uint32_t stack[kLdsStack * kTraceBlock];
     const uint32_t n = pb.queueCount[parity * 2 + 1];
+    TravCount cnt = {0, 0};
     for (uint32_t i = blockIdx.x * kTraceBlock + threadIdx.x; i < n; i += gridDim.x * kTraceBlock) {
         const uint32_t slot = pb.shadowQueue[i];
         const float4 o = pb.rayOrg[slot];
         const float4 d = pb.shadowDir[slot];
         HitRec hit;
-        bool occluded = traverse<true>(sc.nodes, sc.leafTris, V3(o.x, o.y, o.z), V3(d.x, d.y, d.z), kRayEpsilon, d.w, &hit,
-                                       stack + threadIdx.x, kTraceBlock);
+        bool occluded = traverse<true, COUNT>(sc.nodes, sc.leafTris, V3(o.x, o.y, o.z), V3(d.x, d.y, d.z), kRayEpsilon, d.w, &hit,
+                                              stack + threadIdx.x, kTraceBlock, &cnt);
         pb.visible[slot] = occluded ? 0u : 1u;
     }
+    if (COUNT) { waveAdd(&pb.totals[6], cnt.nodes); waveAdd(&pb.totals[7], cnt.tris); }
 }
 
 // Stand-alone closest-hit batch (parity tests of the traversal alone; not on the render path).
@@ -175,7 +193,8 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace_batch(DevScene sc, const 
     for (uint32_t i = blockIdx.x * kTraceBlock + threadIdx.x; i < n; i += gridDim.x * kTraceBlock) {
         const float4 o = org[i], d = dir[i];
         HitRec hit;
-        bool found = traverse<false>(sc.nodes, sc.leafTris, V3(o.x, o.y, o.z), V3(d.x, d.y, d.z), o.w, d.w, &hit, stack + threadIdx.x, kTraceBlock);
+        TravCount cnt = {0, 0};
+        bool found = traverse<false, false>(sc.nodes, sc.leafTris, V3(o.x, o.y, o.z), V3(d.x, d.y, d.z), o.w, d.w, &hit, stack + threadIdx.x, kTraceBlock, &cnt);
         out[i] = found ? make_float4(__uint_as_float(hit.tri), hit.t, hit.b0, hit.b1) : make_float4(__uint_as_float(0xFFFFFFFFu), INFINITY, 0.f, 0.f);
     }
 }
@@ -625,6 +644,10 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(DevScene sc, PathBuffers 
             if (mf) atomicAdd((unsigned long long*)&pb.totals[2], (unsigned long long)__popcll(mf));
         }
     }
+    if (rp.countSlots) {
+        const uint64_t ma = __ballot(slot < rp.numSlots && (emitExt || emitShadow || finished || becameIdle));
+        if (lane == 0 && ma) atomicAdd((unsigned long long*)&pb.totals[3], (unsigned long long)__popcll(ma));
+    }
 }
 
 // Start of a render() call: every slot of the shard goes to ST_START with sample counter 0
@@ -666,12 +689,15 @@ void launchResetSlots(const PathBuffers& pb, const RenderParams& rp, bool clearA
     hipLaunchKernelGGL(k_reset_slots, dim3((rp.numSlots + 255) / 256), dim3(256), 0, stream, pb, rp, clearAcc ? 1u : 0u);
 }
 
-void launchIteration(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, bool first, uint32_t traceBlocks,
-                     hipStream_t stream) {
-    if (!first) {
-        hipLaunchKernelGGL(k_trace_closest, dim3(traceBlocks), dim3(kTraceBlock), 0, stream, sc, pb, parity);
-        hipLaunchKernelGGL(k_trace_shadow, dim3(traceBlocks), dim3(kTraceBlock), 0, stream, sc, pb, parity);
-    }
+void launchTraceClosest(const DevScene& sc, const PathBuffers& pb, uint32_t parity, uint32_t blocks, bool count, hipStream_t stream) {
+    if (count) hipLaunchKernelGGL(k_trace_closest<true>, dim3(blocks), dim3(kTraceBlock), 0, stream, sc, pb, parity);
+    else hipLaunchKernelGGL(k_trace_closest<false>, dim3(blocks), dim3(kTraceBlock), 0, stream, sc, pb, parity);
+}
+void launchTraceShadow(const DevScene& sc, const PathBuffers& pb, uint32_t parity, uint32_t blocks, bool count, hipStream_t stream) {
+    if (count) hipLaunchKernelGGL(k_trace_shadow<true>, dim3(blocks), dim3(kTraceBlock), 0, stream, sc, pb, parity);
+    else hipLaunchKernelGGL(k_trace_shadow<false>, dim3(blocks), dim3(kTraceBlock), 0, stream, sc, pb, parity);
+}
+void launchShade(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, hipStream_t stream) {
     hipLaunchKernelGGL(k_shade, dim3((rp.numSlots + kShadeBlock - 1) / kShadeBlock), dim3(kShadeBlock), 0, stream, sc, pb, rp, parity);
 }
 

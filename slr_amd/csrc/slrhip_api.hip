@@ -40,12 +40,14 @@ int fail(int code, const std::string& msg) {
 template <typename T>
 struct DevArray {
     T* ptr = nullptr;
-    size_t count = 0;
+    size_t count = 0, capacity = 0;
     ~DevArray() { release(); }
-    void release() { if (ptr) { (void)hipFree(ptr); ptr = nullptr; count = 0; } }
+    void release() { if (ptr) { (void)hipFree(ptr); ptr = nullptr; count = 0; capacity = 0; } }
     hipError_t alloc(size_t n) {
-        release();
         if (n == 0) n = 1;
+        if (ptr && n <= capacity) { count = n; return hipSuccess; }     // reuse across render_begin calls
+        release();
+        capacity = n;
         hipError_t e = hipMalloc((void**)&ptr, n * sizeof(T));
         if (e == hipSuccess) count = n;
         return e;
@@ -106,6 +108,12 @@ struct slrhip_ctx {
     PathBuffers buffers;
     uint64_t iterations = 0;
     bool firstRenderCall = true;
+
+    // SLRHIP_FLAG_TIME_KERNELS: 4 events per iteration (before closest, after closest, after shadow, after shade)
+    std::vector<hipEvent_t> events;
+    uint64_t profLaunches[SLRHIP_KERNEL_COUNT] = {0, 0, 0};
+    double profMs[SLRHIP_KERNEL_COUNT] = {0, 0, 0};
+    ~slrhip_ctx() { for (hipEvent_t e : events) (void)hipEventDestroy(e); }
 };
 
 extern "C" {
@@ -322,8 +330,8 @@ int slrhip_render_begin(slrhip_ctx* ctx, const slrhip_render_settings* st, slrhi
     HIP_TRY(ctx->shadowDir.alloc(numSlots));
     HIP_TRY(ctx->flags.alloc(numSlots)); HIP_TRY(ctx->sampleIdx.alloc(numSlots)); HIP_TRY(ctx->visible.alloc(numSlots));
     HIP_TRY(ctx->extQueue.alloc(numSlots)); HIP_TRY(ctx->shadowQueue.alloc(numSlots));
-    HIP_TRY(ctx->queueCount.alloc(4)); HIP_TRY(ctx->activeSlots.alloc(1)); HIP_TRY(ctx->totals.alloc(4));
-    HIP_TRY(hipMemset(ctx->totals.ptr, 0, 4 * sizeof(uint64_t)));
+    HIP_TRY(ctx->queueCount.alloc(4)); HIP_TRY(ctx->activeSlots.alloc(1)); HIP_TRY(ctx->totals.alloc(8));
+    HIP_TRY(hipMemset(ctx->totals.ptr, 0, 8 * sizeof(uint64_t)));
     HIP_TRY(hipMemset(ctx->queueCount.ptr, 0, 4 * sizeof(uint32_t)));
 
     PathBuffers& pb = ctx->buffers;
@@ -339,6 +347,7 @@ int slrhip_render_begin(slrhip_ctx* ctx, const slrhip_render_settings* st, slrhi
     rp.sppBegin = 0; rp.sppCount = 0;
     rp.rngSeed = st->rng_seed; rp.timeStart = st->time_start; rp.timeEnd = st->time_end;
     rp.imageWidth = W; rp.imageHeight = H;
+    rp.countSlots = (ctx->config.flags & SLRHIP_FLAG_COUNT_TRAVERSAL) ? 1u : 0u;
     ctx->settings = *st;
     ctx->shard = shard;
     ctx->iterations = 0;
@@ -370,17 +379,48 @@ int slrhip_render(slrhip_ctx* ctx, uint32_t sppBegin, uint32_t sppCount, void* s
     uint32_t active = rp.numSlots;
     // Each check costs one small copy + stream sync; 16 iterations between checks keeps it < 1 %.
     const int kCheckEvery = 16;
+    const bool timeKernels = (ctx->config.flags & SLRHIP_FLAG_TIME_KERNELS) != 0;
+    const bool count = (ctx->config.flags & SLRHIP_FLAG_COUNT_TRAVERSAL) != 0;
+    if (timeKernels && ctx->events.empty()) {
+        ctx->events.resize((size_t)kCheckEvery * 4);
+        for (hipEvent_t& e : ctx->events) HIP_TRY(hipEventCreate(&e));
+    }
     const uint64_t maxIterations = (uint64_t)(sppCount / rp.stripes + 2) * 128 + 1024;   // paths are <= 100 vertices long
     uint64_t it = 0;
     while (active > 0) {
+        bool firstOfBatch[kCheckEvery];
         for (int k = 0; k < kCheckEvery; ++k) {
-            launchIteration(ctx->scene, ctx->buffers, rp, parity, first, traceBlocks, stream);
+            hipEvent_t* ev = timeKernels ? &ctx->events[(size_t)k * 4] : nullptr;
+            firstOfBatch[k] = first;
+            if (!first) {
+                if (ev) HIP_TRY(hipEventRecord(ev[0], stream));
+                launchTraceClosest(ctx->scene, ctx->buffers, parity, traceBlocks, count, stream);
+                if (ev) HIP_TRY(hipEventRecord(ev[1], stream));
+                launchTraceShadow(ctx->scene, ctx->buffers, parity, traceBlocks, count, stream);
+            }
+            if (ev) HIP_TRY(hipEventRecord(ev[2], stream));
+            launchShade(ctx->scene, ctx->buffers, rp, parity, stream);
+            if (ev) HIP_TRY(hipEventRecord(ev[3], stream));
             first = false;
             parity ^= 1;
             ++it;
         }
         HIP_TRY(hipMemcpyAsync(&active, ctx->activeSlots.ptr, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
+        if (timeKernels) {
+            for (int k = 0; k < kCheckEvery; ++k) {
+                hipEvent_t* ev = &ctx->events[(size_t)k * 4];
+                float ms = 0.0f;
+                if (!firstOfBatch[k]) {
+                    HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[1]));
+                    ctx->profMs[SLRHIP_KERNEL_TRACE_CLOSEST] += ms; ++ctx->profLaunches[SLRHIP_KERNEL_TRACE_CLOSEST];
+                    HIP_TRY(hipEventElapsedTime(&ms, ev[1], ev[2]));
+                    ctx->profMs[SLRHIP_KERNEL_TRACE_SHADOW] += ms; ++ctx->profLaunches[SLRHIP_KERNEL_TRACE_SHADOW];
+                }
+                HIP_TRY(hipEventElapsedTime(&ms, ev[2], ev[3]));
+                ctx->profMs[SLRHIP_KERNEL_SHADE] += ms; ++ctx->profLaunches[SLRHIP_KERNEL_SHADE];
+            }
+        }
         if (it > maxIterations) return fail(SLRHIP_ERR_HIP, "slrhip_render: iteration bound exceeded (internal error)");
     }
     ctx->iterations += it;
@@ -442,6 +482,23 @@ int slrhip_get_counters(slrhip_ctx* ctx, slrhip_counters* out) {
         out->extension_rays = t[0] + q[0] + q[2];
         out->shadow_rays = t[1] + q[1] + q[3];
         out->samples = t[2];
+    }
+    return SLRHIP_OK;
+}
+
+int slrhip_get_profile(slrhip_ctx* ctx, slrhip_profile* out) {
+    if (!ctx || !out) return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_get_profile: null argument");
+    std::memset(out, 0, sizeof(*out));
+    for (int k = 0; k < SLRHIP_KERNEL_COUNT; ++k) { out->launches[k] = ctx->profLaunches[k]; out->milliseconds[k] = ctx->profMs[k]; }
+    if (ctx->haveRender) {
+        HIP_TRY(hipSetDevice(ctx->device));
+        HIP_TRY(hipDeviceSynchronize());
+        uint64_t t[8];
+        HIP_TRY(hipMemcpy(t, ctx->totals.ptr, sizeof(t), hipMemcpyDeviceToHost));
+        out->rays[0] = t[0]; out->rays[1] = t[1];
+        out->nodes[0] = t[4]; out->triangles[0] = t[5];
+        out->nodes[1] = t[6]; out->triangles[1] = t[7];
+        out->slot_visits = t[3];
     }
     return SLRHIP_OK;
 }
