@@ -213,8 +213,9 @@ typedef struct slrhip_counters {
 enum {
     SLRHIP_KERNEL_TRACE_CLOSEST = 0,   /* Scene::intersect            */
     SLRHIP_KERNEL_TRACE_SHADOW = 1,    /* Scene::testVisibility       */
-    SLRHIP_KERNEL_SHADE = 2,           /* getSurfacePoint .. bsdf->sample, sensor add, Job::kernel */
-    SLRHIP_KERNEL_COUNT = 3
+    SLRHIP_KERNEL_SHADE = 2,           /* k_logic: getSurfacePoint .. bsdf->sample (PathTracingRenderer.cpp:149-258) */
+    SLRHIP_KERNEL_REGEN = 3,           /* k_regen: sensor->add + Job::kernel's camera ray (:100-130)  */
+    SLRHIP_KERNEL_COUNT = 4
 };
 typedef struct slrhip_profile {
     uint64_t launches[SLRHIP_KERNEL_COUNT];
@@ -222,7 +223,7 @@ typedef struct slrhip_profile {
     uint64_t rays[2];                             /* rays processed by TRACE_CLOSEST / TRACE_SHADOW    */
     uint64_t nodes[2];                            /* 4-wide nodes fetched (128 B each)                 */
     uint64_t triangles[2];                        /* leaf triangles tested (48 B each)                 */
-    uint64_t slot_visits;                         /* slots processed by SHADE                          */
+    uint64_t slot_visits;                         /* live slots processed by SHADE                     */
 } slrhip_profile;
 
 /* config.flags */

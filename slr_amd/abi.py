@@ -68,12 +68,12 @@ class Counters(C.Structure):
 
 
 class Profile(C.Structure):
-    _fields_ = [("launches", C.c_uint64 * 3), ("milliseconds", C.c_double * 3), ("rays", C.c_uint64 * 2),
+    _fields_ = [("launches", C.c_uint64 * 4), ("milliseconds", C.c_double * 4), ("rays", C.c_uint64 * 2),
                 ("nodes", C.c_uint64 * 2), ("triangles", C.c_uint64 * 2), ("slot_visits", C.c_uint64)]
 
 
 FLAG_TIME_KERNELS, FLAG_COUNT_TRAVERSAL = 1, 2
-KERNEL_NAMES = ("trace_closest", "trace_shadow", "shade")
+KERNEL_NAMES = ("trace_closest", "trace_shadow", "shade", "regen")
 
 DEFAULT_SEED = 1509761209  # libSLRSceneGraph/API.cpp:1080
 

@@ -119,6 +119,37 @@ SLR_DEV int32_t sampleSeed(int32_t rngSeed, uint32_t px, uint32_t py, uint32_t p
     return (int32_t)h;
 }
 
+// Double-precision sin and cos for |x| <= 2 pi (the concentric map only produces theta in
+// [-pi/4, 7 pi/4]).  The reference calls the host libm's double cos/sin and rounds the product
+// r * cos(theta) to float, so any double result within a few 1e-16 of the true value rounds to the
+// same float except when the exact product lies within ~1e-9 ulp_float of a rounding boundary.
+// Two-term Cody-Waite reduction by pi/2 and the fdlibm kernel polynomials (< 1 ulp_double);
+// about 30 f64 operations instead of the general-range library sincos.
+SLR_DEV void sincosQuarterTurns(double x, double* sn, double* cs) {
+    const double k = rint(x * 6.36619772367581382433e-01);                 // x * 2/pi
+    double r = fma(-k, 1.57079632673412561417e+00, x);                      // pio2_1  (33 bits of pi/2)
+    r = fma(-k, 6.07710050650619224932e-11, r);                             // pio2_1t (pi/2 - pio2_1)
+    const double z = r * r;
+    // __kernel_sin
+    double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = fma(z, ps, 2.75573137070700676789e-06);
+    ps = fma(z, ps, -1.98412698298579493134e-04);
+    ps = fma(z, ps, 8.33333333332248946124e-03);
+    const double sinr = fma(z * r, fma(z, ps, -1.66666666666666324348e-01), r);
+    // __kernel_cos
+    double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = fma(z, pc, -2.75573143513906633035e-07);
+    pc = fma(z, pc, 2.48015872894767294178e-05);
+    pc = fma(z, pc, -1.38888888888741095749e-03);
+    pc = fma(z, pc, 4.16666666666666019037e-02);
+    const double cosr = fma(z * z, pc, fma(z, -0.5, 1.0));
+    const int q = (int)k & 3;
+    const double s0 = (q & 1) ? cosr : sinr;
+    const double c0 = (q & 1) ? sinr : cosr;
+    *sn = (q & 2) ? -s0 : s0;
+    *cs = (q == 1 || q == 2) ? -c0 : c0;
+}
+
 // ---- Core/distributions.cpp:37-70 (float instantiation) --------------------------------------------
 // theta *= M_PI_4 is a double multiply rounded to float; cos/sin are the double functions and
 // r * cos(theta) a double product rounded to float.
@@ -137,7 +168,7 @@ SLR_DEV void concentricSampleDisk(float u0, float u1, float* dx, float* dy) {
     }
     theta = (float)((double)theta * kPi4);
     double s, c;
-    sincos((double)theta, &s, &c);
+    sincosQuarterTurns((double)theta, &s, &c);
     *dx = (float)((double)r * c);
     *dy = (float)((double)r * s);
 }

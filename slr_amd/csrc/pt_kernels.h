@@ -9,17 +9,40 @@ namespace slrhip {
 
 // Scene arrays resident in HBM (uploaded once by slrhip_upload_scene).
 struct DevScene {
-    const float4* nodes;          // QNode as 8 x float4
+    const float4* nodes;          // QNode as 8 x float4, breadth-first
     const float4* leafTris;       // LeafTri as 3 x float4
     const ShadeTri* shadeTris;    // indexed by scene triangle index
     const LightTri* lightTris;    // indexed by light index
     const DevMaterial* materials;
     const float* lightPMF;        // RegularConstantDiscrete1D of the aggregate's light list
     const float* lightCDF;        // numLights + 1 entries
+    uint32_t numNodes;
+    uint32_t numMaterials;
     uint32_t numLights;
     uint32_t lightPow2;           // prevPowerOf2(numLights)
     DevCamera camera;
 };
+
+// Queue counters.  A counter word that every wave bumps saturates near 88 atomics/us on this chip
+// (MI355X_MICROARCH.md, rows "dequeue" / "fanin"), which made the first version of the shade kernel
+// atomic-bound (14 400 waves -> 164 us).  So: (1) there is NO extension-ray queue — nearly every live
+// slot has one, the traversal kernel walks all slots and reads the state flag; (2) the shadow and
+// regen queues are split into kShards regions, a workgroup appends to region (blockIdx % kShards) with
+// ONE atomic per workgroup, and every counter sits on its own 128-byte line.
+// One set of counters per iteration parity: kernels READ set `parity`; the logic kernel FILLS set
+// `parity ^ 1`, which k_trace_closest clears beforehand.
+static const uint32_t kShards = 16;
+static const uint32_t kCounterStride = 32;                 // words: one 128-byte line per counter
+enum { Q_SHADOW = 0, Q_REGEN = 1, Q_KINDS = 2 };
+static const uint32_t kQueueSetWords = Q_KINDS * kShards * kCounterStride;
+__host__ __device__ inline uint32_t queueCounterIndex(uint32_t parity, uint32_t kind, uint32_t shard) {
+    return parity * kQueueSetWords + (kind * kShards + shard) * kCounterStride;
+}
+// statistics, sharded the same way: [kind][shard] 64-bit words on separate lines
+enum { T_EXT_RAYS = 0, T_SHADOW_RAYS = 1, T_NODES_CLOSEST = 2, T_TRIS_CLOSEST = 3, T_NODES_SHADOW = 4, T_TRIS_SHADOW = 5,
+       T_SLOT_VISITS = 6, T_KINDS = 7 };
+static const uint32_t kTotalStride = 16;                   // 64-bit words: one 128-byte line
+__host__ __device__ inline uint32_t totalIndex(uint32_t kind, uint32_t shard) { return (kind * kShards + shard) * kTotalStride; }
 
 // Path state, SoA, one record per slot (slot = stripe * numPixels + pixel-of-shard).
 struct PathBuffers {
@@ -37,12 +60,11 @@ struct PathBuffers {
     uint32_t* flags;
     uint32_t* sampleIdx;
     uint32_t* visible;            // result of the shadow ray
-    uint32_t* extQueue;           // slot indices with an extension ray this iteration
-    uint32_t* shadowQueue;        // slot indices with a shadow ray this iteration
-    uint32_t* queueCount;         // [parity][ext, shadow]
+    uint32_t* shadowQueue;        // kShards regions of shardCapacity slot indices: shadow rays of this iteration
+    uint32_t* regenQueue;         // same layout: slots whose path ended (accumulate pixel, start next sample)
+    uint32_t* queueCount;         // [parity][kind][shard], see queueCounterIndex
     uint32_t* activeSlots;        // slots that still have samples to do
-    uint64_t* totals;             // [0] extension rays, [1] shadow rays, [2] finished samples, [3] live slot visits,
-                                  // [4..7] nodes/tris fetched by closest / shadow traversal (COUNT builds)
+    uint64_t* totals;             // [kind][shard], see totalIndex
     const uint32_t* pixelXY;      // pixel-of-shard -> x | y << 16
 };
 
@@ -52,14 +74,19 @@ struct RenderParams {
     int32_t rngSeed;
     float timeStart, timeEnd;
     uint32_t imageWidth, imageHeight;
-    uint32_t countSlots;          // SLRHIP_FLAG_COUNT_TRAVERSAL: also count live slots per shade launch
+    uint32_t countSlots;          // SLRHIP_FLAG_COUNT_TRAVERSAL: also count live slots per logic launch
+    uint32_t shardCapacity;       // entries per queue region = ceil(numBlocks / kShards) * 256
 };
 
 void launchResetSlots(const PathBuffers& pb, const RenderParams& rp, bool clearAccumulators, hipStream_t stream);
-void launchTraceClosest(const DevScene& sc, const PathBuffers& pb, uint32_t parity, uint32_t blocks, bool count, hipStream_t stream);
-void launchTraceShadow(const DevScene& sc, const PathBuffers& pb, uint32_t parity, uint32_t blocks, bool count, hipStream_t stream);
-void launchShade(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, hipStream_t stream);
+void launchRegen(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, hipStream_t stream);
+void launchTraceClosest(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, uint32_t blocks, bool count,
+                        hipStream_t stream);
+void launchTraceShadow(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, uint32_t blocks, bool count,
+                       hipStream_t stream);
+void launchLogic(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, hipStream_t stream);
 void launchResolve(const PathBuffers& pb, const RenderParams& rp, float* dst, hipStream_t stream);
 void launchTraceBatch(const DevScene& sc, const float4* org, const float4* dir, float4* out, uint32_t n, hipStream_t stream);
+int traceBlocksPerCU();
 
 } // namespace slrhip

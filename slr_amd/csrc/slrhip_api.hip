@@ -37,19 +37,28 @@ int fail(int code, const std::string& msg) {
             return fail(SLRHIP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));             \
     } while (0)
 
+// hipMalloc returns 2 MiB-aligned blocks, so the record of slot i would sit at the same offset modulo
+// the HBM channel interleave in every per-slot array, and a wave that loads its ten state records back to
+// back would queue all of them on one channel ("partition camping").  Each array therefore starts at its
+// own skew: a distinct odd multiple of 256 B plus a few KiB.
+static size_t g_skewCounter = 0;
+
 template <typename T>
 struct DevArray {
     T* ptr = nullptr;
+    void* base = nullptr;
     size_t count = 0, capacity = 0;
     ~DevArray() { release(); }
-    void release() { if (ptr) { (void)hipFree(ptr); ptr = nullptr; count = 0; capacity = 0; } }
-    hipError_t alloc(size_t n) {
+    void release() { if (base) { (void)hipFree(base); base = nullptr; ptr = nullptr; count = 0; capacity = 0; } }
+    hipError_t alloc(size_t n, bool skew = false) {
         if (n == 0) n = 1;
         if (ptr && n <= capacity) { count = n; return hipSuccess; }     // reuse across render_begin calls
         release();
         capacity = n;
-        hipError_t e = hipMalloc((void**)&ptr, n * sizeof(T));
-        if (e == hipSuccess) count = n;
+        size_t offset = 0;
+        if (skew) { size_t k = ++g_skewCounter; offset = (k % 61) * 4352 + (k % 7) * 256; }
+        hipError_t e = hipMalloc(&base, n * sizeof(T) + offset);
+        if (e == hipSuccess) { ptr = reinterpret_cast<T*>(static_cast<char*>(base) + offset); count = n; }
         return e;
     }
     hipError_t upload(const std::vector<T>& v) {
@@ -102,19 +111,33 @@ struct slrhip_ctx {
     DevArray<uint32_t> pixelXY;
     DevArray<uint4> rng;
     DevArray<float4> rayOrg, rayDir, hit, alpha, spR, spC, accR, accC, nee, shadowDir;
-    DevArray<uint32_t> flags, sampleIdx, visible, extQueue, shadowQueue, queueCount, activeSlots;
+    DevArray<uint32_t> flags, sampleIdx, visible, shadowQueue, regenQueue, queueCount, activeSlots;
     DevArray<uint64_t> totals;
     DevArray<float> resolveScratch;
     PathBuffers buffers;
     uint64_t iterations = 0;
+    uint64_t samplesDone = 0;
     bool firstRenderCall = true;
 
     // SLRHIP_FLAG_TIME_KERNELS: 4 events per iteration (before closest, after closest, after shadow, after shade)
     std::vector<hipEvent_t> events;
-    uint64_t profLaunches[SLRHIP_KERNEL_COUNT] = {0, 0, 0};
-    double profMs[SLRHIP_KERNEL_COUNT] = {0, 0, 0};
+    uint64_t profLaunches[SLRHIP_KERNEL_COUNT] = {0, 0, 0, 0};
+    double profMs[SLRHIP_KERNEL_COUNT] = {0, 0, 0, 0};
     ~slrhip_ctx() { for (hipEvent_t e : events) (void)hipEventDestroy(e); }
 };
+
+// Sum the sharded statistics words (pt_kernels.h: totalIndex).
+static int readTotals(slrhip_ctx* ctx, uint64_t* out) {
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipDeviceSynchronize());
+    std::vector<uint64_t> raw(ctx->totals.count);
+    HIP_TRY(hipMemcpy(raw.data(), ctx->totals.ptr, raw.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    for (uint32_t k = 0; k < T_KINDS; ++k) {
+        out[k] = 0;
+        for (uint32_t sh = 0; sh < kShards; ++sh) out[k] += raw[totalIndex(k, sh)];
+    }
+    return SLRHIP_OK;
+}
 
 extern "C" {
 
@@ -280,6 +303,8 @@ int slrhip_upload_scene(slrhip_ctx* ctx, const slrhip_scene_desc* d) {
     sc.materials = ctx->materials.ptr;
     sc.lightPMF = ctx->lightPMF.ptr;
     sc.lightCDF = ctx->lightCDF.ptr;
+    sc.numNodes = (uint32_t)bvh.nodes.size();
+    sc.numMaterials = (uint32_t)mats.size();
     sc.numLights = (uint32_t)lights.size();
     sc.lightPow2 = prevPowerOf2(sc.numLights);
     sc.camera = cam;
@@ -323,22 +348,26 @@ int slrhip_render_begin(slrhip_ctx* ctx, const slrhip_render_settings* st, slrhi
     if (numSlots > 0x7FFFFFFFull) return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_render_begin: too many path slots");
 
     HIP_TRY(ctx->pixelXY.upload(pixels));
-    HIP_TRY(ctx->rng.alloc(numSlots));
-    HIP_TRY(ctx->rayOrg.alloc(numSlots)); HIP_TRY(ctx->rayDir.alloc(numSlots)); HIP_TRY(ctx->hit.alloc(numSlots));
-    HIP_TRY(ctx->alpha.alloc(numSlots)); HIP_TRY(ctx->spR.alloc(numSlots)); HIP_TRY(ctx->spC.alloc(numSlots));
-    HIP_TRY(ctx->accR.alloc(numSlots)); HIP_TRY(ctx->accC.alloc(numSlots)); HIP_TRY(ctx->nee.alloc(numSlots));
-    HIP_TRY(ctx->shadowDir.alloc(numSlots));
-    HIP_TRY(ctx->flags.alloc(numSlots)); HIP_TRY(ctx->sampleIdx.alloc(numSlots)); HIP_TRY(ctx->visible.alloc(numSlots));
-    HIP_TRY(ctx->extQueue.alloc(numSlots)); HIP_TRY(ctx->shadowQueue.alloc(numSlots));
-    HIP_TRY(ctx->queueCount.alloc(4)); HIP_TRY(ctx->activeSlots.alloc(1)); HIP_TRY(ctx->totals.alloc(8));
-    HIP_TRY(hipMemset(ctx->totals.ptr, 0, 8 * sizeof(uint64_t)));
-    HIP_TRY(hipMemset(ctx->queueCount.ptr, 0, 4 * sizeof(uint32_t)));
+    HIP_TRY(ctx->rng.alloc(numSlots, true));
+    HIP_TRY(ctx->rayOrg.alloc(numSlots, true)); HIP_TRY(ctx->rayDir.alloc(numSlots, true)); HIP_TRY(ctx->hit.alloc(numSlots, true));
+    HIP_TRY(ctx->alpha.alloc(numSlots, true)); HIP_TRY(ctx->spR.alloc(numSlots, true)); HIP_TRY(ctx->spC.alloc(numSlots, true));
+    HIP_TRY(ctx->accR.alloc(numSlots, true)); HIP_TRY(ctx->accC.alloc(numSlots, true)); HIP_TRY(ctx->nee.alloc(numSlots, true));
+    HIP_TRY(ctx->shadowDir.alloc(numSlots, true));
+    HIP_TRY(ctx->flags.alloc(numSlots, true)); HIP_TRY(ctx->sampleIdx.alloc(numSlots, true)); HIP_TRY(ctx->visible.alloc(numSlots, true));
+    // queue regions: slot block b appends to region b % kShards, so a region holds at most ceil(numBlocks / kShards) blocks
+    const uint32_t numBlocks = (uint32_t)((numSlots + 255) / 256);
+    const uint32_t shardCapacity = ((numBlocks + kShards - 1) / kShards) * 256;
+    HIP_TRY(ctx->shadowQueue.alloc((size_t)shardCapacity * kShards, true)); HIP_TRY(ctx->regenQueue.alloc((size_t)shardCapacity * kShards, true));
+    HIP_TRY(ctx->queueCount.alloc(2 * kQueueSetWords)); HIP_TRY(ctx->activeSlots.alloc(1));
+    HIP_TRY(ctx->totals.alloc((size_t)T_KINDS * kShards * kTotalStride));
+    HIP_TRY(hipMemset(ctx->totals.ptr, 0, ctx->totals.count * sizeof(uint64_t)));
+    HIP_TRY(hipMemset(ctx->queueCount.ptr, 0, 2 * kQueueSetWords * sizeof(uint32_t)));
 
     PathBuffers& pb = ctx->buffers;
     pb.rng = ctx->rng.ptr; pb.rayOrg = ctx->rayOrg.ptr; pb.rayDir = ctx->rayDir.ptr; pb.hit = ctx->hit.ptr;
     pb.alpha = ctx->alpha.ptr; pb.spR = ctx->spR.ptr; pb.spC = ctx->spC.ptr; pb.accR = ctx->accR.ptr; pb.accC = ctx->accC.ptr;
     pb.nee = ctx->nee.ptr; pb.shadowDir = ctx->shadowDir.ptr; pb.flags = ctx->flags.ptr; pb.sampleIdx = ctx->sampleIdx.ptr;
-    pb.visible = ctx->visible.ptr; pb.extQueue = ctx->extQueue.ptr; pb.shadowQueue = ctx->shadowQueue.ptr;
+    pb.visible = ctx->visible.ptr; pb.shadowQueue = ctx->shadowQueue.ptr; pb.regenQueue = ctx->regenQueue.ptr;
     pb.queueCount = ctx->queueCount.ptr; pb.activeSlots = ctx->activeSlots.ptr; pb.totals = ctx->totals.ptr;
     pb.pixelXY = ctx->pixelXY.ptr;
 
@@ -348,6 +377,8 @@ int slrhip_render_begin(slrhip_ctx* ctx, const slrhip_render_settings* st, slrhi
     rp.rngSeed = st->rng_seed; rp.timeStart = st->time_start; rp.timeEnd = st->time_end;
     rp.imageWidth = W; rp.imageHeight = H;
     rp.countSlots = (ctx->config.flags & SLRHIP_FLAG_COUNT_TRAVERSAL) ? 1u : 0u;
+    rp.shardCapacity = shardCapacity;
+    ctx->samplesDone = 0;
     ctx->settings = *st;
     ctx->shard = shard;
     ctx->iterations = 0;
@@ -368,62 +399,55 @@ int slrhip_render(slrhip_ctx* ctx, uint32_t sppBegin, uint32_t sppCount, void* s
 
     launchResetSlots(ctx->buffers, rp, ctx->firstRenderCall, stream);
     ctx->firstRenderCall = false;
-    // grid-stride traversal kernels sized to fill the chip: 6 waves/SIMD at 78 VGPRs -> 6 blocks of 256 per CU
-    const uint32_t maxBlocks = (rp.numSlots + 255) / 256;
-    uint32_t traceBlocks = (uint32_t)ctx->numCUs * 8;
-    if (traceBlocks > maxBlocks) traceBlocks = maxBlocks;
-    if (traceBlocks == 0) traceBlocks = 1;
+    // persistent traversal workgroups: a fixed number per CU, each staging the top of the tree in LDS once
+    const uint32_t traceBlocks = (uint32_t)ctx->numCUs * (uint32_t)traceBlocksPerCU();
 
     uint32_t parity = 0;
-    bool first = true;
     uint32_t active = rp.numSlots;
     // Each check costs one small copy + stream sync; 16 iterations between checks keeps it < 1 %.
     const int kCheckEvery = 16;
+    const int kEv = 5;    // events per iteration: before regen, after regen, after closest, after shadow, after logic
     const bool timeKernels = (ctx->config.flags & SLRHIP_FLAG_TIME_KERNELS) != 0;
     const bool count = (ctx->config.flags & SLRHIP_FLAG_COUNT_TRAVERSAL) != 0;
     if (timeKernels && ctx->events.empty()) {
-        ctx->events.resize((size_t)kCheckEvery * 4);
+        ctx->events.resize((size_t)kCheckEvery * kEv);
         for (hipEvent_t& e : ctx->events) HIP_TRY(hipEventCreate(&e));
     }
     const uint64_t maxIterations = (uint64_t)(sppCount / rp.stripes + 2) * 128 + 1024;   // paths are <= 100 vertices long
     uint64_t it = 0;
     while (active > 0) {
-        bool firstOfBatch[kCheckEvery];
         for (int k = 0; k < kCheckEvery; ++k) {
-            hipEvent_t* ev = timeKernels ? &ctx->events[(size_t)k * 4] : nullptr;
-            firstOfBatch[k] = first;
-            if (!first) {
-                if (ev) HIP_TRY(hipEventRecord(ev[0], stream));
-                launchTraceClosest(ctx->scene, ctx->buffers, parity, traceBlocks, count, stream);
-                if (ev) HIP_TRY(hipEventRecord(ev[1], stream));
-                launchTraceShadow(ctx->scene, ctx->buffers, parity, traceBlocks, count, stream);
-            }
+            hipEvent_t* ev = timeKernels ? &ctx->events[(size_t)k * kEv] : nullptr;
+            if (ev) HIP_TRY(hipEventRecord(ev[0], stream));
+            launchRegen(ctx->scene, ctx->buffers, rp, parity, stream);
+            if (ev) HIP_TRY(hipEventRecord(ev[1], stream));
+            launchTraceClosest(ctx->scene, ctx->buffers, rp, parity, traceBlocks, count, stream);
             if (ev) HIP_TRY(hipEventRecord(ev[2], stream));
-            launchShade(ctx->scene, ctx->buffers, rp, parity, stream);
+            launchTraceShadow(ctx->scene, ctx->buffers, rp, parity, traceBlocks, count, stream);
             if (ev) HIP_TRY(hipEventRecord(ev[3], stream));
-            first = false;
+            launchLogic(ctx->scene, ctx->buffers, rp, parity, stream);
+            if (ev) HIP_TRY(hipEventRecord(ev[4], stream));
             parity ^= 1;
             ++it;
         }
         HIP_TRY(hipMemcpyAsync(&active, ctx->activeSlots.ptr, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         if (timeKernels) {
+            static const int cls[4] = {SLRHIP_KERNEL_REGEN, SLRHIP_KERNEL_TRACE_CLOSEST, SLRHIP_KERNEL_TRACE_SHADOW, SLRHIP_KERNEL_SHADE};
             for (int k = 0; k < kCheckEvery; ++k) {
-                hipEvent_t* ev = &ctx->events[(size_t)k * 4];
-                float ms = 0.0f;
-                if (!firstOfBatch[k]) {
-                    HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[1]));
-                    ctx->profMs[SLRHIP_KERNEL_TRACE_CLOSEST] += ms; ++ctx->profLaunches[SLRHIP_KERNEL_TRACE_CLOSEST];
-                    HIP_TRY(hipEventElapsedTime(&ms, ev[1], ev[2]));
-                    ctx->profMs[SLRHIP_KERNEL_TRACE_SHADOW] += ms; ++ctx->profLaunches[SLRHIP_KERNEL_TRACE_SHADOW];
+                hipEvent_t* ev = &ctx->events[(size_t)k * kEv];
+                for (int j = 0; j < 4; ++j) {
+                    float ms = 0.0f;
+                    HIP_TRY(hipEventElapsedTime(&ms, ev[j], ev[j + 1]));
+                    ctx->profMs[cls[j]] += ms;
+                    ++ctx->profLaunches[cls[j]];
                 }
-                HIP_TRY(hipEventElapsedTime(&ms, ev[2], ev[3]));
-                ctx->profMs[SLRHIP_KERNEL_SHADE] += ms; ++ctx->profLaunches[SLRHIP_KERNEL_SHADE];
             }
         }
         if (it > maxIterations) return fail(SLRHIP_ERR_HIP, "slrhip_render: iteration bound exceeded (internal error)");
     }
     ctx->iterations += it;
+    ctx->samplesDone += (uint64_t)rp.numPixels * sppCount;      // every slot ran out of passes: all samples are accumulated
     HIP_TRY(hipGetLastError());
     return SLRHIP_OK;
 }
@@ -472,16 +496,12 @@ int slrhip_get_counters(slrhip_ctx* ctx, slrhip_counters* out) {
     out->build_seconds = ctx->buildSeconds;
     out->iterations = ctx->iterations;
     if (ctx->haveRender) {
-        HIP_TRY(hipSetDevice(ctx->device));
-        HIP_TRY(hipDeviceSynchronize());
-        uint64_t t[4] = {0, 0, 0, 0};
-        HIP_TRY(hipMemcpy(t, ctx->totals.ptr, sizeof(t), hipMemcpyDeviceToHost));
-        uint32_t q[4] = {0, 0, 0, 0};
-        HIP_TRY(hipMemcpy(q, ctx->queueCount.ptr, sizeof(q), hipMemcpyDeviceToHost));
-        // rays of the last, not yet folded, iteration are still in the queue counters
-        out->extension_rays = t[0] + q[0] + q[2];
-        out->shadow_rays = t[1] + q[1] + q[3];
-        out->samples = t[2];
+        uint64_t t[T_KINDS];
+        int rc = readTotals(ctx, t);
+        if (rc != SLRHIP_OK) return rc;
+        out->extension_rays = t[T_EXT_RAYS];
+        out->shadow_rays = t[T_SHADOW_RAYS];
+        out->samples = ctx->samplesDone;
     }
     return SLRHIP_OK;
 }
@@ -491,14 +511,13 @@ int slrhip_get_profile(slrhip_ctx* ctx, slrhip_profile* out) {
     std::memset(out, 0, sizeof(*out));
     for (int k = 0; k < SLRHIP_KERNEL_COUNT; ++k) { out->launches[k] = ctx->profLaunches[k]; out->milliseconds[k] = ctx->profMs[k]; }
     if (ctx->haveRender) {
-        HIP_TRY(hipSetDevice(ctx->device));
-        HIP_TRY(hipDeviceSynchronize());
-        uint64_t t[8];
-        HIP_TRY(hipMemcpy(t, ctx->totals.ptr, sizeof(t), hipMemcpyDeviceToHost));
-        out->rays[0] = t[0]; out->rays[1] = t[1];
-        out->nodes[0] = t[4]; out->triangles[0] = t[5];
-        out->nodes[1] = t[6]; out->triangles[1] = t[7];
-        out->slot_visits = t[3];
+        uint64_t t[T_KINDS];
+        int rc = readTotals(ctx, t);
+        if (rc != SLRHIP_OK) return rc;
+        out->rays[0] = t[T_EXT_RAYS]; out->rays[1] = t[T_SHADOW_RAYS];
+        out->nodes[0] = t[T_NODES_CLOSEST]; out->triangles[0] = t[T_TRIS_CLOSEST];
+        out->nodes[1] = t[T_NODES_SHADOW]; out->triangles[1] = t[T_TRIS_SHADOW];
+        out->slot_visits = t[T_SLOT_VISITS];
     }
     return SLRHIP_OK;
 }
