@@ -33,6 +33,21 @@ SHADOW_RAY_BYTES = 4 + 16 + 16 + 4         # queue entry, origin, direction+dist
 SHADE_SLOT_BYTES = 588                     # state read 200 + state written 180 + ShadeTri 96 + DevMaterial 80 + queues 8 + pixel RMW/... 24
 
 
+class quiet_stdout:
+    """The reference prints progress lines with printf (PathTracingRenderer.cpp:89, SBVH.h:405); keep the
+    process's stdout for the one JSON line by pointing fd 1 at stderr while the CPU legs run."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -180,6 +195,8 @@ def main():
         # ---- CPU baseline and matched-seed parity (N = 1 only; the checker, never the thing measured) ---
         out["cpu_baseline"] = None
         if world == 1 and args.cpu_seconds > 0:
+            guard = quiet_stdout()
+            guard.__enter__()
             from oracle import binding as ob
             # the GPU box gives a 1-GPU job a 16-CPU share; never start more workers than that
             cores = max(1, min(len(os.sched_getaffinity(0)), os.cpu_count() or 1, 16))
@@ -216,6 +233,7 @@ def main():
                 out["parity"] = {"spp": n, "rmse_vs_cpu_matched_seeds": float(np.sqrt(np.mean(d * d))),
                                  "bit_exact_fraction": float(exact.mean()), "mean_radiance": float(want.mean() / n * sens)}
             out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
+            guard.__exit__()
         print(json.dumps(out))
     ctx.close()
     if world > 1:
