@@ -69,11 +69,11 @@ def main():
     import torch
     import torch.distributed as dist
 
-    from slr_amd import Context, abi, scenes
+    from slr_amd import Context, abi, distributed, scenes
 
+    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
@@ -81,9 +81,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    distributed.init("nccl")
 
     W, H, spp = args.width, args.height, args.spp
     scene = scenes.cornell_box_spheres(W / H, 48, 24, args.right_sphere)
@@ -95,11 +93,8 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
-        ctx.render_begin(settings, shard=(rank, world))
-        ctx.render(0, spp, stream)
-        ctx.resolve_into(fb.data_ptr(), fb.numel(), stream)
-        if world > 1:
-            dist.reduce(fb, dst=0, op=dist.ReduceOp.SUM)     # disjoint supports: sum == gather
+        # shard render -> resolve -> one RCCL sum-reduce to rank 0 (disjoint tile supports: sum == gather)
+        distributed.render_step(ctx, settings, spp, fb, rank, world, stream)
 
     def fence():
         torch.cuda.synchronize()

@@ -136,6 +136,15 @@ def render_native(ref_scene, settings, spp, threads=0):
     return fb, sec.value
 
 
+def ref_save_image(ref_lib, fb, sensitivity, scale, path):
+    fb = np.ascontiguousarray(fb, np.float32)
+    f = ref_lib.lib.slr_ref_save_image
+    f.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_char_p]
+    rc = f(fb.ctypes.data, fb.shape[1], fb.shape[0], sensitivity, scale, path.encode())
+    if rc != 0:
+        raise RuntimeError("reference saveImage failed: %d" % rc)
+
+
 def load(which="oracle", mode=abi.MODE_RGB):
     if which == "oracle":
         path = os.path.join(HERE, "libslr_oracle.so")

@@ -381,4 +381,18 @@ int slr_ref_render_native(slr_oracle_scene* s, const slrhip_render_settings* st,
     return renderUnmodified(s, st, spp, n, fbSum, seconds);
 }
 
+int slr_ref_save_image(const float* fb, uint32_t width, uint32_t height, float sensitivity, float scale, const char* path) {
+    if (!fb || !path) return 1;
+    static bool inited = false;
+    if (!inited) { initSpectrum(); inited = true; }
+    ImageSensor sensor(width, height, sensitivity);
+    for (uint32_t y = 0; y < height; ++y)
+        for (uint32_t x = 0; x < width; ++x) {
+            SpectrumStorage& px = sensor.pixel(x, y);
+            for (int k = 0; k < kComponents; ++k) { px.value.result[k] = fb[((size_t)y * width + x) * kComponents + k]; px.value.comp[k] = 0.0f; }
+        }
+    sensor.saveImage(path, scale);
+    return 0;
+}
+
 } // extern "C"

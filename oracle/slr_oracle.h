@@ -82,6 +82,11 @@ int slr_ref_render_serial(slr_oracle_scene* s, const slrhip_render_settings* set
 int slr_ref_render_native(slr_oracle_scene* s, const slrhip_render_settings* settings, uint32_t spp, int threads,
                           float* fb_sum, double* seconds);
 
+/* ImageSensor::saveImage (ImageSensor.cpp:138-186) on a given linear framebuffer: fills the reference's
+ * sensor with `fb` ([H][W][C] sums), calls saveImage(path, scale) and returns 0.  `sensitivity` is the
+ * ImageSensor constructor argument.  Reference build only; pins the product's slrhip_tonemap_bgr8.     */
+int slr_ref_save_image(const float* fb, uint32_t width, uint32_t height, float sensitivity, float scale, const char* path);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,112 @@
+// SLRHip.cpp — see SLRHip.h.  Host C++ only; everything on the GPU goes through the C ABI.
+#include "SLRHip.h"
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+namespace SLRHip {
+
+Scene::Scene() { std::memset(&m_camera, 0, sizeof(m_camera)); }
+
+uint32_t Scene::addVertex(const float position[3], const float normal[3], const float tangent[3], const float texcoord[2]) {
+    slrhip_vertex v;
+    for (int i = 0; i < 3; ++i) { v.position[i] = position[i]; v.normal[i] = normal[i]; v.tangent[i] = tangent[i]; }
+    v.texcoord[0] = texcoord[0]; v.texcoord[1] = texcoord[1];
+    m_vertices.push_back(v);
+    return (uint32_t)m_vertices.size() - 1;
+}
+uint32_t Scene::addTriangle(uint32_t v0, uint32_t v1, uint32_t v2, uint32_t material) {
+    slrhip_triangle t = {{v0, v1, v2}, material};
+    m_triangles.push_back(t);
+    return (uint32_t)m_triangles.size() - 1;
+}
+uint32_t Scene::addSpectrumRGB(float r, float g, float b) {
+    slrhip_spectrum s;
+    std::memset(&s, 0, sizeof(s));
+    s.kind = SLRHIP_SPECTRUM_RGB_ONLY;
+    s.rgb[0] = r; s.rgb[1] = g; s.rgb[2] = b;
+    m_spectra.push_back(s);
+    return (uint32_t)m_spectra.size() - 1;
+}
+uint32_t Scene::addMaterial(uint32_t type, int32_t s0, int32_t s1, int32_t s2, float param, int32_t emittance) {
+    slrhip_material m = {type, {s0, s1, s2}, param, emittance};
+    m_materials.push_back(m);
+    return (uint32_t)m_materials.size() - 1;
+}
+slrhip_scene_desc Scene::desc() const {
+    slrhip_scene_desc d;
+    std::memset(&d, 0, sizeof(d));
+    d.vertices = m_vertices.data(); d.num_vertices = (uint32_t)m_vertices.size();
+    d.triangles = m_triangles.data(); d.num_triangles = (uint32_t)m_triangles.size();
+    d.materials = m_materials.data(); d.num_materials = (uint32_t)m_materials.size();
+    d.spectra = m_spectra.data(); d.num_spectra = (uint32_t)m_spectra.size();
+    d.spectrum_data = m_spectrumData.data(); d.num_spectrum_data = (uint32_t)m_spectrumData.size();
+    d.camera = m_camera;
+    d.env = nullptr;
+    return d;
+}
+
+static void die(const char* what, int rc) {
+    std::fprintf(stderr, "%s failed (%d): %s\n", what, rc, slrhip_last_error_string());
+    std::exit(-1);      // HostProgram/main.cpp:39-42
+}
+
+void PathTracingRenderer::render(const Scene& scene, const RenderSettings& settings) const {
+    slrhip_config cfg = {m_device, SLRHIP_MODE_RGB, 0, 0};
+    slrhip_ctx* ctx = nullptr;
+    int rc = slrhip_create(&cfg, &ctx);
+    if (rc) die("slrhip_create", rc);
+    slrhip_scene_desc desc = scene.desc();
+    if ((rc = slrhip_upload_scene(ctx, &desc))) die("slrhip_upload_scene", rc);
+
+    slrhip_render_settings st;
+    st.image_width = settings.getInt(RenderSettingItem::ImageWidth);
+    st.image_height = settings.getInt(RenderSettingItem::ImageHeight);
+    st.time_start = settings.getFloat(RenderSettingItem::TimeStart);
+    st.time_end = settings.getFloat(RenderSettingItem::TimeEnd);
+    st.brightness = settings.getFloat(RenderSettingItem::Brightness);
+    st.rng_seed = settings.getInt(RenderSettingItem::RNGSeed);
+    slrhip_shard whole = {0, 1};
+    if ((rc = slrhip_render_begin(ctx, &st, whole))) die("slrhip_render_begin", rc);
+
+    // sensitivity of PerspectiveCamera.cpp:23 (ImageSensor::saveImage multiplies the scale by it, ImageSensor.cpp:143-147)
+    const slrhip_camera& cam = scene.camera();
+    float sensitivity = cam.sensitivity > 0 ? cam.sensitivity : (float)(1.0f / (M_PI * (double)cam.lens_radius * (double)cam.lens_radius));
+    if (std::isinf(sensitivity)) sensitivity = 1.0f;
+
+    const size_t numFloats = (size_t)st.image_width * st.image_height * 3;
+    std::vector<float> fb(numFloats);
+    const uint32_t byteWidth = 3u * (uint32_t)st.image_width + (uint32_t)st.image_width % 4u;
+    std::vector<uint8_t> bmp((size_t)byteWidth * st.image_height);
+
+    // the pass loop of PathTracingRenderer.cpp:63-94: images after 1, 2, 4, ... passes, at most 16 of them
+    uint32_t exportPass = 1, imgIdx = 0;
+    const uint32_t endIdx = 16;
+    auto start = std::chrono::system_clock::now();
+    uint32_t done = 0;
+    while (done < m_samplesPerPixel) {
+        const uint32_t upTo = exportPass <= m_samplesPerPixel ? exportPass : m_samplesPerPixel;
+        if ((rc = slrhip_render(ctx, done, upTo - done, nullptr))) die("slrhip_render", rc);
+        done = upTo;
+        if (done == exportPass) {
+            if ((rc = slrhip_read_framebuffer(ctx, fb.data(), numFloats))) die("slrhip_read_framebuffer", rc);
+            char filename[256];
+            std::snprintf(filename, sizeof(filename), "%03u.bmp", imgIdx);
+            double elapsed = (double)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::system_clock::now() - start).count();
+            const float scale = st.brightness / (float)done * sensitivity;
+            if ((rc = slrhip_tonemap_bgr8(fb.data(), st.image_width, st.image_height, 3, scale, bmp.data(), bmp.size()))) die("slrhip_tonemap_bgr8", rc);
+            const std::string path = m_outputDir + "/" + filename;
+            if ((rc = slrhip_save_bmp(path.c_str(), bmp.data(), st.image_width, st.image_height))) die("slrhip_save_bmp", rc);
+            std::printf("%u samples: %s, %g[s]\n", exportPass, filename, elapsed * 0.001f);
+            ++imgIdx;
+            if (imgIdx == endIdx) break;
+            exportPass += exportPass;
+        }
+    }
+    slrhip_destroy(ctx);
+}
+
+} // namespace SLRHip

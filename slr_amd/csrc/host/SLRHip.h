@@ -1,0 +1,71 @@
+// SLRHip.h — host-side C++ mirror of the reference's renderer interface for the path-tracing hot path.
+//
+// Same names, argument meaning and error behaviour as the reference, so a libSLR host program switches by
+// changing one `new`:
+//   SLR::Renderer            libSLR/Core/Renderer.h:15-19          -> SLRHip::Renderer
+//   SLR::RenderSettings      libSLR/Core/RenderSettings.h:15-42    -> SLRHip::RenderSettings (same item enum, same getters)
+//   SLR::PathTracingRenderer libSLR/Renderers/PathTracingRenderer.h:16-43 -> SLRHip::PathTracingRenderer(spp)
+//   SLR::Scene               libSLR/Core/SurfaceObject.h:239-260   -> SLRHip::Scene, a FLAT scene: the reference's Scene is a
+//                            private pointer graph (no accessor for triangles or materials), so the host layer owns the arrays.
+// render() drives the C ABI of include/slrhip.h and reproduces what the reference's render() leaves behind:
+// "%03u.bmp" after 1, 2, 4, ... passes with scale Brightness / (s + 1), and the stdout line
+// "%u samples: %s, %g[s]" (PathTracingRenderer.cpp:83-94).  Failures print to stderr and exit(-1) as
+// HostProgram/main.cpp:39-42 does.
+#pragma once
+#include <cstdint>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../../include/slrhip.h"
+
+namespace SLRHip {
+
+enum class RenderSettingItem { ImageWidth, ImageHeight, TimeStart, TimeEnd, Brightness, RNGSeed };
+
+class RenderSettings {
+    std::map<RenderSettingItem, int32_t> m_int32Values;
+    std::map<RenderSettingItem, float> m_floatValues;
+public:
+    void addItem(RenderSettingItem item, int32_t value) { m_int32Values[item] = value; }
+    void addItem(RenderSettingItem item, float value) { m_floatValues[item] = value; }
+    int32_t getInt(RenderSettingItem item) const { return m_int32Values.at(item); }
+    float getFloat(RenderSettingItem item) const { return m_floatValues.at(item); }
+};
+
+// Flat scene owned by the host program (what libSLRSceneGraph would have flattened: TriangleMeshNode.cpp:68-112).
+class Scene {
+    std::vector<slrhip_vertex> m_vertices;
+    std::vector<slrhip_triangle> m_triangles;
+    std::vector<slrhip_material> m_materials;
+    std::vector<slrhip_spectrum> m_spectra;
+    std::vector<float> m_spectrumData;
+    slrhip_camera m_camera;
+public:
+    Scene();
+    uint32_t addVertex(const float position[3], const float normal[3], const float tangent[3], const float texcoord[2]);
+    uint32_t addTriangle(uint32_t v0, uint32_t v1, uint32_t v2, uint32_t material);
+    uint32_t addSpectrumRGB(float r, float g, float b);
+    uint32_t addMaterial(uint32_t type, int32_t s0, int32_t s1, int32_t s2, float param, int32_t emittance);
+    void setCamera(const slrhip_camera& camera) { m_camera = camera; }
+    const slrhip_camera& camera() const { return m_camera; }
+    slrhip_scene_desc desc() const;
+};
+
+class Renderer {
+public:
+    virtual ~Renderer() {}
+    virtual void render(const Scene& scene, const RenderSettings& settings) const = 0;
+};
+
+class PathTracingRenderer : public Renderer {
+    uint32_t m_samplesPerPixel;
+    int m_device;
+    std::string m_outputDir;
+public:
+    explicit PathTracingRenderer(uint32_t spp, int device = 0, const std::string& outputDir = ".")
+        : m_samplesPerPixel(spp), m_device(device), m_outputDir(outputDir) {}
+    void render(const Scene& scene, const RenderSettings& settings) const override;
+};
+
+} // namespace SLRHip

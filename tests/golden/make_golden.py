@@ -70,6 +70,20 @@ def main():
     for i, s in enumerate(seeds):
         kat["uints_%d" % i], kat["floats_%d" % i] = lib.rng(int(s), 64)
     np.savez_compressed(os.path.join(HERE, "rng_kat.npz"), **kat)
+    # ImageSensor::saveImage on a known framebuffer -> BMP bytes (pins slrhip_tonemap_bgr8 / slrhip_save_bmp)
+    import tempfile
+    rng = np.random.default_rng(7)
+    w, h = 37, 21                      # width % 4 != 0 exercises the reference's row padding (ImageSensor.cpp:149)
+    fb = (rng.random((h, w, 3)) ** 4 * 3.0).astype(np.float32)
+    fb[0, 0] = 0.0
+    fb[1, 1] = (1e-4, 2e-4, 3e-4)
+    fb[2, 2] = (50.0, 60.0, 70.0)
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "t.bmp")
+        ob.ref_save_image(lib, fb, 509.29581, 0.37, path)
+        bmp = np.frombuffer(open(path, "rb").read(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(HERE, "tonemap_bmp.npz"), framebuffer=fb, sensitivity=np.float32(509.29581),
+                        scale=np.float32(0.37), bmp=bmp)
     make("rgb_tiny_box", scenes.tiny_box(1.0), lib, 32, 32, 8, 2)
     make("rgb_cornell_glass", scenes.cornell_box_spheres(4.0 / 3.0, 16, 8, "glass"), lib, 48, 36, 8, 2)
     make("rgb_cornell_matte", scenes.cornell_box_spheres(4.0 / 3.0, 16, 8, "matte"), lib, 48, 36, 8, 2)

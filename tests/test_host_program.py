@@ -1,0 +1,40 @@
+"""GPU: the C++ Renderer-shaped adapter (slr_amd/csrc/host) run as a libSLR-style host program; its BMP after 8
+passes must equal the tone-mapped framebuffer of the same scene rendered through the Python binding."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import binding as ob
+from slr_amd import Context, binding, scenes
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cornell_host_program_writes_reference_style_output(tmp_path):
+    exe = os.path.join(ROOT, "slr_amd", "csrc", "host", "cornell_main")
+    if not os.path.exists(exe):
+        pytest.skip("host program not built")
+    w, h, spp = 64, 48, 8
+    out = subprocess.check_output([exe, str(spp), str(w), str(h), str(tmp_path)], text=True)
+    lines = [l for l in out.splitlines() if "samples:" in l]
+    assert [l.split(" ")[0] for l in lines] == ["1", "2", "4", "8"]              # export cadence of PathTracingRenderer.cpp:83-94
+    assert lines[3].split(" ")[2].rstrip(",") == "003.bmp"
+    bmp = np.frombuffer(open(tmp_path / "003.bmp", "rb").read(), np.uint8)
+
+    sc = scenes.tiny_box(w / h)                                                  # same walls + light, built in Python
+    st = ob.settings(w, h)
+    ctx = Context(stripes=0)
+    fb = ctx.render_image(sc, st, spp)
+    ctx.close()
+    lib = binding.load_library()
+    byte_width = 3 * w + w % 4
+    mine = np.zeros(byte_width * h, np.uint8)
+    sens = float(np.float32(1.0 / (np.pi * np.float64(np.float32(0.025)) ** 2)))
+    scale = np.float32(np.float32(1.0) / np.float32(spp)) * np.float32(sens)
+    assert lib.slrhip_tonemap_bgr8(fb.ctypes.data, w, h, 3, C.c_float(float(scale)), mine.ctypes.data, mine.size) == 0
+    diff = np.abs(bmp[54:].astype(int) - mine.astype(int))
+    assert diff.max() <= 1 and (diff != 0).mean() < 0.02
