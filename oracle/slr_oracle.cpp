@@ -505,6 +505,11 @@ inline bool dtMatches(uint32_t type, uint32_t t) { uint32_t res = type & t; retu
 inline bool dtIsDelta(uint32_t v) { return (v & DT_Delta) && !(v & DT_NonDelta); }        // :86
 inline bool dtIsDispersive(uint32_t v) { return (v & DT_Dispersive) != 0; }
 
+
+// std::max / std::min as the reference uses them: (a < b) ? b : a and (b < a) ? b : a
+inline float stdmax(float a, float b) { return (a < b) ? b : a; }
+inline float stdmin(float a, float b) { return (b < a) ? b : a; }
+
 template <int N>
 struct BSDFQuery {   // DDF.h:118-126
     V3 dir_sn, gNormal_sn;
@@ -523,8 +528,24 @@ struct BSDF {
     uint32_t kind;      // SLRHIP_MATERIAL_*
     uint32_t type;      // DirectionType of the lobe
     Spec<N> a, b, c;    // matte: a = R;  metal: a = coeffR, b = eta, c = k;  glass: a = coeff, b = etaExt, c = etaInt
-    float param;
+    float param;        // matte: sigma (< 0: Lambert);  microfacet: alpha_g
+    float onA, onB;     // Oren-Nayar m_A, m_B (OrenNayerBRDF.h:28-30)
 };
+
+// OrenNayerBRDF::sampleInternal / evaluateInternal share this term (OrenNayerBRDF.cpp:19-27,46-53).
+// "sin" terms are 1 - z^2 without the square root, as in the reference.
+template <int N>
+inline Spec<N> orenNayar(const BSDF<N>& f, V3 dirI, V3 dirO, bool guardNonFinite) {
+    float sinThetaI = 1.0f - dirI.z * dirI.z;
+    float sinThetaO = 1.0f - dirO.z * dirO.z;
+    float absTanThetaI = sinThetaI / std::abs(dirI.z);
+    float absTanThetaO = sinThetaO / std::abs(dirO.z);
+    float sinAlpha = stdmax(sinThetaI, sinThetaO);
+    float tanBeta = stdmin(absTanThetaI, absTanThetaO);
+    float cos_dAzimuth = (dirI.x * dirO.x + dirI.y * dirO.y) / (sinThetaI * sinThetaO);
+    if (guardNonFinite && !std::isfinite(cos_dAzimuth)) cos_dAzimuth = 0.0f;
+    return f.a * (float)((double)(f.onA + f.onB * stdmax(0.0f, cos_dAzimuth) * sinAlpha * tanBeta) / M_PI);
+}
 
 // Core/directional_distribution_functions.cpp:68-78  FresnelConductor::evaluate
 template <int N>
@@ -564,11 +585,104 @@ Spec<N> fresnelDielectric(const Spec<N>& etaExt, const Spec<N>& etaInt, float co
     return ret;
 }
 
+
+
+// ------------------------------------------------------------------------------------------
+// GGX, Core/directional_distribution_functions.cpp:162-268.  std::pow(float, int) is the double
+// pow; unqualified cos/sin/tan inside namespace SLR are the double C functions; std::acos,
+// std::atan2, std::tan, std::cos, std::sin on floats are the float overloads.
+// ------------------------------------------------------------------------------------------
+struct GGX {
+    float alpha_g;
+    // :176-183
+    float evaluate(V3 m) const {
+        if (m.z <= 0) return 0.0f;
+        float theta_m = std::acos(m.z);
+        float cosTheta_m = m.z;
+        float tanTheta_m = std::tan(theta_m);
+        return (float)((double)(alpha_g * alpha_g) /
+                       (M_PI * std::pow((double)cosTheta_m, 4.0) * std::pow((double)(alpha_g * alpha_g + tanTheta_m * tanTheta_m), 2.0)));
+    }
+    // :264-268
+    float evaluateSmithG1(V3 v, V3 m) const {
+        float chi = (dot(v, m) / v.z) > 0 ? 1 : 0;
+        float theta_v = std::acos(std::min(1.0f, std::max(-1.0f, v.z)));
+        return (float)((double)(chi * 2) / (1 + std::sqrt(1 + std::pow((double)(alpha_g * std::tan(theta_v)), 2.0))));
+    }
+    // :260-262
+    float evaluatePDF(V3 v, V3 m) const { return evaluateSmithG1(v, m) * absDot(v, m) * evaluate(m) / std::abs(v.z); }
+    // :191-258  Heitz-14 visible-normal sampling
+    float sample(V3 v, float u0, float u1, V3* m, float* normalPDF) const {
+        float alpha_gx = alpha_g, alpha_gy = alpha_g;
+        V3 sv = normalize(V3(alpha_gx * v.x, alpha_gy * v.y, v.z));
+        float theta_sv = std::acos(sv.z);
+        float phi_sv = std::atan2(sv.y, sv.x);
+        if (sv.z > 0.99999f) { theta_sv = 0.0f; phi_sv = 0.0f; }
+        float slope_x, slope_y;
+        if (theta_sv < 0.0001) {
+            const float r = std::sqrt(u0 / (1 - u0));
+            const float phi = (float)(2 * M_PI * u1);
+            slope_x = (float)(r * ::cos((double)phi));
+            slope_y = (float)(r * ::sin((double)phi));
+        }
+        else {
+            const float tan_theta_i = (float)::tan((double)theta_sv);
+            const float a = 1 / tan_theta_i;
+            const float G1 = (float)(2 / (1 + std::sqrt(1.0 + 1.0 / (a * a))));
+            const float A = (float)(2.0 * u0 / G1 - 1.0);
+            const float tmp = (float)(1.0 / (A * A - 1.0));
+            const float B = tan_theta_i;
+            const float D = std::sqrt(B * B * tmp * tmp - (A * A - B * B) * tmp);
+            const float slope_x_1 = B * tmp - D;
+            const float slope_x_2 = B * tmp + D;
+            slope_x = (A < 0 || slope_x_2 > 1.0 / tan_theta_i) ? slope_x_1 : slope_x_2;
+            if (u0 == 0) slope_x = 0;
+            float S;
+            if (u1 > 0.5) { S = 1.0; u1 = (float)(2.0 * (u1 - 0.5)); }
+            else { S = -1.0; u1 = (float)(2.0 * (0.5 - u1)); }
+            const float z = (float)((u1 * (u1 * (u1 * 0.27385 - 0.73369) + 0.46341)) / (u1 * (u1 * (u1 * 0.093073 + 0.309420) - 1.000000) + 0.597999));
+            slope_y = (float)(S * z * std::sqrt(1.0 + slope_x * slope_x));
+        }
+        float tmp = std::cos(phi_sv) * slope_x - std::sin(phi_sv) * slope_y;
+        slope_y = std::sin(phi_sv) * slope_x + std::cos(phi_sv) * slope_y;
+        slope_x = tmp;
+        slope_x *= alpha_gx;
+        slope_y *= alpha_gy;
+        *m = normalize(V3(-slope_x, -slope_y, 1));
+        float D = evaluate(*m);
+        *normalPDF = evaluateSmithG1(v, *m) * absDot(v, *m) * D / std::abs(v.z);
+        return D;
+    }
+};
+
+// DDF.cpp:80-88 / :113-129  per-wavelength Fresnel
+template <int N>
+inline float fresnelDielectric1(const Spec<N>& etaExt, const Spec<N>& etaInt, float cosEnter, int wlIdx) {
+    cosEnter = std::min(1.0f, std::max(-1.0f, cosEnter));
+    bool entering = cosEnter > 0.0f;
+    const float eEnter = entering ? etaExt[wlIdx] : etaInt[wlIdx];
+    const float eExit = entering ? etaInt[wlIdx] : etaExt[wlIdx];
+    float sinExit = eEnter / eExit * std::sqrt(std::fmax(0.0f, 1.0f - cosEnter * cosEnter));
+    cosEnter = std::fabs(cosEnter);
+    if (sinExit >= 1.0f) return 1.0f;
+    float cosExit = std::sqrt(std::fmax(0.0f, 1.0f - sinExit * sinExit));
+    return fresnelEvalF(eEnter, eExit, cosEnter, cosExit);
+}
+
 // sampleInternal of each lobe.  Returns fs_sn; result->dirPDF == 0 signals failure.
 template <int N>
 Spec<N> bsdfSampleInternal(const BSDF<N>& f, const BSDFQuery<N>& q, float uComponent, const float uDir[2], BSDFResult* result) {
     switch (f.kind) {
     case SLRHIP_MATERIAL_MATTE: {
+        if (f.param >= 0.0f) {
+            // BSDFs/OrenNayerBRDF.cpp:12-34
+            bool frontSide = dot(q.dir_sn, q.gNormal_sn) > 0;
+            result->dir_sn = cosineSampleHemisphere(uDir[0], uDir[1]);
+            result->dirPDF = (float)((double)result->dir_sn.z / M_PI);
+            result->dirType = f.type;
+            result->dir_sn.z *= frontSide ? 1 : -1;
+            return orenNayar(f, result->dir_sn, q.dir_sn, true);
+        }
         // BSDFs/basic_BSDFs.cpp:12-26  LambertianBRDF::sampleInternal
         result->dir_sn = cosineSampleHemisphere(uDir[0], uDir[1]);
         result->dirPDF = (float)((double)result->dir_sn.z / M_PI);
@@ -613,6 +727,72 @@ Spec<N> bsdfSampleInternal(const BSDF<N>& f, const BSDFQuery<N>& q, float uCompo
             return ret / std::fabs(cosExit);
         }
     }
+    case SLRHIP_MATERIAL_MICROFACET_METAL: {
+        // BSDFs/MicrofacetBSDF.cpp:11-45  MicrofacetBRDF::sampleInternal
+        GGX D_ = {f.param};
+        bool entering = q.dir_sn.z >= 0.0f;
+        int32_t sign = entering ? 1 : -1;
+        V3 m; float mPDF;
+        float D = D_.sample((float)sign * q.dir_sn, uDir[0], uDir[1], &m, &mPDF);
+        float dotHV = dot(q.dir_sn, m);
+        if (dotHV * sign <= 0) { result->dirPDF = 0.0f; return Spec<N>(); }
+        result->dir_sn = 2 * dotHV * m - q.dir_sn;
+        if (result->dir_sn.z * q.dir_sn.z <= 0) { result->dirPDF = 0.0f; return Spec<N>(); }
+        float commonPDFTerm = 1.0f / (4 * dotHV * sign);
+        result->dirPDF = commonPDFTerm * mPDF;
+        result->dirType = f.type;
+        Spec<N> F = fresnelConductor(f.b, f.c, dotHV);
+        float G = D_.evaluateSmithG1(q.dir_sn, m) * D_.evaluateSmithG1(result->dir_sn, m);
+        return F * D * G / (4 * q.dir_sn.z * result->dir_sn.z);
+    }
+    case SLRHIP_MATERIAL_MICROFACET_GLASS: {
+        // MicrofacetBSDF.cpp:113-196  MicrofacetBSDF::sampleInternal (flags = All, adjoint = false)
+        GGX D_ = {f.param};
+        bool entering = q.dir_sn.z >= 0.0f;
+        int32_t sign = entering ? 1 : -1;
+        const Spec<N>& eEnter = entering ? f.b : f.c;
+        const Spec<N>& eExit = entering ? f.c : f.b;
+        V3 m; float mPDF;
+        float D = D_.sample((float)sign * q.dir_sn, uDir[0], uDir[1], &m, &mPDF);
+        float dotHV = dot(q.dir_sn, m);
+        if (dotHV * sign <= 0 || std::isnan(D)) { result->dirPDF = 0.0f; return Spec<N>(); }
+        Spec<N> F = fresnelDielectric(f.b, f.c, dotHV);
+        float reflectProb = importance(F, (uint16_t)q.wlHint);
+        if (uComponent < reflectProb) {
+            result->dir_sn = 2 * dotHV * m - q.dir_sn;
+            if (result->dir_sn.z * q.dir_sn.z <= 0) { result->dirPDF = 0.0f; return Spec<N>(); }
+            float commonPDFTerm = reflectProb / (4 * dotHV * sign);
+            result->dirPDF = commonPDFTerm * mPDF;
+            result->dirType = DT_Reflection | DT_HighFreq;
+            float G = D_.evaluateSmithG1(q.dir_sn, m) * D_.evaluateSmithG1(result->dir_sn, m);
+            return F * D * G / (4 * q.dir_sn.z * result->dir_sn.z);
+        }
+        else {
+            float recRelIOR = eEnter[q.wlHint] / eExit[q.wlHint];
+            float innerRoot = 1 + recRelIOR * recRelIOR * (dotHV * dotHV - 1);
+            if (innerRoot < 0) { result->dirPDF = 0.0f; return Spec<N>(); }
+            result->dir_sn = (recRelIOR * dotHV - sign * std::sqrt(innerRoot)) * m - recRelIOR * q.dir_sn;
+            if (result->dir_sn.z * q.dir_sn.z >= 0) { result->dirPDF = 0.0f; return Spec<N>(); }
+            float dotHL = dot(result->dir_sn, m);
+            float commonPDFTerm = (float)((double)(1 - reflectProb) / std::pow((double)(eEnter[q.wlHint] * dotHV + eExit[q.wlHint] * dotHL), 2.0));
+            result->dirPDF = commonPDFTerm * mPDF * eExit[q.wlHint] * eExit[q.wlHint] * std::fabs(dotHL);
+            result->dirType = DT_Transmission | DT_HighFreq;
+            Spec<N> ret;
+            for (int wlIdx = 0; wlIdx < N; ++wlIdx) {
+                V3 m_wl = normalize(-(eEnter[wlIdx] * q.dir_sn + eExit[wlIdx] * result->dir_sn));
+                float dotHV_wl = dot(q.dir_sn, m_wl);
+                float dotHL_wl = dot(result->dir_sn, m_wl);
+                float F_wl = fresnelDielectric1(f.b, f.c, dotHV_wl, wlIdx);
+                float G_wl = D_.evaluateSmithG1(q.dir_sn, m_wl) * D_.evaluateSmithG1(result->dir_sn, m_wl);
+                float D_wl = D_.evaluate(m_wl);
+                ret[wlIdx] = (float)((double)(std::fabs(dotHV_wl * dotHL_wl) * (1 - F_wl) * G_wl * D_wl) /
+                                     std::pow((double)(eEnter[wlIdx] * dotHV_wl + eExit[wlIdx] * dotHL_wl), 2.0));
+            }
+            ret = ret / std::fabs(q.dir_sn.z * result->dir_sn.z);
+            ret = ret * (eEnter * eEnter);
+            return ret;
+        }
+    }
     default:
         result->dirPDF = 0.0f;
         return Spec<N>();
@@ -640,10 +820,60 @@ Spec<N> bsdfEvaluate(const BSDF<N>& f, const BSDFQuery<N>& q, V3 dir) {
     Spec<N> fs_sn;
     switch (f.kind) {
     case SLRHIP_MATERIAL_MATTE:
-        // basic_BSDFs.cpp:28-39  LambertianBRDF::evaluateInternal
+        // basic_BSDFs.cpp:28-39  LambertianBRDF::evaluateInternal / OrenNayerBRDF.cpp:36-56
         if (q.dir_sn.z * dir.z <= 0.0f) fs_sn = Spec<N>();
+        else if (f.param >= 0.0f) fs_sn = orenNayar(f, dir, q.dir_sn, false);
         else fs_sn = f.a / (float)M_PI;
         break;
+    case SLRHIP_MATERIAL_MICROFACET_METAL: {
+        // MicrofacetBSDF.cpp:47-71  MicrofacetBRDF::evaluateInternal
+        if (dir.z * q.dir_sn.z <= 0) { fs_sn = Spec<N>(); break; }
+        GGX D_ = {f.param};
+        bool entering = q.dir_sn.z >= 0.0f;
+        int32_t sign = entering ? 1 : -1;
+        V3 m = (float)sign * normalize(q.dir_sn + dir);
+        float dotHV = dot(q.dir_sn, m);
+        float D = D_.evaluate(m);
+        Spec<N> F = fresnelConductor(f.b, f.c, dotHV);
+        float G = D_.evaluateSmithG1(q.dir_sn, m) * D_.evaluateSmithG1(dir, m);
+        fs_sn = F * D * G / (4 * q.dir_sn.z * dir.z);
+        break;
+    }
+    case SLRHIP_MATERIAL_MICROFACET_GLASS: {
+        // MicrofacetBSDF.cpp:198-247  MicrofacetBSDF::evaluateInternal (mQuery.flags after the side test)
+        GGX D_ = {f.param};
+        bool entering = q.dir_sn.z >= 0.0f;
+        int32_t sign = entering ? 1 : -1;
+        float dotNVdotNL = dir.z * q.dir_sn.z;
+        if (dotNVdotNL > 0 && dtMatches(flags, DT_Reflection | DT_AllFreq)) {
+            V3 m = (float)sign * normalize(q.dir_sn + dir);
+            float dotHV = dot(q.dir_sn, m);
+            float D = D_.evaluate(m);
+            Spec<N> F = fresnelDielectric(f.b, f.c, dotHV);
+            float G = D_.evaluateSmithG1(q.dir_sn, m) * D_.evaluateSmithG1(dir, m);
+            fs_sn = F * D * G / (4 * dotNVdotNL);
+        }
+        else if (dotNVdotNL < 0 && dtMatches(flags, DT_Transmission | DT_AllFreq)) {
+            const Spec<N>& eEnter = entering ? f.b : f.c;
+            const Spec<N>& eExit = entering ? f.c : f.b;
+            Spec<N> ret;
+            for (int wlIdx = 0; wlIdx < N; ++wlIdx) {
+                V3 m_wl = normalize(-(eEnter[wlIdx] * q.dir_sn + eExit[wlIdx] * dir));
+                float dotHV_wl = dot(q.dir_sn, m_wl);
+                float dotHL_wl = dot(dir, m_wl);
+                float F_wl = fresnelDielectric1(f.b, f.c, dotHV_wl, wlIdx);
+                float G_wl = D_.evaluateSmithG1(q.dir_sn, m_wl) * D_.evaluateSmithG1(dir, m_wl);
+                float D_wl = D_.evaluate(m_wl);
+                ret[wlIdx] = (float)((double)(std::fabs(dotHV_wl * dotHL_wl) * (1 - F_wl) * G_wl * D_wl) /
+                                     std::pow((double)(eEnter[wlIdx] * dotHV_wl + eExit[wlIdx] * dotHL_wl), 2.0));
+            }
+            ret = ret / std::fabs(dotNVdotNL);
+            ret = ret * (eEnter * eEnter);
+            fs_sn = ret;
+        }
+        else fs_sn = Spec<N>();
+        break;
+    }
     default:   // SpecularBRDF / SpecularBSDF::evaluateInternal return Zero (basic_BSDFs.cpp:73-77,151-155)
         fs_sn = Spec<N>();
         break;
@@ -658,9 +888,49 @@ float bsdfEvaluatePDF(const BSDF<N>& f, const BSDFQuery<N>& q, V3 dir) {
     if (!dtMatches(f.type, q.flags)) return 0;
     switch (f.kind) {
     case SLRHIP_MATERIAL_MATTE:
-        // basic_BSDFs.cpp:41-50
+        // basic_BSDFs.cpp:41-50, OrenNayerBRDF.cpp:58-66 (identical)
         if (q.dir_sn.z * dir.z <= 0.0f) return 0.0f;
         return (float)((double)std::abs(dir.z) / M_PI);
+    case SLRHIP_MATERIAL_MICROFACET_METAL: {
+        // MicrofacetBSDF.cpp:73-100
+        if (dir.z * q.dir_sn.z <= 0) return 0.0f;
+        GGX D_ = {f.param};
+        bool entering = q.dir_sn.z >= 0.0f;
+        int32_t sign = entering ? 1 : -1;
+        V3 m = (float)sign * normalize(q.dir_sn + dir);
+        float dotHV = dot(q.dir_sn, m);
+        if (dotHV * sign <= 0) return 0.0f;
+        float mPDF = D_.evaluatePDF((float)sign * q.dir_sn, m);
+        float commonPDFTerm = 1.0f / (4 * dotHV * sign);
+        return commonPDFTerm * mPDF;
+    }
+    case SLRHIP_MATERIAL_MICROFACET_GLASS: {
+        // MicrofacetBSDF.cpp:249-303 (query.flags = All)
+        GGX D_ = {f.param};
+        bool entering = q.dir_sn.z >= 0.0f;
+        int32_t sign = entering ? 1 : -1;
+        float dotNVdotNL = dir.z * q.dir_sn.z;
+        if (dotNVdotNL == 0) return 0.0f;
+        const Spec<N>& eEnter = entering ? f.b : f.c;
+        const Spec<N>& eExit = entering ? f.c : f.b;
+        V3 m;
+        if (dotNVdotNL > 0) m = (float)sign * normalize(q.dir_sn + dir);
+        else m = normalize(-(eEnter[q.wlHint] * q.dir_sn + eExit[q.wlHint] * dir));
+        float dotHV = dot(q.dir_sn, m);
+        if (dotHV * sign <= 0) return 0.0f;
+        float mPDF = D_.evaluatePDF((float)sign * q.dir_sn, m);
+        Spec<N> F = fresnelDielectric(f.b, f.c, dotHV);
+        float reflectProb = importance(F, (uint16_t)q.wlHint);
+        if (dotNVdotNL > 0) {
+            float commonPDFTerm = reflectProb / (4 * dotHV * sign);
+            return commonPDFTerm * mPDF;
+        }
+        else {
+            float dotHL = dot(dir, m);
+            float commonPDFTerm = (float)((double)(1 - reflectProb) / std::pow((double)(eEnter[q.wlHint] * dotHV + eExit[q.wlHint] * dotHL), 2.0));
+            return commonPDFTerm * mPDF * eExit[q.wlHint] * eExit[q.wlHint] * std::fabs(dotHL);
+        }
+    }
     default:
         return 0.0f;
     }
@@ -674,10 +944,26 @@ BSDF<3> createBSDF(const Scene& s, const SurfPt& sp, uint16_t wlFlags) {
     BSDF<3> f;
     f.kind = m.type;
     f.param = m.param;
+    f.onA = f.onB = 0.0f;
     switch (m.type) {
     case SLRHIP_MATERIAL_MATTE:
-        f.type = DT_Reflection | DT_LowFreq;                                   // basic_BSDFs.h:27
+        f.type = DT_Reflection | DT_LowFreq;                                   // basic_BSDFs.h:27, OrenNayerBRDF.h:29
         f.a = 1.0f * evalSpectrumRGB(s, m.spectrum[0]);
+        if (m.param >= 0.0f) {                                                 // OrenNayerBRDF.h:28-30 (double literals)
+            float sigma = m.param;
+            f.onA = (float)(1.0f - 0.5f * sigma * sigma / (sigma * sigma + 0.33));
+            f.onB = (float)(0.45 * sigma * sigma / (sigma * sigma + 0.09));
+        }
+        break;
+    case SLRHIP_MATERIAL_MICROFACET_METAL:
+        f.type = DT_Reflection | DT_HighFreq;                                  // MicrofacetBSDF.h:27-28
+        f.b = evalSpectrumRGB(s, m.spectrum[1]);
+        f.c = evalSpectrumRGB(s, m.spectrum[2]);
+        break;
+    case SLRHIP_MATERIAL_MICROFACET_GLASS:
+        f.type = DT_Reflection | DT_Transmission | DT_HighFreq;                // MicrofacetBSDF.h:44-46
+        f.b = evalSpectrumRGB(s, m.spectrum[1]);
+        f.c = evalSpectrumRGB(s, m.spectrum[2]);
         break;
     case SLRHIP_MATERIAL_METAL:
         f.type = DT_Reflection | DT_Delta0D;                                   // basic_BSDFs.h:43

@@ -66,9 +66,8 @@ static_assert(sizeof(LightTri) == 144, "LightTri is nine float4");
 // constant textures evaluated once: RGBTemplate::evaluate returns itself, RGBTypes.h:124-126).
 struct alignas(16) DevMaterial {
     uint32_t type;          // SLRHIP_MATERIAL_*
-    float param;
-    int32_t emitting;
-    uint32_t pad;
+    float param;            // matte: sigma (< 0: Lambert) | microfacet: alpha_g
+    float onA, onB;         // Oren-Nayar m_A, m_B (OrenNayerBRDF.h:28-30), evaluated on the host in double like the reference
     float a[4];             // matte: R | metal: coeffR | glass: coeff
     float b[4];             // metal: eta | glass: etaExt
     float c[4];             // metal: k   | glass: etaInt

@@ -11,6 +11,7 @@ namespace slrhip {
 struct Mat {
     uint32_t type;
     float param;
+    float onA, onB;
     RGB a, b, c, emittance;
 };
 
@@ -20,12 +21,117 @@ SLR_DEV Mat loadMat(const DevMaterial* m) {
     Mat r;
     r.type = __float_as_uint(h.x);
     r.param = h.y;
+    r.onA = h.z; r.onB = h.w;
     r.a = RGB(a.x, a.y, a.z); r.b = RGB(b.x, b.y, b.z); r.c = RGB(c.x, c.y, c.z); r.emittance = RGB(e.x, e.y, e.z);
     return r;
 }
 
 // DiffuseEDF::evaluate, EDFs/basic_EDFs.cpp:19-23: (dir.z > 0 ? 1.0f / M_PI : 0.0f) -> float
 SLR_DEV float diffuseEDF(V3 dir) { return dir.z > 0.0f ? (float)(1.0 / kPi) : 0.0f; }
+
+// std::max / std::min as the reference uses them (NaN in the second argument yields the first)
+SLR_DEV float stdmax(float a, float b) { return (a < b) ? b : a; }
+SLR_DEV float stdmin(float a, float b) { return (b < a) ? b : a; }
+
+// OrenNayerBRDF (BSDFs/OrenNayerBRDF.cpp:19-27,46-53): "sin" terms are 1 - z^2 without the square root
+SLR_DEV RGB orenNayar(const Mat& m, V3 dirI, V3 dirO, bool guardNonFinite) {
+    float sinThetaI = 1.0f - dirI.z * dirI.z;
+    float sinThetaO = 1.0f - dirO.z * dirO.z;
+    float absTanThetaI = sinThetaI / fabsf(dirI.z);
+    float absTanThetaO = sinThetaO / fabsf(dirO.z);
+    float sinAlpha = stdmax(sinThetaI, sinThetaO);
+    float tanBeta = stdmin(absTanThetaI, absTanThetaO);
+    float cos_dAzimuth = (dirI.x * dirO.x + dirI.y * dirO.y) / (sinThetaI * sinThetaO);
+    if (guardNonFinite && !isfinite(cos_dAzimuth)) cos_dAzimuth = 0.0f;
+    return m.a * (float)((double)(m.onA + m.onB * stdmax(0.0f, cos_dAzimuth) * sinAlpha * tanBeta) / kPi);
+}
+
+// GGX, Core/directional_distribution_functions.cpp:162-268.  The float libm calls (acosf, atan2f, tanf, cosf,
+// sinf) are the device library's: they can differ from the host's in the last ulp, so scenes with microfacet
+// lobes are compared with a tolerance instead of bit for bit (tests/test_gpu_parity.py).
+struct GGX {
+    float alpha_g;
+    SLR_DEV float evaluate(V3 m) const {                                         // :176-183
+        if (m.z <= 0) return 0.0f;
+        float theta_m = acosf(m.z);
+        float cosTheta_m = m.z;
+        float tanTheta_m = tanf(theta_m);
+        double c2 = (double)cosTheta_m * (double)cosTheta_m;
+        double s = (double)(alpha_g * alpha_g + tanTheta_m * tanTheta_m);
+        return (float)((double)(alpha_g * alpha_g) / (kPi * (c2 * c2) * (s * s)));      // std::pow(x, 4), std::pow(x, 2) in double
+    }
+    SLR_DEV float evaluateSmithG1(V3 v, V3 m) const {                            // :264-268
+        float chi = (dot(v, m) / v.z) > 0 ? 1 : 0;
+        float theta_v = acosf(fminf(1.0f, fmaxf(-1.0f, v.z)));
+        double t = (double)(alpha_g * tanf(theta_v));
+        return (float)((double)(chi * 2) / (1 + sqrt(1 + t * t)));
+    }
+    SLR_DEV float evaluatePDF(V3 v, V3 m) const { return evaluateSmithG1(v, m) * absDot(v, m) * evaluate(m) / fabsf(v.z); }   // :260-262
+    SLR_DEV float sample(V3 v, float u0, float u1, V3* m, float* normalPDF) const {     // :191-258
+        float alpha_gx = alpha_g, alpha_gy = alpha_g;
+        V3 sv = normalize(V3(alpha_gx * v.x, alpha_gy * v.y, v.z));
+        float theta_sv = acosf(sv.z);
+        float phi_sv = atan2f(sv.y, sv.x);
+        if (sv.z > 0.99999f) { theta_sv = 0.0f; phi_sv = 0.0f; }
+        float slope_x, slope_y;
+        if ((double)theta_sv < 0.0001) {
+            const float r = sqrtf(u0 / (1 - u0));
+            const float phi = (float)(2 * kPi * (double)u1);
+            slope_x = (float)((double)r * cos((double)phi));
+            slope_y = (float)((double)r * sin((double)phi));
+        }
+        else {
+            const float tan_theta_i = (float)tan((double)theta_sv);
+            const float a = 1 / tan_theta_i;
+            const float G1 = (float)(2 / (1 + sqrt(1.0 + 1.0 / (double)(a * a))));
+            const float A = (float)(2.0 * (double)u0 / (double)G1 - 1.0);
+            const float tmp = (float)(1.0 / ((double)(A * A) - 1.0));
+            const float B = tan_theta_i;
+            const float D = sqrtf(B * B * tmp * tmp - (A * A - B * B) * tmp);
+            const float slope_x_1 = B * tmp - D;
+            const float slope_x_2 = B * tmp + D;
+            slope_x = (A < 0 || (double)slope_x_2 > 1.0 / (double)tan_theta_i) ? slope_x_1 : slope_x_2;
+            if (u0 == 0) slope_x = 0;
+            float S;
+            if ((double)u1 > 0.5) { S = 1.0f; u1 = (float)(2.0 * ((double)u1 - 0.5)); }
+            else { S = -1.0f; u1 = (float)(2.0 * (0.5 - (double)u1)); }
+            const double w = (double)u1;
+            const float z = (float)((w * (w * (w * 0.27385 - 0.73369) + 0.46341)) / (w * (w * (w * 0.093073 + 0.309420) - 1.000000) + 0.597999));
+            slope_y = (float)((double)(S * z) * sqrt(1.0 + (double)(slope_x * slope_x)));
+        }
+        float tmp = cosf(phi_sv) * slope_x - sinf(phi_sv) * slope_y;
+        slope_y = sinf(phi_sv) * slope_x + cosf(phi_sv) * slope_y;
+        slope_x = tmp;
+        slope_x *= alpha_gx;
+        slope_y *= alpha_gy;
+        *m = normalize(V3(-slope_x, -slope_y, 1));
+        float D = evaluate(*m);
+        *normalPDF = evaluateSmithG1(v, *m) * absDot(v, *m) * D / fabsf(v.z);
+        return D;
+    }
+};
+
+// FresnelDielectric::evaluate(cosEnter, wlIdx), DDF.cpp:113-129
+SLR_DEV float fresnelDielectricWl(RGB etaExt, RGB etaInt, float cosEnter, uint32_t wl) {
+    cosEnter = fminf(1.0f, fmaxf(-1.0f, cosEnter));
+    bool entering = cosEnter > 0.0f;
+    const float eEnter = entering ? etaExt.comp(wl) : etaInt.comp(wl);
+    const float eExit = entering ? etaInt.comp(wl) : etaExt.comp(wl);
+    return fresnelDielectric1(eEnter, eExit, sqrtf(fmaxf(0.0f, 1.0f - cosEnter * cosEnter)), fabsf(cosEnter));
+}
+
+// One wavelength of the Walter-07 transmission term (MicrofacetBSDF.cpp:170-181, :225-236)
+SLR_DEV float mfTransmissionWl(const GGX& D_, const Mat& m, RGB eEnter, RGB eExit, V3 dirOut, V3 dir, uint32_t wl) {
+    const float ee = eEnter.comp(wl), ex = eExit.comp(wl);
+    V3 m_wl = normalize(-(ee * dirOut + ex * dir));
+    float dotHV_wl = dot(dirOut, m_wl);
+    float dotHL_wl = dot(dir, m_wl);
+    float F_wl = fresnelDielectricWl(m.b, m.c, dotHV_wl, wl);
+    float G_wl = D_.evaluateSmithG1(dirOut, m_wl) * D_.evaluateSmithG1(dir, m_wl);
+    float D_wl = D_.evaluate(m_wl);
+    double den = (double)(ee * dotHV_wl + ex * dotHL_wl);
+    return (float)((double)(fabsf(dotHV_wl * dotHL_wl) * (1 - F_wl) * G_wl * D_wl) / (den * den));
+}
 
 struct BsdfSample {
     V3 dir_sn;
@@ -40,12 +146,15 @@ SLR_DEV uint32_t bsdfType(uint32_t matType, uint32_t wlFlags) {
     case SLRHIP_MATERIAL_MATTE: return DT_Reflection | DT_LowFreq;
     case SLRHIP_MATERIAL_METAL: return DT_Reflection | DT_Delta0D;
     case SLRHIP_MATERIAL_GLASS: return DT_Reflection | DT_Transmission | DT_Delta0D | ((wlFlags & 1u) ? 0u : (uint32_t)DT_Dispersive);
+    case SLRHIP_MATERIAL_MICROFACET_METAL: return DT_Reflection | DT_HighFreq;                     // MicrofacetBSDF.h:27-28
+    case SLRHIP_MATERIAL_MICROFACET_GLASS: return DT_Reflection | DT_Transmission | DT_HighFreq;   // MicrofacetBSDF.h:44-46
     default: return 0;
     }
 }
 
 // BSDF::sample (DDF.h:231-246) over sampleInternal of LambertianBRDF / SpecularBRDF / SpecularBSDF
 // (BSDFs/basic_BSDFs.cpp:12-26, 61-71, 95-149); query.flags = All, adjoint = false.
+template <bool MF>
 SLR_DEV RGB bsdfSample(const Mat& m, uint32_t type, V3 dirOut, V3 gNorm, uint32_t wl, float uComp, float u0, float u1, BsdfSample* res) {
     res->dirPDF = 0.0f;
     res->dirType = 0;
@@ -53,11 +162,76 @@ SLR_DEV RGB bsdfSample(const Mat& m, uint32_t type, V3 dirOut, V3 gNorm, uint32_
     RGB fs_sn;
     switch (m.type) {
     case SLRHIP_MATERIAL_MATTE: {
+        // LambertianBRDF basic_BSDFs.cpp:12-26 / OrenNayerBRDF.cpp:12-34: same cosine sample, different value
         res->dir_sn = cosineSampleHemisphere(u0, u1);
         res->dirPDF = (float)((double)res->dir_sn.z / kPi);
         res->dirType = type;
         res->dir_sn.z *= dot(dirOut, gNorm) > 0 ? 1 : -1;
-        fs_sn = m.a / (float)kPi;
+        fs_sn = m.param >= 0.0f ? orenNayar(m, res->dir_sn, dirOut, true) : m.a / (float)kPi;
+        break;
+    }
+    case SLRHIP_MATERIAL_MICROFACET_METAL: {
+        if (!MF) return RGB();      // kernels instantiated for scenes without microfacet lobes carry none of this code
+        // MicrofacetBRDF::sampleInternal, BSDFs/MicrofacetBSDF.cpp:11-45
+        GGX D_ = {m.param};
+        bool entering = dirOut.z >= 0.0f;
+        float sign = entering ? 1.0f : -1.0f;
+        V3 mm; float mPDF;
+        float D = D_.sample(sign * dirOut, u0, u1, &mm, &mPDF);
+        float dotHV = dot(dirOut, mm);
+        if (dotHV * sign <= 0) return RGB();
+        res->dir_sn = 2 * dotHV * mm - dirOut;
+        if (res->dir_sn.z * dirOut.z <= 0) return RGB();
+        float commonPDFTerm = 1.0f / (4 * dotHV * sign);
+        res->dirPDF = commonPDFTerm * mPDF;
+        res->dirType = type;
+        RGB F = fresnelConductor(m.b, m.c, dotHV);
+        float G = D_.evaluateSmithG1(dirOut, mm) * D_.evaluateSmithG1(res->dir_sn, mm);
+        fs_sn = F * D * G / (4 * dirOut.z * res->dir_sn.z);
+        break;
+    }
+    case SLRHIP_MATERIAL_MICROFACET_GLASS: {
+        if (!MF) return RGB();
+        // MicrofacetBSDF::sampleInternal, MicrofacetBSDF.cpp:113-196 (flags = All, adjoint = false)
+        GGX D_ = {m.param};
+        bool entering = dirOut.z >= 0.0f;
+        float sign = entering ? 1.0f : -1.0f;
+        RGB eEnter = entering ? m.b : m.c;
+        RGB eExit = entering ? m.c : m.b;
+        V3 mm; float mPDF;
+        float D = D_.sample(sign * dirOut, u0, u1, &mm, &mPDF);
+        float dotHV = dot(dirOut, mm);
+        if (dotHV * sign <= 0 || isnan(D)) return RGB();
+        RGB F = fresnelDielectric(m.b, m.c, dotHV);
+        float reflectProb = importance(F, wl);
+        if (uComp < reflectProb) {
+            res->dir_sn = 2 * dotHV * mm - dirOut;
+            if (res->dir_sn.z * dirOut.z <= 0) return RGB();
+            float commonPDFTerm = reflectProb / (4 * dotHV * sign);
+            res->dirPDF = commonPDFTerm * mPDF;
+            res->dirType = DT_Reflection | DT_HighFreq;
+            float G = D_.evaluateSmithG1(dirOut, mm) * D_.evaluateSmithG1(res->dir_sn, mm);
+            fs_sn = F * D * G / (4 * dirOut.z * res->dir_sn.z);
+        }
+        else {
+            float ee = eEnter.comp(wl), ex = eExit.comp(wl);
+            float recRelIOR = ee / ex;
+            float innerRoot = 1 + recRelIOR * recRelIOR * (dotHV * dotHV - 1);
+            if (innerRoot < 0) return RGB();
+            res->dir_sn = (recRelIOR * dotHV - sign * sqrtf(innerRoot)) * mm - recRelIOR * dirOut;
+            if (res->dir_sn.z * dirOut.z >= 0) return RGB();
+            float dotHL = dot(res->dir_sn, mm);
+            double den = (double)(ee * dotHV + ex * dotHL);
+            float commonPDFTerm = (float)((double)(1 - reflectProb) / (den * den));
+            float pdf = commonPDFTerm * mPDF * ex * ex * fabsf(dotHL);
+            RGB ret(mfTransmissionWl(D_, m, eEnter, eExit, dirOut, res->dir_sn, 0), mfTransmissionWl(D_, m, eEnter, eExit, dirOut, res->dir_sn, 1),
+                    mfTransmissionWl(D_, m, eEnter, eExit, dirOut, res->dir_sn, 2));
+            ret = ret / fabsf(dirOut.z * res->dir_sn.z);
+            ret = ret * (eEnter * eEnter);
+            res->dirPDF = pdf;
+            res->dirType = DT_Transmission | DT_HighFreq;
+            fs_sn = ret;
+        }
         break;
     }
     case SLRHIP_MATERIAL_METAL: {
@@ -106,21 +280,115 @@ SLR_DEV RGB bsdfSample(const Mat& m, uint32_t type, V3 dirOut, V3 gNorm, uint32_
     return fs_sn * snCorrection;
 }
 
-// BSDF::evaluate (DDF.h:247-267) + evaluatePDF (:268-279) for the NEE direction.
-SLR_DEV RGB bsdfEvaluate(const Mat& m, uint32_t type, V3 dirOut, V3 gNorm, V3 dir, float* pdf) {
-    *pdf = 0.0f;
-    if (dtMatches(type, DT_All) && m.type == SLRHIP_MATERIAL_MATTE) {
-        // LambertianBRDF::evaluatePDFInternal basic_BSDFs.cpp:41-50
-        if (!(dirOut.z * dir.z <= 0.0f)) *pdf = (float)((double)fabsf(dir.z) / kPi);
+// BSDF::evaluatePDF (DDF.h:268-279; query.flags = All) of the lobes that have a non-delta component.
+template <bool MF>
+SLR_DEV float bsdfEvaluatePDF(const Mat& m, uint32_t type, V3 dirOut, V3 dir, uint32_t wl) {
+    if (!dtMatches(type, DT_All)) return 0.0f;
+    switch (m.type) {
+    case SLRHIP_MATERIAL_MATTE:
+        // LambertianBRDF::evaluatePDFInternal basic_BSDFs.cpp:41-50 == OrenNayerBRDF.cpp:58-66
+        if (dirOut.z * dir.z <= 0.0f) return 0.0f;
+        return (float)((double)fabsf(dir.z) / kPi);
+    case SLRHIP_MATERIAL_MICROFACET_METAL: {
+        if (!MF) return 0.0f;
+        // MicrofacetBSDF.cpp:73-100
+        if (dir.z * dirOut.z <= 0) return 0.0f;
+        GGX D_ = {m.param};
+        float sign = dirOut.z >= 0.0f ? 1.0f : -1.0f;
+        V3 mm = sign * normalize(dirOut + dir);
+        float dotHV = dot(dirOut, mm);
+        if (dotHV * sign <= 0) return 0.0f;
+        float mPDF = D_.evaluatePDF(sign * dirOut, mm);
+        float commonPDFTerm = 1.0f / (4 * dotHV * sign);
+        return commonPDFTerm * mPDF;
     }
+    case SLRHIP_MATERIAL_MICROFACET_GLASS: {
+        if (!MF) return 0.0f;
+        // MicrofacetBSDF.cpp:249-303
+        GGX D_ = {m.param};
+        bool entering = dirOut.z >= 0.0f;
+        float sign = entering ? 1.0f : -1.0f;
+        float dotNVdotNL = dir.z * dirOut.z;
+        if (dotNVdotNL == 0) return 0.0f;
+        float ee = (entering ? m.b : m.c).comp(wl), ex = (entering ? m.c : m.b).comp(wl);
+        V3 mm;
+        if (dotNVdotNL > 0) mm = sign * normalize(dirOut + dir);
+        else mm = normalize(-(ee * dirOut + ex * dir));
+        float dotHV = dot(dirOut, mm);
+        if (dotHV * sign <= 0) return 0.0f;
+        float mPDF = D_.evaluatePDF(sign * dirOut, mm);
+        RGB F = fresnelDielectric(m.b, m.c, dotHV);
+        float reflectProb = importance(F, wl);
+        if (dotNVdotNL > 0) {
+            float commonPDFTerm = reflectProb / (4 * dotHV * sign);
+            return commonPDFTerm * mPDF;
+        }
+        float dotHL = dot(dir, mm);
+        double den = (double)(ee * dotHV + ex * dotHL);
+        float commonPDFTerm = (float)((double)(1 - reflectProb) / (den * den));
+        return commonPDFTerm * mPDF * ex * ex * fabsf(dotHL);
+    }
+    default:
+        return 0.0f;
+    }
+}
+
+// BSDF::evaluate (DDF.h:247-267) + evaluatePDF for the NEE direction.
+template <bool MF>
+SLR_DEV RGB bsdfEvaluate(const Mat& m, uint32_t type, V3 dirOut, V3 gNorm, V3 dir, uint32_t wl, float* pdf) {
+    *pdf = bsdfEvaluatePDF<MF>(m, type, dirOut, dir, wl);
     bool reflect = dot(gNorm, dirOut) * dot(gNorm, dir) > 0;                       // sideTest DDF.h:213-216
     uint32_t flags = DT_All & (DT_AllFreq | (reflect ? DT_Reflection : DT_Transmission));
     if (!dtMatches(type, flags)) return RGB();
     RGB fs_sn;
-    if (m.type == SLRHIP_MATERIAL_MATTE) {
-        // LambertianBRDF::evaluateInternal basic_BSDFs.cpp:28-39
+    switch (m.type) {
+    case SLRHIP_MATERIAL_MATTE:
+        // LambertianBRDF::evaluateInternal basic_BSDFs.cpp:28-39 / OrenNayerBRDF.cpp:36-56
         if (dirOut.z * dir.z <= 0.0f) fs_sn = RGB();
+        else if (m.param >= 0.0f) fs_sn = orenNayar(m, dir, dirOut, false);
         else fs_sn = m.a / (float)kPi;
+        break;
+    case SLRHIP_MATERIAL_MICROFACET_METAL: {
+        if (!MF) break;
+        // MicrofacetBRDF::evaluateInternal MicrofacetBSDF.cpp:47-71
+        if (dir.z * dirOut.z <= 0) break;
+        GGX D_ = {m.param};
+        float sign = dirOut.z >= 0.0f ? 1.0f : -1.0f;
+        V3 mm = sign * normalize(dirOut + dir);
+        float dotHV = dot(dirOut, mm);
+        float D = D_.evaluate(mm);
+        RGB F = fresnelConductor(m.b, m.c, dotHV);
+        float G = D_.evaluateSmithG1(dirOut, mm) * D_.evaluateSmithG1(dir, mm);
+        fs_sn = F * D * G / (4 * dirOut.z * dir.z);
+        break;
+    }
+    case SLRHIP_MATERIAL_MICROFACET_GLASS: {
+        if (!MF) break;
+        // MicrofacetBSDF::evaluateInternal MicrofacetBSDF.cpp:198-247 (mQuery.flags after the side test)
+        GGX D_ = {m.param};
+        bool entering = dirOut.z >= 0.0f;
+        float sign = entering ? 1.0f : -1.0f;
+        float dotNVdotNL = dir.z * dirOut.z;
+        if (dotNVdotNL > 0 && dtMatches(flags, DT_Reflection | DT_AllFreq)) {
+            V3 mm = sign * normalize(dirOut + dir);
+            float dotHV = dot(dirOut, mm);
+            float D = D_.evaluate(mm);
+            RGB F = fresnelDielectric(m.b, m.c, dotHV);
+            float G = D_.evaluateSmithG1(dirOut, mm) * D_.evaluateSmithG1(dir, mm);
+            fs_sn = F * D * G / (4 * dotNVdotNL);
+        }
+        else if (dotNVdotNL < 0 && dtMatches(flags, DT_Transmission | DT_AllFreq)) {
+            RGB eEnter = entering ? m.b : m.c;
+            RGB eExit = entering ? m.c : m.b;
+            RGB ret(mfTransmissionWl(D_, m, eEnter, eExit, dirOut, dir, 0), mfTransmissionWl(D_, m, eEnter, eExit, dirOut, dir, 1),
+                    mfTransmissionWl(D_, m, eEnter, eExit, dirOut, dir, 2));
+            ret = ret / fabsf(dotNVdotNL);
+            fs_sn = ret * (eEnter * eEnter);
+        }
+        break;
+    }
+    default:   // SpecularBRDF / SpecularBSDF::evaluateInternal return Zero (basic_BSDFs.cpp:73-77,151-155)
+        break;
     }
     float snCorrection = fabsf(dir.z / dot(dir, gNorm));
     return fs_sn * snCorrection;

@@ -20,6 +20,7 @@ struct DevScene {
     uint32_t numMaterials;
     uint32_t numLights;
     uint32_t lightPow2;           // prevPowerOf2(numLights)
+    uint32_t hasMicrofacet;       // any SLRHIP_MATERIAL_MICROFACET_* in the scene
     DevCamera camera;
 };
 

@@ -20,8 +20,6 @@
 // wave cycles waiting on memory), and the material / light tables live in LDS.
 #include <hip/hip_runtime.h>
 
-#include <cstdlib>
-
 #include "pt_bsdf.h"
 #include "pt_kernels.h"
 
@@ -108,7 +106,7 @@ struct ShadeLds {
     float lightCDF[kLdsLights + 1];
 };
 
-template <bool LDS_TABLES>
+template <bool LDS_TABLES, bool MF>
 __global__ __launch_bounds__(kShadeBlock) void k_logic(DevScene sc, PathBuffers pb, RenderParams rp, uint32_t parity) {
     __shared__ ShadeLds lds;
     __shared__ PushLds pushLds;
@@ -260,7 +258,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_logic(DevScene sc, PathBuffers 
                         RGB Le = M * RGB(diffuseEDF(shadowDir_l));
                         float lightPDF = lightProb * areaPDF;
                         float pdfDir;
-                        RGB fs = bsdfEvaluate(m, type, dirOut_sn, gNorm_sn, shadowDir_sn, &pdfDir);
+                        RGB fs = bsdfEvaluate<MF>(m, type, dirOut_sn, gNorm_sn, shadowDir_sn, wl, &pdfDir);
                         float cosLight = absDot(-shadowDir, lgn);
                         float bsdfPDF = pdfDir * cosLight / dist2;
                         float MISWeight = 1.0f;
@@ -274,7 +272,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_logic(DevScene sc, PathBuffers 
                     float u0 = rng.nextFloat();
                     float u1 = rng.nextFloat();
                     BsdfSample bs;
-                    RGB fs = bsdfSample(m, type, dirOut_sn, gNorm_sn, wl, uComp, u0, u1, &bs);
+                    RGB fs = bsdfSample<MF>(m, type, dirOut_sn, gNorm_sn, wl, uComp, u0, u1, &bs);
                     if (fs.isZero() || bs.dirPDF == 0.0f) {
                         finish = true;                                         // :209
                     }
@@ -474,12 +472,13 @@ void launchRegen(const DevScene& sc, const PathBuffers& pb, const RenderParams& 
     hipLaunchKernelGGL(k_regen, dim3(rp.shardCapacity / kShadeBlock * kShards), dim3(kShadeBlock), 0, stream, sc, pb, rp, parity);
 }
 void launchLogic(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, hipStream_t stream) {
-    const dim3 grid((rp.numSlots + kShadeBlock - 1) / kShadeBlock);
-    static const bool noLds = getenv("SLRHIP_DEBUG_NO_LDS_TABLES") != nullptr;
-    if (!noLds && sc.numMaterials <= (uint32_t)kLdsMaterials && sc.numLights <= (uint32_t)kLdsLights)
-        hipLaunchKernelGGL(k_logic<true>, grid, dim3(kShadeBlock), 0, stream, sc, pb, rp, parity);
-    else
-        hipLaunchKernelGGL(k_logic<false>, grid, dim3(kShadeBlock), 0, stream, sc, pb, rp, parity);
+    const dim3 grid((rp.numSlots + kShadeBlock - 1) / kShadeBlock), block(kShadeBlock);
+    const bool ldsTables = sc.numMaterials <= (uint32_t)kLdsMaterials && sc.numLights <= (uint32_t)kLdsLights;
+    // four instantiations: the microfacet (GGX) code costs ~45 VGPRs, so scenes without such lobes get a kernel without it
+    if (ldsTables && !sc.hasMicrofacet) hipLaunchKernelGGL((k_logic<true, false>), grid, block, 0, stream, sc, pb, rp, parity);
+    else if (ldsTables) hipLaunchKernelGGL((k_logic<true, true>), grid, block, 0, stream, sc, pb, rp, parity);
+    else if (!sc.hasMicrofacet) hipLaunchKernelGGL((k_logic<false, false>), grid, block, 0, stream, sc, pb, rp, parity);
+    else hipLaunchKernelGGL((k_logic<false, true>), grid, block, 0, stream, sc, pb, rp, parity);
 }
 void launchResolve(const PathBuffers& pb, const RenderParams& rp, float* dst, hipStream_t stream) {
     hipLaunchKernelGGL(k_resolve, dim3((rp.numPixels + 255) / 256), dim3(256), 0, stream, pb, rp, dst);

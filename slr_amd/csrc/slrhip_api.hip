@@ -190,16 +190,23 @@ int slrhip_upload_scene(slrhip_ctx* ctx, const slrhip_scene_desc* d) {
             return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: triangle index out of range");
     }
     std::vector<DevMaterial> mats(d->num_materials);
+    std::vector<char> emitting(d->num_materials, 0);
     for (uint32_t i = 0; i < d->num_materials; ++i) {
         const slrhip_material& m = d->materials[i];
         DevMaterial dm;
         std::memset(&dm, 0, sizeof(dm));
         dm.type = m.type;
         dm.param = m.param;
-        if (m.type == SLRHIP_MATERIAL_MATTE && m.param >= 0.0f)
-            return fail(SLRHIP_ERR_UNSUPPORTED, "slrhip_upload_scene: Oren-Nayar (sigma >= 0) not implemented in this build");
-        if (m.type > SLRHIP_MATERIAL_GLASS)
-            return fail(SLRHIP_ERR_UNSUPPORTED, "slrhip_upload_scene: microfacet materials not implemented in this build");
+        if (m.type > SLRHIP_MATERIAL_MICROFACET_GLASS)
+            return fail(SLRHIP_ERR_UNSUPPORTED, "slrhip_upload_scene: unknown material type");
+        if (m.type == SLRHIP_MATERIAL_MATTE && m.param >= 0.0f) {
+            // OrenNayerBRDF ctor, OrenNayerBRDF.h:28-30: double literals in a float expression
+            const float sigma = m.param;
+            dm.onA = (float)(1.0f - 0.5f * sigma * sigma / (sigma * sigma + 0.33));
+            dm.onB = (float)(0.45 * sigma * sigma / (sigma * sigma + 0.09));
+        }
+        if ((m.type == SLRHIP_MATERIAL_MICROFACET_METAL || m.type == SLRHIP_MATERIAL_MICROFACET_GLASS) && !(m.param > 0.0f))
+            return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: microfacet material needs alpha_g > 0");
         auto fetch = [&](int32_t idx, float* dst) -> bool {
             if (idx < 0) return true;
             if ((uint32_t)idx >= d->num_spectra) return false;
@@ -211,7 +218,9 @@ int slrhip_upload_scene(slrhip_ctx* ctx, const slrhip_scene_desc* d) {
             return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: spectrum index out of range");
         if (m.spectrum[0] < 0 && m.type <= SLRHIP_MATERIAL_GLASS)
             return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: material without its first spectrum");
-        dm.emitting = m.emittance >= 0 ? 1 : 0;
+        if (m.type >= SLRHIP_MATERIAL_METAL && (m.spectrum[1] < 0 || m.spectrum[2] < 0))
+            return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: material without its eta / k spectra");
+        emitting[i] = m.emittance >= 0;
         mats[i] = dm;
     }
 
@@ -246,7 +255,7 @@ int slrhip_upload_scene(slrhip_ctx* ctx, const slrhip_scene_desc* d) {
         s.areaPDF = 1.0f / (0.5f * len);                    // 1 / Triangle::area() :217-222
         s.material = t.material;
         s.light = -1;
-        if (mats[t.material].emitting) {
+        if (emitting[t.material]) {
             s.light = (int32_t)lights.size();
             LightTri l;
             std::memset(&l, 0, sizeof(l));
@@ -306,6 +315,9 @@ int slrhip_upload_scene(slrhip_ctx* ctx, const slrhip_scene_desc* d) {
     sc.numNodes = (uint32_t)bvh.nodes.size();
     sc.numMaterials = (uint32_t)mats.size();
     sc.numLights = (uint32_t)lights.size();
+    sc.hasMicrofacet = 0;
+    for (const DevMaterial& dm : mats)
+        if (dm.type == SLRHIP_MATERIAL_MICROFACET_METAL || dm.type == SLRHIP_MATERIAL_MICROFACET_GLASS) sc.hasMicrofacet = 1;
     sc.lightPow2 = prevPowerOf2(sc.numLights);
     sc.camera = cam;
     ctx->bvhDepth = bvh.depth;

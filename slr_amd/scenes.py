@@ -217,3 +217,39 @@ def tiny_box(aspect=1.0):
     b = SceneBuilder()
     cornell_walls(b)
     return b.build(cornell_camera(aspect), name="tiny_box")
+
+
+# RGB-mode eta / k of titanium (Cornell_Box_Boxes.txt:32-33 uses the "Titanium" IOR table); fixed scene inputs.
+TITANIUM_ETA_RGB = (2.7407, 2.5418, 2.2370)
+TITANIUM_K_RGB = (3.8143, 3.4345, 3.0235)
+
+
+def cornell_lobes(kind, aspect=1.0, segments=16, rings=8):
+    """Cornell walls + one sphere carrying the lobe under test: 'oren_nayar', 'ggx_metal' or 'ggx_glass'."""
+    b = SceneBuilder()
+    cornell_walls(b)
+    if kind == "oren_nayar":
+        m = b.matte(b.spectrum_srgb_nonlinear(0.7, 0.6, 0.3), sigma=0.6)
+    elif kind == "ggx_metal":
+        m = b.microfacet_metal(b.spectrum_rgb(*TITANIUM_ETA_RGB), b.spectrum_rgb(*TITANIUM_K_RGB), 0.1)
+    elif kind == "ggx_glass":
+        m = b.microfacet_glass(b.spectrum_rgb(*AIR_ETA_RGB), b.spectrum_rgb(*BK7_ETA_RGB), 0.2)
+    else:
+        raise ValueError(kind)
+    b.add_uv_sphere(segments, rings, m, _translate(-0.3, 0, -0.5) @ _scale(0.6) @ _translate(0, 1, 0))
+    return b.build(cornell_camera(aspect), name="cornell_" + kind)
+
+
+def cornell_box_boxes(aspect=1.0):
+    """Config 3 of BASELINE.json, RGB variant: Cornell_Box_Boxes-shaped scene (TestScenes/Cornell_Box_Boxes.txt:7-53):
+    white/red/blue walls, 0.5 x 0.5 light at y = 0.999 scaled to this box, two boxes: a GGX titanium conductor
+    (alpha_g = 0.1) and a matte one."""
+    b = SceneBuilder()
+    cornell_walls(b)
+    ti = b.microfacet_metal(b.spectrum_rgb(*TITANIUM_ETA_RGB), b.spectrum_rgb(*TITANIUM_K_RGB), 0.1)
+    white = b.matte(b.spectrum_srgb_nonlinear(0.75, 0.75, 0.75))
+    tall = _translate(-0.5, 0.0, -1.0) @ _rotate(0.3, (0, 1, 0)) @ _translate(0, 0.8, 0) @ np.diag([0.8, 1.6, 0.8, 1.0])
+    short = _translate(0.55, 0.0, 0.2) @ _rotate(-0.35, (0, 1, 0)) @ _translate(0, 0.4, 0) @ np.diag([0.8, 0.8, 0.8, 1.0])
+    b.add_box(ti, tall)
+    b.add_box(white, short)
+    return b.build(cornell_camera(aspect), name="cornell_box_boxes")

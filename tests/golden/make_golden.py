@@ -86,6 +86,9 @@ def main():
                         scale=np.float32(0.37), bmp=bmp)
     make("rgb_tiny_box", scenes.tiny_box(1.0), lib, 32, 32, 8, 2)
     make("rgb_cornell_glass", scenes.cornell_box_spheres(4.0 / 3.0, 16, 8, "glass"), lib, 48, 36, 8, 2)
+    make("rgb_oren_nayar", scenes.cornell_lobes("oren_nayar"), lib, 40, 40, 8, 2)
+    make("rgb_ggx_metal", scenes.cornell_lobes("ggx_metal"), lib, 40, 40, 8, 2)
+    make("rgb_ggx_glass", scenes.cornell_lobes("ggx_glass"), lib, 40, 40, 8, 2)
     make("rgb_cornell_matte", scenes.cornell_box_spheres(4.0 / 3.0, 16, 8, "matte"), lib, 48, 36, 8, 2)
 
 

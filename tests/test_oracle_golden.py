@@ -7,7 +7,7 @@ from helpers import assert_bit_equal, load_golden, scene_from_golden
 from oracle import binding as ob
 from slr_amd import abi
 
-SCENES = ["rgb_tiny_box", "rgb_cornell_glass", "rgb_cornell_matte"]
+SCENES = ["rgb_tiny_box", "rgb_cornell_glass", "rgb_cornell_matte", "rgb_oren_nayar", "rgb_ggx_metal", "rgb_ggx_glass"]
 
 
 def test_rng_known_answers(oracle_rgb):

@@ -45,3 +45,22 @@ def test_random_rays_bit_exact(oracle_rgb, ref_rgb):
     assert (same | tie).all()
     assert tie.sum() <= n // 500
     assert_bit_equal(ho["dist"], hr["dist"], "dist")
+
+
+@pytest.mark.parametrize("kind", ["oren_nayar", "ggx_metal", "ggx_glass"])
+def test_lobes_bit_exact(oracle_rgb, ref_rgb, kind):
+    sc = scenes.cornell_lobes(kind, segments=24, rings=12)
+    so, sr = oracle_rgb.scene(sc), ref_rgb.scene(sc)
+    st = ob.settings(56, 56, seed=31337)
+    fo, _ = so.render(st, 8)
+    fr, _ = sr.render(st, 8)
+    assert_bit_equal(fo, fr, kind)
+
+
+def test_boxes_scene_bit_exact(oracle_rgb, ref_rgb):
+    sc = scenes.cornell_box_boxes()
+    so, sr = oracle_rgb.scene(sc), ref_rgb.scene(sc)
+    st = ob.settings(64, 64, seed=5)
+    fo, _ = so.render(st, 8)
+    fr, _ = sr.render(st, 8)
+    assert_bit_equal(fo, fr, "cornell_box_boxes")
