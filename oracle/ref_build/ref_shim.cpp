@@ -26,6 +26,8 @@
 
 #include "BSDFs/basic_BSDFs.h"
 #include "BasicTypes/Spectrum.h"
+#include "BasicTypes/common_spectra.h"
+#include "BasicTypes/spectrum_library.h"
 #include "Cameras/PerspectiveCamera.h"
 #include "Core/ImageSensor.h"
 #include "Core/RenderSettings.h"
@@ -392,6 +394,94 @@ int slr_ref_save_image(const float* fb, uint32_t width, uint32_t height, float s
             for (int k = 0; k < kComponents; ++k) { px.value.result[k] = fb[((size_t)y * width + x) * kComponents + k]; px.value.comp[k] = 0.0f; }
         }
     sensor.saveImage(path, scale);
+    return 0;
+}
+
+long slr_ref_dump_table(int what, const char* name, void* dst, long capacity) {
+    using namespace Upsampling;
+    if (what == 0) {
+        const long n = GridWidth * GridHeight * (long)sizeof(spectrum_grid_cell_t);
+        if (dst && capacity >= n) std::memcpy(dst, spectrum_grid, n);
+        return n;
+    }
+    if (what == 1) {
+        // the number of data points is the largest index any cell references, + 1
+        uint32_t maxIdx = 0;
+        for (uint32_t c = 0; c < GridWidth * GridHeight; ++c)
+            for (uint32_t k = 0; k < spectrum_grid[c].num_points; ++k) maxIdx = std::max<uint32_t>(maxIdx, spectrum_grid[c].idx[k]);
+        const long per = 2 + 2 + NumWavelengthSamples;
+        const long n = (long)(maxIdx + 1) * per;
+        if (dst && capacity >= n) {
+            float* f = (float*)dst;
+            for (uint32_t i = 0; i <= maxIdx; ++i) {
+                const spectrum_data_point_t& p = spectrum_data_points[i];
+                f[0] = p.xystar[0]; f[1] = p.xystar[1]; f[2] = p.uv[0]; f[3] = p.uv[1];
+                for (uint32_t k = 0; k < NumWavelengthSamples; ++k) f[4 + k] = p.spectrum[k];
+                f += per;
+            }
+        }
+        return n;
+    }
+    if (what == 2) {
+        const long n = 3 * (long)NumCMFSamples;
+        if (dst && capacity >= n) {
+            float* f = (float*)dst;
+            for (uint32_t i = 0; i < NumCMFSamples; ++i) { f[i] = xbar_2deg[i]; f[NumCMFSamples + i] = ybar_2deg[i]; f[2 * NumCMFSamples + i] = zbar_2deg[i]; }
+        }
+        return n;
+    }
+    if (what == 3) {
+        const long n = StandardIlluminant::NumSamples;
+        if (dst && capacity >= n) std::memcpy(dst, StandardIlluminant::D65, n * sizeof(float));
+        return n;
+    }
+    if (what == 4 && name) {
+        auto it = SpectrumLibrary::IORs.find(name);
+        if (it == SpectrumLibrary::IORs.end()) return -1;
+        const SpectrumLibrary::IndexOfRefraction& ior = it->second;
+        const bool regular = ior.dType == SpectrumLibrary::DistributionType::Regular;
+        const long ns = ior.numSamples;
+        const long n = 5 + 3 * ns;
+        if (dst && capacity >= n) {
+            float* f = (float*)dst;
+            f[0] = (float)ns; f[1] = ior.minLambdas; f[2] = ior.maxLambdas; f[3] = regular ? 1.0f : 0.0f; f[4] = ior.ks ? 1.0f : 0.0f;
+            for (long i = 0; i < ns; ++i) {
+                f[5 + i] = ior.lambdas ? ior.lambdas[i] : 0.0f;
+                f[5 + ns + i] = ior.etas[i];
+                f[5 + 2 * ns + i] = ior.ks ? ior.ks[i] : 0.0f;
+            }
+        }
+        return n;
+    }
+    return -1;
+}
+
+int slr_ref_eval_spectrum(const slrhip_scene_desc* d, uint32_t index, float offset, float* out) {
+#ifdef Use_Spectral_Representation
+    if (!d || !out || index >= d->num_spectra) return 1;
+    static bool inited = false;
+    if (!inited) { initSpectrum(); inited = true; }
+    InputSpectrum* sp = makeSpectrum(d, d->spectra[index]);
+    if (!sp) return 2;
+    float pdf;
+    WavelengthSamples wls = WavelengthSamples::createWithEqualOffsets(offset, 0.0f, &pdf);
+    SampledSpectrum v = sp->evaluate(wls);
+    for (int k = 0; k < kComponents; ++k) out[k] = v[k];
+    delete sp;
+    return 0;
+#else
+    (void)d; (void)index; (void)offset; (void)out;
+    return 3;
+#endif
+}
+
+int slr_ref_upsample(int spType, int space, float e0, float e1, float e2, float* uvs) {
+    if (!uvs) return 1;
+    static const SpectrumType types[3] = {SpectrumType::Reflectance, SpectrumType::Illuminant, SpectrumType::IndexOfRefraction};
+    static const ColorSpace spaces[4] = {ColorSpace::sRGB, ColorSpace::sRGB_NonLinear, ColorSpace::xyY, ColorSpace::XYZ};
+    if (spType < 0 || spType > 2 || space < 0 || space > 3) return 1;
+    UpsampledContinuousSpectrum s(types[spType], spaces[space], e0, e1, e2);
+    uvs[0] = s.u; uvs[1] = s.v; uvs[2] = s.scale;
     return 0;
 }
 

@@ -96,13 +96,26 @@ template <int N> inline Spec<N> operator/(Spec<N> a, float s) { float rc = 1.0f 
 template <int N> inline Spec<N> operator+(Spec<N> a, float s) { return a + Spec<N>(s); } // implicit ctor from scalar
 template <int N> inline Spec<N> operator-(Spec<N> a, float s) { return a - Spec<N>(s); }
 
-// RGBTypes.h:103-108  importance(): 0.9-primary weighting
-inline float importance(const Spec<3>& s, uint16_t selectedLambda) {
-    float sum = s.c[0] + s.c[1] + s.c[2];
+// importance(): 0.9-primary weighting.  RGBTypes.h:103-108 (sum = r + g + b, marginal = (1 - primary) / 2) and
+// SpectrumTypes.h:512-526 (running sum from 0, marginal = (1 - primary) / (N - 1)) are the same float
+// operations for N = 3, so one template serves both.
+template <int N>
+inline float importance(const Spec<N>& s, uint16_t selectedLambda) {
+    float sum = 0;
+    for (int i = 0; i < N; ++i) sum += s.c[i];
     const float primary = 0.9f;
-    const float marginal = (1 - primary) / 2;
+    const float marginal = (1 - primary) / (N - 1);
     return sum * marginal + s.c[selectedLambda] * (primary - marginal);
 }
+
+// WavelengthSamples: RGBSamplesTemplate (RGBTypes.h:19-48) / WavelengthSamplesTemplate (SpectrumTypes.h:17-65)
+template <int N>
+struct Wls {
+    float lambdas[N];
+    uint16_t selectedLambda;
+    uint16_t flags;              // bit 0 = LambdaIsSelected
+};
+static const float kWavelengthLowBound = 360.0f, kWavelengthHighBound = 830.0f;   // BasicTypes/Spectrum.h:115-116
 
 // BasicTypes/CompensatedSum.h:15-32
 template <typename T>
@@ -488,12 +501,84 @@ bool testVisibility(const Scene& s, const SurfPt& shdP, const SurfPt& lightP, sl
 // Spectra / materials (RGB mode: InputSpectrum = RGBTemplate, evaluate() returns itself,
 // RGBTypes.h:124-126; ConstantSpectrumTexture constant_textures.h:16-31)
 // ------------------------------------------------------------------------------------------
-inline Spec<3> evalSpectrumRGB(const Scene& s, int32_t idx) {
-    Spec<3> r;
-    const slrhip_spectrum& sp = s.spectra[idx];
-    r.c[0] = sp.rgb[0]; r.c[1] = sp.rgb[1]; r.c[2] = sp.rgb[2];
-    return r;
-}
+template <int N> struct EvalSpectrum;
+
+template <> struct EvalSpectrum<3> {
+    static Spec<3> eval(const Scene& s, int32_t idx, const Wls<3>&) {
+        Spec<3> r;
+        const slrhip_spectrum& sp = s.spectra[idx];
+        r.c[0] = sp.rgb[0]; r.c[1] = sp.rgb[1]; r.c[2] = sp.rgb[2];
+        return r;
+    }
+};
+
+// Spectral mode: ConstantSpectrumTexture::evaluate -> ContinuousSpectrum::evaluate(wls)
+template <> struct EvalSpectrum<16> {
+    static Spec<16> eval(const Scene& s, int32_t idx, const Wls<16>& wls) {
+        const int N = 16;
+        const slrhip_spectrum& sp = s.spectra[idx];
+        const float* data = s.spectrumData.data() + sp.data_offset;
+        Spec<16> ret(0.0f);
+        switch (sp.kind) {
+        case SLRHIP_SPECTRUM_REGULAR: {
+            // RegularContinuousSpectrumTemplate::evaluate, SpectrumTypes.h:90-109
+            const float minLambda = sp.lambda_min, maxLambda = sp.lambda_max;
+            const uint32_t numSamples = sp.num_samples;
+            const float* values = data;
+            for (int i = 0; i < N; ++i) {
+                float binF = (wls.lambdas[i] - minLambda) / (maxLambda - minLambda) * (numSamples - 1);
+                if (binF <= 0.0f) { ret[i] = values[0]; continue; }
+                else if (binF >= numSamples - 1) { ret[i] = values[numSamples - 1]; continue; }
+                int32_t bin = int32_t(binF);
+                float t = binF - bin;
+                ret[i] = (1 - t) * values[bin] + t * values[bin + 1];
+            }
+            return ret;
+        }
+        case SLRHIP_SPECTRUM_IRREGULAR: {
+            // IrregularContinuousSpectrumTemplate::evaluate, SpectrumTypes.h:139-160
+            const uint32_t numSamples = sp.num_samples;
+            const float* lambdas = data;
+            const float* values = data + numSamples;
+            uint32_t searchBase = 0;
+            for (int i = 0; i < N; ++i) {
+                int32_t lowIdx = std::max((int32_t)std::distance(lambdas, std::lower_bound(lambdas + searchBase, lambdas + numSamples, wls.lambdas[i])) - 1, 0);
+                searchBase = lowIdx;
+                if (lowIdx >= (int32_t)numSamples - 1) { ret[i] = values[numSamples - 1]; continue; }
+                float t = (wls.lambdas[i] - lambdas[lowIdx]) / (lambdas[lowIdx + 1] - lambdas[lowIdx]);
+                if (t <= 0.0f) { ret[i] = values[0]; continue; }
+                ret[i] = (1 - t) * values[lowIdx] + t * values[lowIdx + 1];
+            }
+            return ret;
+        }
+        case SLRHIP_SPECTRUM_UPSAMPLED: {
+            // UpsampledContinuousSpectrumTemplate::evaluate, SpectrumTypes.h:239-339.  The cell lookup and the
+            // barycentric weights (:241-312) depend only on (u, v): resolved by the scene builder into
+            // `weights` + the 3 or 4 data-point spectra (slr_amd/spectra.py); the wavelength loop is here.
+            const uint32_t numPoints = sp.reserved;             // 0: outside the grid -> Zero (:241-242)
+            if (numPoints == 0) return Spec<16>(0.0f);
+            const uint32_t NumWavelengthSamples = sp.num_samples;    // 95
+            const float* weights = data;
+            const float* spectra = data + 4;
+            for (int i = 0; i < N; ++i) {
+                float lambda = wls.lambdas[i];
+                float p = (lambda - 360.0f) / (830.0f - 360.0f);
+                float sBinF = p * (NumWavelengthSamples - 1);
+                uint32_t sBin = (uint32_t)sBinF;
+                uint32_t sBinNext = (sBin + 1 < NumWavelengthSamples) ? (sBin + 1) : (NumWavelengthSamples - 1);
+                float t = sBinF - sBin;
+                for (uint32_t j = 0; j < numPoints; ++j) {
+                    const float* spectrum = spectra + (size_t)j * NumWavelengthSamples;
+                    ret[i] += weights[j] * (spectrum[sBin] * (1 - t) + spectrum[sBinNext] * t);
+                }
+            }
+            return ret * sp.scale;
+        }
+        default:
+            return Spec<16>(0.0f);
+        }
+    }
+};
 
 enum : uint32_t {   // Core/directional_distribution_functions.h:18-51
     DT_LowFreq = 1 << 0, DT_HighFreq = 1 << 1, DT_Delta0D = 1 << 2, DT_Delta1D = 1 << 3,
@@ -939,16 +1024,18 @@ float bsdfEvaluatePDF(const BSDF<N>& f, const BSDFQuery<N>& q, V3 dir) {
 // SurfacePoint::createBSDF (geometry.cpp:56-58) -> SurfaceMaterial::getBSDF
 // (basic_SurfaceMaterials.cpp:15-43; EmitterSurfaceMaterial forwards to its base material,
 //  surface_material.h:65).  `scale * spectrum` with scale = 1.0f is an exact multiply.
-BSDF<3> createBSDF(const Scene& s, const SurfPt& sp, uint16_t wlFlags) {
+template <int N>
+BSDF<N> createBSDF(const Scene& s, const SurfPt& sp, const Wls<N>& wls) {
+    const uint16_t wlFlags = wls.flags;
     const slrhip_material& m = s.materials[s.tris[sp.tri].material];
-    BSDF<3> f;
+    BSDF<N> f;
     f.kind = m.type;
     f.param = m.param;
     f.onA = f.onB = 0.0f;
     switch (m.type) {
     case SLRHIP_MATERIAL_MATTE:
         f.type = DT_Reflection | DT_LowFreq;                                   // basic_BSDFs.h:27, OrenNayerBRDF.h:29
-        f.a = 1.0f * evalSpectrumRGB(s, m.spectrum[0]);
+        f.a = 1.0f * EvalSpectrum<N>::eval(s, m.spectrum[0], wls);
         if (m.param >= 0.0f) {                                                 // OrenNayerBRDF.h:28-30 (double literals)
             float sigma = m.param;
             f.onA = (float)(1.0f - 0.5f * sigma * sigma / (sigma * sigma + 0.33));
@@ -957,26 +1044,26 @@ BSDF<3> createBSDF(const Scene& s, const SurfPt& sp, uint16_t wlFlags) {
         break;
     case SLRHIP_MATERIAL_MICROFACET_METAL:
         f.type = DT_Reflection | DT_HighFreq;                                  // MicrofacetBSDF.h:27-28
-        f.b = evalSpectrumRGB(s, m.spectrum[1]);
-        f.c = evalSpectrumRGB(s, m.spectrum[2]);
+        f.b = EvalSpectrum<N>::eval(s, m.spectrum[1], wls);
+        f.c = EvalSpectrum<N>::eval(s, m.spectrum[2], wls);
         break;
     case SLRHIP_MATERIAL_MICROFACET_GLASS:
         f.type = DT_Reflection | DT_Transmission | DT_HighFreq;                // MicrofacetBSDF.h:44-46
-        f.b = evalSpectrumRGB(s, m.spectrum[1]);
-        f.c = evalSpectrumRGB(s, m.spectrum[2]);
+        f.b = EvalSpectrum<N>::eval(s, m.spectrum[1], wls);
+        f.c = EvalSpectrum<N>::eval(s, m.spectrum[2], wls);
         break;
     case SLRHIP_MATERIAL_METAL:
         f.type = DT_Reflection | DT_Delta0D;                                   // basic_BSDFs.h:43
-        f.a = 1.0f * evalSpectrumRGB(s, m.spectrum[0]);
-        f.b = evalSpectrumRGB(s, m.spectrum[1]);
-        f.c = evalSpectrumRGB(s, m.spectrum[2]);
+        f.a = 1.0f * EvalSpectrum<N>::eval(s, m.spectrum[0], wls);
+        f.b = EvalSpectrum<N>::eval(s, m.spectrum[1], wls);
+        f.c = EvalSpectrum<N>::eval(s, m.spectrum[2], wls);
         break;
     case SLRHIP_MATERIAL_GLASS:
         // dispersive = !wls.lambdaSelected()  basic_SurfaceMaterials.cpp:42, basic_BSDFs.h:59-61
         f.type = DT_Reflection | DT_Transmission | DT_Delta0D | ((wlFlags & 1) ? 0u : (uint32_t)DT_Dispersive);
-        f.a = 1.0f * evalSpectrumRGB(s, m.spectrum[0]);
-        f.b = evalSpectrumRGB(s, m.spectrum[1]);
-        f.c = evalSpectrumRGB(s, m.spectrum[2]);
+        f.a = 1.0f * EvalSpectrum<N>::eval(s, m.spectrum[0], wls);
+        f.b = EvalSpectrum<N>::eval(s, m.spectrum[1], wls);
+        f.c = EvalSpectrum<N>::eval(s, m.spectrum[2], wls);
         break;
     default:
         f.type = 0;
@@ -986,9 +1073,11 @@ BSDF<3> createBSDF(const Scene& s, const SurfPt& sp, uint16_t wlFlags) {
 }
 
 inline bool isEmitting(const Scene& s, uint32_t tri) { return s.materials[s.tris[tri].material].emittance >= 0; }
-inline Spec<3> emittance(const Scene& s, uint32_t tri) { return evalSpectrumRGB(s, s.materials[s.tris[tri].material].emittance); }
+template <int N>
+inline Spec<N> emittance(const Scene& s, uint32_t tri, const Wls<N>& wls) { return EvalSpectrum<N>::eval(s, s.materials[s.tris[tri].material].emittance, wls); }
 // EDFs/basic_EDFs.cpp:19-23  DiffuseEDF::evaluate: `dir.z > 0 ? 1.0f / M_PI : 0.0f` (double) -> SampledSpectrum(float)
-inline Spec<3> diffuseEDFEvaluate(V3 dir) { return Spec<3>(dir.z > 0.0f ? (float)(1.0f / M_PI) : 0.0f); }
+template <int N>
+inline Spec<N> diffuseEDFEvaluate(V3 dir) { return Spec<N>(dir.z > 0.0f ? (float)(1.0f / M_PI) : 0.0f); }
 
 // ------------------------------------------------------------------------------------------
 // Cameras/PerspectiveCamera.cpp
@@ -1038,23 +1127,24 @@ inline float evaluateLightProb(const Scene& s, uint32_t tri) {
 // ------------------------------------------------------------------------------------------
 // Renderers/PathTracingRenderer.cpp:137-262  Job::contribution
 // ------------------------------------------------------------------------------------------
-Spec<3> contribution(const Scene& scene, uint16_t selectedLambda, uint16_t wlFlagsInit, const Ray& initRay, XorShift& rng,
-                     slr_oracle_counters* ctr) {
-    uint16_t wlFlags = wlFlagsInit;
+template <int N>
+Spec<N> contribution(const Scene& scene, const Wls<N>& initWLs, const Ray& initRay, XorShift& rng, slr_oracle_counters* ctr) {
+    Wls<N> wls = initWLs;
+    const uint16_t selectedLambda = wls.selectedLambda;
     Ray ray = initRay;
     SurfPt surfPt;
-    Spec<3> alpha(1.0f);
+    Spec<N> alpha(1.0f);
     float initY = importance(alpha, selectedLambda);
-    Kahan<Spec<3>> sp;
+    Kahan<Spec<N>> sp;
     uint32_t pathLength = 0;
 
     Isect isect;
-    if (!sceneIntersect(scene, ray, &isect, ctr)) return Spec<3>();
+    if (!sceneIntersect(scene, ray, &isect, ctr)) return Spec<N>();
     getSurfacePoint(scene, isect, &surfPt);
 
     V3 dirOut_sn = surfPt.frame.toLocal(-ray.dir);
     if (isEmitting(scene, surfPt.tri)) {
-        Spec<3> Le = emittance(scene, surfPt.tri) * diffuseEDFEvaluate(dirOut_sn);
+        Spec<N> Le = emittance(scene, surfPt.tri, wls) * diffuseEDFEvaluate<N>(dirOut_sn);
         sp.add(alpha * Le);
     }
     if (surfPt.atInfinity) return sp.result;
@@ -1064,8 +1154,8 @@ Spec<3> contribution(const Scene& scene, uint16_t selectedLambda, uint16_t wlFla
         if (pathLength >= 100) break;
         if (ctr) ++ctr->loop_iterations;
         V3 gNorm_sn = surfPt.frame.toLocal(surfPt.gNormal);
-        BSDF<3> bsdf = createBSDF(scene, surfPt, wlFlags);
-        BSDFQuery<3> fsQuery;
+        BSDF<N> bsdf = createBSDF(scene, surfPt, wls);
+        BSDFQuery<N> fsQuery;
         fsQuery.dir_sn = dirOut_sn; fsQuery.gNormal_sn = gNorm_sn; fsQuery.wlHint = (int16_t)selectedLambda; fsQuery.flags = DT_All;
 
         // Next Event Estimation  :169-204
@@ -1076,7 +1166,7 @@ Spec<3> contribution(const Scene& scene, uint16_t selectedLambda, uint16_t wlFla
             float lu1 = rng.getFloat0cTo1o();
             SurfPt lp; float areaPDF;
             triSample(scene, lightTri, lu0, lu1, &lp, &areaPDF);
-            Spec<3> M = emittance(scene, lightTri);                    // SingleSurfaceObject::sample :82-91
+            Spec<N> M = emittance(scene, lightTri, wls);                    // SingleSurfaceObject::sample :82-91
 
             if (testVisibility(scene, surfPt, lp, ctr)) {
                 // SurfacePoint::getDirectionFrom geometry.cpp:32-43
@@ -1086,10 +1176,10 @@ Spec<3> contribution(const Scene& scene, uint16_t selectedLambda, uint16_t wlFla
                 V3 shadowDir_l = lp.frame.toLocal(-shadowDir);
                 V3 shadowDir_sn = surfPt.frame.toLocal(shadowDir);
 
-                Spec<3> Le = M * diffuseEDFEvaluate(shadowDir_l);
+                Spec<N> Le = M * diffuseEDFEvaluate<N>(shadowDir_l);
                 float lightPDF = lightProb * areaPDF;
 
-                Spec<3> fs = bsdfEvaluate(bsdf, fsQuery, shadowDir_sn);
+                Spec<N> fs = bsdfEvaluate(bsdf, fsQuery, shadowDir_sn);
                 float cosLight = absDot(-shadowDir, lp.gNormal);
                 float bsdfPDF = bsdfEvaluatePDF(bsdf, fsQuery, shadowDir_sn) * cosLight / dist2;
 
@@ -1108,11 +1198,11 @@ Spec<3> contribution(const Scene& scene, uint16_t selectedLambda, uint16_t wlFla
         float uDir[2];
         uDir[0] = rng.getFloat0cTo1o();
         uDir[1] = rng.getFloat0cTo1o();
-        Spec<3> fs = bsdfSample(bsdf, fsQuery, uComp, uDir, &fsResult);
+        Spec<N> fs = bsdfSample(bsdf, fsQuery, uComp, uDir, &fsResult);
         if (fs.isZero() || fsResult.dirPDF == 0.0f) break;
         if (dtIsDispersive(fsResult.dirType)) {
-            fsResult.dirPDF /= 3;                   // WavelengthSamples::NumComponents (RGBTypes.h:47-48)
-            wlFlags |= 1;                           // LambdaIsSelected
+            fsResult.dirPDF /= N;                   // WavelengthSamples::NumComponents (RGBTypes.h:47-48 / SpectrumTypes.h:66-67)
+            wls.flags |= 1;                         // LambdaIsSelected
         }
         alpha = alpha * (fs * absDot(fsResult.dir_sn, gNorm_sn) / fsResult.dirPDF);
 
@@ -1128,7 +1218,7 @@ Spec<3> contribution(const Scene& scene, uint16_t selectedLambda, uint16_t wlFla
         // implicit light sampling :232-249
         if (isEmitting(scene, surfPt.tri)) {
             float bsdfPDF = fsResult.dirPDF;
-            Spec<3> Le = emittance(scene, surfPt.tri) * diffuseEDFEvaluate(dirOut_sn);
+            Spec<N> Le = emittance(scene, surfPt.tri, wls) * diffuseEDFEvaluate<N>(dirOut_sn);
             float lightProb = evaluateLightProb(scene, surfPt.tri);
             float dist2 = sqLength(ray.org - surfPt.p);                    // sqDistance(p, shadingPoint)
             float lightPDF = lightProb * (1.0f / triArea(scene, surfPt.tri)) * dist2 / absDot(ray.dir, surfPt.gNormal);
@@ -1151,8 +1241,9 @@ Spec<3> contribution(const Scene& scene, uint16_t selectedLambda, uint16_t wlFla
 // Renderers/PathTracingRenderer.cpp:100-135  Job::kernel body for ONE pixel sample.
 // Draw order is left to right (the pinned clang build).
 // ------------------------------------------------------------------------------------------
+template <int N>
 void pixelSample(const Scene& scene, const slrhip_render_settings& st, uint32_t basePixelX, uint32_t basePixelY, XorShift& rng,
-                 slr_oracle_counters* ctr, float* px, float* py, Spec<3>* out) {
+                 slr_oracle_counters* ctr, float* px, float* py, Spec<N>* out, Wls<N>* outWls) {
     const Camera& cam = scene.camera;
     float v = rng.getFloat0cTo1o();
     float time = st.time_start * (1 - v) + st.time_end * v;                 // light_path_samplers.h:50
@@ -1160,11 +1251,16 @@ void pixelSample(const Scene& scene, const slrhip_render_settings& st, uint32_t 
     float pxx = basePixelX + rng.getFloat0cTo1o();                          // :51 (uint32 + float)
     float pyy = basePixelY + rng.getFloat0cTo1o();
 
-    // RGBSamplesTemplate::createWithEqualOffsets RGBTypes.h:37-45 (two draws, offset unused)
-    float wlOffset = rng.getFloat0cTo1o(); (void)wlOffset;
+    // createWithEqualOffsets: RGBTypes.h:37-45 (offset unused, PDF 1) / SpectrumTypes.h:54-64
+    float wlOffset = rng.getFloat0cTo1o();
     float uLambda = rng.getFloat0cTo1o();
-    uint16_t selectedLambda = std::min(uint16_t(3 * uLambda), uint16_t(2));
-    float selectWLPDF = 1;
+    Wls<N> wls;
+    float selectWLPDF;
+    for (int i = 0; i < N; ++i)
+        wls.lambdas[i] = kWavelengthLowBound + (kWavelengthHighBound - kWavelengthLowBound) * (i + wlOffset) / N;
+    wls.selectedLambda = std::min(uint16_t(N * uLambda), uint16_t(N - 1));
+    wls.flags = 0;
+    selectWLPDF = N == 3 ? 1.0f : N / (kWavelengthHighBound - kWavelengthLowBound);
 
     // camera->sample PerspectiveCamera.cpp:33-57
     float lu0 = rng.getFloat0cTo1o();
@@ -1193,13 +1289,28 @@ void pixelSample(const Scene& scene, const slrhip_render_settings& st, uint32_t 
     ray.dir = lensFrame.fromLocal(dirLocal);
     ray.distMin = 0.0f;
     ray.distMax = INFINITY;
-    Spec<3> C = contribution(scene, selectedLambda, 0, ray, rng, ctr);
+    Spec<N> C = contribution<N>(scene, wls, ray, rng, ctr);
 
     // :126  weight = (We0 * We1) * (absDot(ray.dir, gNormal) / (areaPDF * dirPDF * selectWLPDF))
-    Spec<3> weight = (Spec<3>(1.0f) * Spec<3>(1.0f)) * (absDot(ray.dir, lensN) / (areaPDF * dirPDF * selectWLPDF));
+    Spec<N> weight = (Spec<N>(1.0f) * Spec<N>(1.0f)) * (absDot(ray.dir, lensN) / (areaPDF * dirPDF * selectWLPDF));
     *out = weight * C;
+    *outWls = wls;
     *px = pxx;
     *py = pyy;
+}
+
+// SpectrumStorage::add.  RGB: value += val (RGBTypes.h:176-179).  Spectral: each sample goes to the storage bin of
+// its wavelength, scaled by the reciprocal bin width, and the 16-bin addend is Kahan-added (SpectrumTypes.h:818-836).
+inline void storageAdd(Kahan<Spec<3>>& px, const Wls<3>&, const Spec<3>& val) { px.add(val); }
+inline void storageAdd(Kahan<Spec<16>>& px, const Wls<16>& wls, const Spec<16>& val) {
+    const uint32_t numStrata = 16;
+    const float recBinWidth = numStrata / (kWavelengthHighBound - kWavelengthLowBound);
+    Spec<16> addend(0.0f);
+    for (int i = 0; i < 16; ++i) {
+        uint32_t sBin = std::min(uint32_t((wls.lambdas[i] - kWavelengthLowBound) / (kWavelengthHighBound - kWavelengthLowBound) * numStrata), numStrata - 1);
+        addend[sBin] += val[i] * recBinWidth;
+    }
+    px.add(addend);
 }
 
 int32_t sampleSeed(int32_t rngSeed, uint32_t px, uint32_t py, uint32_t pass) {
@@ -1223,7 +1334,8 @@ extern "C" {
 
 slr_oracle_scene* slr_oracle_create(const slrhip_scene_desc* d, int mode) {
     if (!d || !d->vertices || !d->triangles || !d->materials || d->num_triangles == 0) return nullptr;
-    if (mode != SLRHIP_MODE_RGB) return nullptr;   // spectral restatement: later row
+    if (mode != SLRHIP_MODE_RGB && mode != SLRHIP_MODE_SPECTRAL) return nullptr;
+    if (mode == SLRHIP_MODE_SPECTRAL && !d->spectrum_data) return nullptr;
     Scene* s = new Scene();
     s->mode = mode;
     s->vertices.assign(d->vertices, d->vertices + d->num_vertices);
@@ -1254,9 +1366,13 @@ void slr_oracle_destroy(slr_oracle_scene* s) { delete s; }
 
 int slr_oracle_components(const slr_oracle_scene* s) { return s->mode == SLRHIP_MODE_RGB ? 3 : 16; }
 
-int slr_oracle_render(slr_oracle_scene* s, const slrhip_render_settings* st, slrhip_shard shard, uint32_t sppBegin, uint32_t sppCount,
-                      int threads, float* fbSum, float* fbComp, slr_oracle_counters* counters) {
-    if (!s || !st || !fbSum || !fbComp || shard.shard_count == 0) return 1;
+}  // extern "C"
+
+namespace {
+
+template <int N>
+int renderT(slr_oracle_scene* s, const slrhip_render_settings* st, slrhip_shard shard, uint32_t sppBegin, uint32_t sppCount,
+            int threads, float* fbSum, float* fbComp, slr_oracle_counters* counters) {
     const uint32_t W = (uint32_t)st->image_width, H = (uint32_t)st->image_height;
     const uint32_t tilesX = (W + 7) >> 3;                    // ImageSensor.cpp:43-44
     if (threads <= 0) threads = (int)std::thread::hardware_concurrency();
@@ -1272,17 +1388,17 @@ int slr_oracle_render(slr_oracle_scene* s, const slrhip_render_settings* st, slr
             for (uint32_t x = 0; x < W; ++x) {
                 uint32_t tile = (y >> 3) * tilesX + (x >> 3);
                 if (tile % shard.shard_count != shard.shard_index) continue;
-                size_t o = ((size_t)y * W + x) * 3;
-                Kahan<Spec<3>> acc;
-                for (int k = 0; k < 3; ++k) { acc.result[k] = fbSum[o + k]; acc.comp[k] = fbComp[o + k]; }
+                size_t o = ((size_t)y * W + x) * N;
+                Kahan<Spec<N>> acc;
+                for (int k = 0; k < N; ++k) { acc.result[k] = fbSum[o + k]; acc.comp[k] = fbComp[o + k]; }
                 for (uint32_t p = sppBegin; p < sppBegin + sppCount; ++p) {
                     XorShift rng(sampleSeed(st->rng_seed, x, y, p), &c.rng_draws);
-                    float px, py; Spec<3> contrib;
-                    pixelSample(*s, *st, x, y, rng, &c, &px, &py, &contrib);
-                    acc.add(contrib);                                    // RGBStorage::add RGBTypes.h:176-179
+                    float px, py; Spec<N> contrib; Wls<N> wls;
+                    pixelSample<N>(*s, *st, x, y, rng, &c, &px, &py, &contrib, &wls);
+                    storageAdd(acc, wls, contrib);
                     ++c.samples;
                 }
-                for (int k = 0; k < 3; ++k) { fbSum[o + k] = acc.result[k]; fbComp[o + k] = acc.comp[k]; }
+                for (int k = 0; k < N; ++k) { fbSum[o + k] = acc.result[k]; fbComp[o + k] = acc.comp[k]; }
             }
         }
     };
@@ -1294,13 +1410,79 @@ int slr_oracle_render(slr_oracle_scene* s, const slrhip_render_settings* st, slr
     return 0;
 }
 
+// out[0..N) = what ImageSensor::add would add to the pixel (spectral: the binned, scaled addend), then p.x, p.y
+template <int N>
+int sampleT(slr_oracle_scene* s, const slrhip_render_settings* st, uint32_t px, uint32_t py, uint32_t pass, float* out) {
+    XorShift rng(sampleSeed(st->rng_seed, px, py, pass));
+    float fx, fy; Spec<N> contrib; Wls<N> wls;
+    pixelSample<N>(*s, *st, px, py, rng, nullptr, &fx, &fy, &contrib, &wls);
+    Kahan<Spec<N>> acc;
+    storageAdd(acc, wls, contrib);
+    for (int k = 0; k < N; ++k) out[k] = acc.result[k];
+    out[N] = fx; out[N + 1] = fy;
+    return 0;
+}
+
+// PathTracingRenderer.cpp:27-98 with numThreads == 1: topRand(seed); sampler(topRand.getUInt());
+// passes outermost, tiles row-major (:74-79), pixels row-major inside a tile (:103-104).
+template <int N>
+int renderSerialT(slr_oracle_scene* s, const slrhip_render_settings* st, uint32_t spp, float* fbSum, slr_oracle_counters* counters) {
+    const uint32_t W = (uint32_t)st->image_width, H = (uint32_t)st->image_height;
+    const uint32_t tilesX = (W + 7) >> 3, tilesY = (H + 7) >> 3;
+    XorShift topRand(st->rng_seed);
+    slr_oracle_counters c;
+    std::memset(&c, 0, sizeof(c));
+    XorShift rng((int32_t)topRand.getUInt(), &c.rng_draws);
+    std::vector<Kahan<Spec<N>>> fb((size_t)W * H);
+    for (uint32_t p = 0; p < spp; ++p)
+        for (uint32_t ty = 0; ty < tilesY; ++ty)
+            for (uint32_t tx = 0; tx < tilesX; ++tx)
+                for (uint32_t ly = 0; ly < 8; ++ly)
+                    for (uint32_t lx = 0; lx < 8; ++lx) {
+                        float px, py; Spec<N> contrib; Wls<N> wls;
+                        pixelSample<N>(*s, *st, tx * 8 + lx, ty * 8 + ly, rng, &c, &px, &py, &contrib, &wls);
+                        // ImageSensor::add ImageSensor.cpp:124-129
+                        uint32_t ipx = std::min((uint32_t)px, W - 1), ipy = std::min((uint32_t)py, H - 1);
+                        storageAdd(fb[(size_t)ipy * W + ipx], wls, contrib);
+                        ++c.samples;
+                    }
+    for (size_t i = 0; i < fb.size(); ++i) for (int k = 0; k < N; ++k) fbSum[i * N + k] = fb[i].result[k];
+    if (counters) addCounters(counters, c);
+    return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+int slr_oracle_render(slr_oracle_scene* s, const slrhip_render_settings* st, slrhip_shard shard, uint32_t sppBegin, uint32_t sppCount,
+                      int threads, float* fbSum, float* fbComp, slr_oracle_counters* counters) {
+    if (!s || !st || !fbSum || !fbComp || shard.shard_count == 0) return 1;
+    return s->mode == SLRHIP_MODE_RGB ? renderT<3>(s, st, shard, sppBegin, sppCount, threads, fbSum, fbComp, counters)
+                                      : renderT<16>(s, st, shard, sppBegin, sppCount, threads, fbSum, fbComp, counters);
+}
+
 int slr_oracle_sample(slr_oracle_scene* s, const slrhip_render_settings* st, uint32_t px, uint32_t py, uint32_t pass, float* out) {
     if (!s || !st || !out) return 1;
-    XorShift rng(sampleSeed(st->rng_seed, px, py, pass));
-    float fx, fy; Spec<3> contrib;
-    pixelSample(*s, *st, px, py, rng, nullptr, &fx, &fy, &contrib);
-    for (int k = 0; k < 3; ++k) out[k] = contrib[k];
-    out[3] = fx; out[4] = fy;
+    return s->mode == SLRHIP_MODE_RGB ? sampleT<3>(s, st, px, py, pass, out) : sampleT<16>(s, st, px, py, pass, out);
+}
+
+int slr_oracle_render_serial(slr_oracle_scene* s, const slrhip_render_settings* st, uint32_t spp, float* fbSum,
+                             slr_oracle_counters* counters) {
+    if (!s || !st || !fbSum) return 1;
+    return s->mode == SLRHIP_MODE_RGB ? renderSerialT<3>(s, st, spp, fbSum, counters) : renderSerialT<16>(s, st, spp, fbSum, counters);
+}
+
+int slr_oracle_eval_spectrum(const slrhip_scene_desc* d, uint32_t index, float offset, float* out) {
+    if (!d || !out || index >= d->num_spectra) return 1;
+    Scene tmp;
+    tmp.spectra.assign(d->spectra, d->spectra + d->num_spectra);
+    if (d->spectrum_data) tmp.spectrumData.assign(d->spectrum_data, d->spectrum_data + d->num_spectrum_data);
+    Wls<16> wls;
+    for (int i = 0; i < 16; ++i) wls.lambdas[i] = kWavelengthLowBound + (kWavelengthHighBound - kWavelengthLowBound) * (i + offset) / 16;
+    wls.selectedLambda = 0; wls.flags = 0;
+    Spec<16> v = EvalSpectrum<16>::eval(tmp, (int32_t)index, wls);
+    for (int k = 0; k < 16; ++k) out[k] = v[k];
     return 0;
 }
 
@@ -1327,35 +1509,6 @@ void slr_oracle_rng(int32_t seed, uint32_t n, uint32_t* uints, float* floats) {
     for (uint32_t i = 0; i < n; ++i) uints[i] = a.getUInt();
     XorShift b(seed);
     for (uint32_t i = 0; i < n; ++i) floats[i] = b.getFloat0cTo1o();
-}
-
-// PathTracingRenderer.cpp:27-98 with numThreads == 1: topRand(seed); sampler(topRand.getUInt());
-// passes outermost, tiles row-major (:74-79), pixels row-major inside a tile (:103-104).
-int slr_oracle_render_serial(slr_oracle_scene* s, const slrhip_render_settings* st, uint32_t spp, float* fbSum,
-                             slr_oracle_counters* counters) {
-    if (!s || !st || !fbSum) return 1;
-    const uint32_t W = (uint32_t)st->image_width, H = (uint32_t)st->image_height;
-    const uint32_t tilesX = (W + 7) >> 3, tilesY = (H + 7) >> 3;
-    XorShift topRand(st->rng_seed);
-    slr_oracle_counters c;
-    std::memset(&c, 0, sizeof(c));
-    XorShift rng((int32_t)topRand.getUInt(), &c.rng_draws);
-    std::vector<Kahan<Spec<3>>> fb((size_t)W * H);
-    for (uint32_t p = 0; p < spp; ++p)
-        for (uint32_t ty = 0; ty < tilesY; ++ty)
-            for (uint32_t tx = 0; tx < tilesX; ++tx)
-                for (uint32_t ly = 0; ly < 8; ++ly)
-                    for (uint32_t lx = 0; lx < 8; ++lx) {
-                        float px, py; Spec<3> contrib;
-                        pixelSample(*s, *st, tx * 8 + lx, ty * 8 + ly, rng, &c, &px, &py, &contrib);
-                        // ImageSensor::add ImageSensor.cpp:124-129
-                        uint32_t ipx = std::min((uint32_t)px, W - 1), ipy = std::min((uint32_t)py, H - 1);
-                        fb[(size_t)ipy * W + ipx].add(contrib);
-                        ++c.samples;
-                    }
-    for (size_t i = 0; i < fb.size(); ++i) for (int k = 0; k < 3; ++k) fbSum[i * 3 + k] = fb[i].result[k];
-    if (counters) addCounters(counters, c);
-    return 0;
 }
 
 } // extern "C"

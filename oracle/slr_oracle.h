@@ -87,6 +87,24 @@ int slr_ref_render_native(slr_oracle_scene* s, const slrhip_render_settings* set
  * ImageSensor constructor argument.  Reference build only; pins the product's slrhip_tonemap_bgr8.     */
 int slr_ref_save_image(const float* fb, uint32_t width, uint32_t height, float sensitivity, float scale, const char* path);
 
+/* Published numeric tables the spectral path needs and that only exist inside the reference tree:
+ * the Meng-15 upsampling grid (Spectrum.h:199-575: cells + data points), the CIE 1931 2-degree CMFs
+ * (xbar/ybar/zbar_2deg, 471 samples), D65 (common_spectra.cpp:185) and the IOR tables of
+ * spectrum_library.cpp.  tools/extract_spectral_tables.py dumps them once into slr_amd/data/ as data.
+ * what: 0 grid cells (GridWidth*GridHeight x 8 bytes), 1 data points (n x (2+2+95) floats), 2 CMFs (3 x 471),
+ * 3 D65 (531), 4+i: IOR table i as [numSamples, min, max, regular?, lambdas..., etas..., ks...].
+ * Returns the number of floats/bytes written (or needed when dst is NULL), -1 for an unknown table.  */
+long slr_ref_dump_table(int what, const char* name, void* dst, long capacity);
+
+/* SampledSpectrum evaluation of one scene spectrum at the wavelengths of createWithEqualOffsets(offset, .)
+ * (ConstantSpectrumTexture::evaluate -> InputSpectrum::evaluate).  out: 16 floats.  Spectral builds.    */
+int slr_ref_eval_spectrum(const slrhip_scene_desc* scene, uint32_t spectrum_index, float offset, float* out);
+int slr_oracle_eval_spectrum(const slrhip_scene_desc* scene, uint32_t spectrum_index, float offset, float* out);
+
+/* UpsampledContinuousSpectrum(spType, space, e0, e1, e2) constructor (SpectrumTypes.h:180-237): out = u, v, scale.
+ * sp_type: 0 Reflectance, 1 Illuminant, 2 IndexOfRefraction; space: 0 sRGB, 1 sRGB_NonLinear, 2 xyY, 3 XYZ.   */
+int slr_ref_upsample(int sp_type, int space, float e0, float e1, float e2, float* uvs);
+
 #ifdef __cplusplus
 }
 #endif

@@ -11,7 +11,7 @@ import math
 
 import numpy as np
 
-from . import abi
+from . import abi, spectra
 
 
 def _translate(x, y, z):
@@ -53,26 +53,33 @@ def make_camera(local_to_world, aspect, fov_y, lens_radius, img_dist, obj_dist, 
 
 class SceneBuilder:
     def __init__(self):
-        self.vertices, self.triangles, self.materials, self.spectra, self.spectrum_data = [], [], [], [], []
+        self.vertices, self.triangles, self.materials = [], [], []
+        self.sset = spectra.SpectrumSet()     # every constant carries its RGB value and its spectral descriptor
 
-    # --- spectra --------------------------------------------------------------------
+    # --- spectra (the scene language's Spectrum(...) overloads, libSLRSceneGraph/API.cpp:286-441) -------
     def spectrum_rgb(self, r, g, b, uvs=None):
-        """RGB-mode value (+ optional spectral descriptor filled in by slr_amd.spectra)."""
+        """RGB-mode-only constant (no spectral descriptor: spectral contexts reject it)."""
         rec = np.zeros((), dtype=abi.spectrum_dtype)
         rec["kind"] = abi.SPEC_RGB_ONLY
         rec["rgb"] = (r, g, b)
-        self.spectra.append(rec)
-        return len(self.spectra) - 1
+        return self.sset._append(rec, [])
 
     def spectrum_srgb_nonlinear(self, r, g, b):
-        """Spectrum(r, g, b) of the scene language: non-linear sRGB reflectance
-        (libSLRSceneGraph/API.cpp:62-63,295-296 -> sRGB_degamma, Spectrum.cpp:24-30)."""
-        def degamma(v):
-            v = np.float32(v)
-            if v <= 0.04045:
-                return np.float32(np.float64(v) / 12.92)
-            return np.float32(math.pow((np.float64(v) + 0.055) / 1.055, 2.4))
-        return self.spectrum_rgb(degamma(r), degamma(g), degamma(b))
+        """Spectrum(r, g, b): Reflectance in non-linear sRGB (API.cpp:62-63,295-296).  RGB mode: sRGB_degamma
+        (API.cpp:1286-1291); spectral mode: UpsampledContinuousSpectrum (API.cpp:1139-1141)."""
+        return self.sset.reflectance_srgb(r, g, b)
+
+    def spectrum_grey(self, v):
+        """Spectrum("Reflectance", v): linear grey (API.cpp:327)."""
+        return self.sset.reflectance_grey(v)
+
+    def spectrum_d65(self, scale, rgb):
+        """Spectrum("ID": "D65") * scale (API.cpp:405-406,443-462); `rgb` is its RGB-mode value."""
+        return self.sset.d65(scale, rgb)
+
+    def spectrum_ior(self, name, which, rgb):
+        """Spectrum("ID": name, which): eta (0) or k (1) of spectrum_library.cpp; `rgb` is its RGB-mode value."""
+        return self.sset.ior(name, which, rgb)
 
     # --- materials -----------------------------------------------------------------
     def material(self, mtype, spectra=(-1, -1, -1), param=-1.0, emittance=-1):
@@ -161,15 +168,15 @@ class SceneBuilder:
         return abi.Scene(np.array(self.vertices, dtype=abi.vertex_dtype),
                          np.array(self.triangles, dtype=abi.triangle_dtype),
                          np.array(self.materials, dtype=abi.material_dtype),
-                         np.array(self.spectra, dtype=abi.spectrum_dtype),
-                         np.array(self.spectrum_data, dtype=np.float32), camera, env, name)
+                         np.array(self.sset.records, dtype=abi.spectrum_dtype),
+                         np.array(self.sset.data, dtype=np.float32), camera, env, name)
 
 
 # RGB-mode constants of the scene's named spectra.  In the reference these come from
 # Spectrum::create's RGB branch (libSLRSceneGraph/API.cpp:1326-1347: integrate the table
 # against the CMFs, XYZ -> sRGB, clamp).  Values below are fixed scene INPUTS of the
 # synthetic scene (the same numbers go to oracle, reference and GPU).
-D65_TIMES_4_RGB = (400.0, 400.0, 400.0)
+D65_RGB = (100.0, 100.0, 100.0)        # x 4 = (400, 400, 400) for the Cornell light
 ALUMINIUM_ETA_RGB = (1.657, 0.880, 0.521)
 ALUMINIUM_K_RGB = (9.224, 6.270, 4.837)
 AIR_ETA_RGB = (1.000277, 1.000277, 1.000277)
@@ -186,7 +193,7 @@ def cornell_walls(b):
     b.add_quad([(-1.5, 0, 2.55), (1.5, 0, 2.55), (1.5, 0, -2.55), (-1.5, 0, -2.55)], (0, 1, 0), (1, 0, 0), white)
     b.add_quad([(-1.5, 0, -2.55), (1.5, 0, -2.55), (1.5, 2.5, -2.55), (-1.5, 2.5, -2.55)], (0, 0, 1), (1, 0, 0), white)
     b.add_quad([(-1.5, 2.5, -2.55), (1.5, 2.5, -2.55), (1.5, 2.5, 2.55), (-1.5, 2.5, 2.55)], (0, -1, 0), (1, 0, 0), white)
-    light = b.matte(b.spectrum_srgb_nonlinear(0.9, 0.9, 0.9), emittance=b.spectrum_rgb(*D65_TIMES_4_RGB))
+    light = b.matte(b.spectrum_srgb_nonlinear(0.9, 0.9, 0.9), emittance=b.spectrum_d65(4.0, D65_RGB))
     b.add_quad([(-0.5, 2.499, -0.5), (0.5, 2.499, -0.5), (0.5, 2.499, 0.5), (-0.5, 2.499, 0.5)], (0, -1, 0), (1, 0, 0), light)
 
 
@@ -201,11 +208,11 @@ def cornell_box_spheres(aspect=4.0 / 3.0, segments=48, rings=24, right="glass"):
     (BK7 glass as in Cornell_Box_Spheres.txt:120-130, or Lambert for 'Lambert+specular only')."""
     b = SceneBuilder()
     cornell_walls(b)
-    one = b.spectrum_rgb(1.0, 1.0, 1.0)  # Spectrum("Reflectance", 1.0): linear grey, API.cpp:327
-    left = b.metal(one, b.spectrum_rgb(*ALUMINIUM_ETA_RGB), b.spectrum_rgb(*ALUMINIUM_K_RGB))
+    one = b.spectrum_grey(1.0)           # Spectrum("Reflectance", 1.0): linear grey, API.cpp:327
+    left = b.metal(one, b.spectrum_ior("Aluminium", 0, ALUMINIUM_ETA_RGB), b.spectrum_ior("Aluminium", 1, ALUMINIUM_K_RGB))
     b.add_uv_sphere(segments, rings, left, _translate(-0.7, 0, -1.05) @ _scale(0.5) @ _translate(0, 1, 0))
     if right == "glass":
-        mat = b.glass(b.spectrum_rgb(0.999, 0.999, 0.999), b.spectrum_rgb(*AIR_ETA_RGB), b.spectrum_rgb(*BK7_ETA_RGB))
+        mat = b.glass(b.spectrum_grey(0.999), b.spectrum_ior("Air", 0, AIR_ETA_RGB), b.spectrum_ior("Glass_BK7", 0, BK7_ETA_RGB))
     else:
         mat = b.matte(b.spectrum_srgb_nonlinear(0.75, 0.75, 0.25))
     b.add_uv_sphere(segments, rings, mat, _translate(0.7, 0, 0) @ _scale(0.5) @ _translate(0, 1, 0))
@@ -231,9 +238,9 @@ def cornell_lobes(kind, aspect=1.0, segments=16, rings=8):
     if kind == "oren_nayar":
         m = b.matte(b.spectrum_srgb_nonlinear(0.7, 0.6, 0.3), sigma=0.6)
     elif kind == "ggx_metal":
-        m = b.microfacet_metal(b.spectrum_rgb(*TITANIUM_ETA_RGB), b.spectrum_rgb(*TITANIUM_K_RGB), 0.1)
+        m = b.microfacet_metal(b.spectrum_ior("Titanium", 0, TITANIUM_ETA_RGB), b.spectrum_ior("Titanium", 1, TITANIUM_K_RGB), 0.1)
     elif kind == "ggx_glass":
-        m = b.microfacet_glass(b.spectrum_rgb(*AIR_ETA_RGB), b.spectrum_rgb(*BK7_ETA_RGB), 0.2)
+        m = b.microfacet_glass(b.spectrum_ior("Air", 0, AIR_ETA_RGB), b.spectrum_ior("Glass_BK7", 0, BK7_ETA_RGB), 0.2)
     else:
         raise ValueError(kind)
     b.add_uv_sphere(segments, rings, m, _translate(-0.3, 0, -0.5) @ _scale(0.6) @ _translate(0, 1, 0))
@@ -246,7 +253,7 @@ def cornell_box_boxes(aspect=1.0):
     (alpha_g = 0.1) and a matte one."""
     b = SceneBuilder()
     cornell_walls(b)
-    ti = b.microfacet_metal(b.spectrum_rgb(*TITANIUM_ETA_RGB), b.spectrum_rgb(*TITANIUM_K_RGB), 0.1)
+    ti = b.microfacet_metal(b.spectrum_ior("Titanium", 0, TITANIUM_ETA_RGB), b.spectrum_ior("Titanium", 1, TITANIUM_K_RGB), 0.1)
     white = b.matte(b.spectrum_srgb_nonlinear(0.75, 0.75, 0.75))
     tall = _translate(-0.5, 0.0, -1.0) @ _rotate(0.3, (0, 1, 0)) @ _translate(0, 0.8, 0) @ np.diag([0.8, 1.6, 0.8, 1.0])
     short = _translate(0.55, 0.0, 0.2) @ _rotate(-0.35, (0, 1, 0)) @ _translate(0, 0.4, 0) @ np.diag([0.8, 0.8, 0.8, 1.0])
