@@ -128,6 +128,10 @@ class Context:
         _check(self.lib, self.lib.slrhip_trace_rays(self.handle, rays.ctypes.data, n, hits.ctypes.data), "slrhip_trace_rays")
         return hits[:, 0].copy().view(np.uint32), hits[:, 1], hits[:, 2], hits[:, 3]
 
+    @property
+    def mode(self):
+        return abi.MODE_SPECTRAL if self.components == 16 else abi.MODE_RGB
+
     def render_image(self, scene, settings, spp, shard=(0, 1)):
         """Convenience: upload, render all passes, read back the linear float framebuffer."""
         self.upload_scene(scene)

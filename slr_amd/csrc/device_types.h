@@ -75,6 +75,24 @@ struct alignas(16) DevMaterial {
 };
 static_assert(sizeof(DevMaterial) == 80, "DevMaterial layout");
 
+// Spectral mode: a material names its constant spectra; they are evaluated at the path's wavelengths per hit
+// (ConstantSpectrumTexture::evaluate, Textures/constant_textures.h:16-31), like the reference does.
+struct alignas(16) DevMaterialS {
+    uint32_t type;
+    float param, onA, onB;
+    int32_t spec[4];        // a, b, c, emittance: indices into the spectrum table, -1 = unused
+};
+static_assert(sizeof(DevMaterialS) == 32, "DevMaterialS layout");
+
+struct alignas(16) DevSpectrum {
+    uint32_t kind;          // SLRHIP_SPECTRUM_*
+    uint32_t numPoints;     // UPSAMPLED: 3 or 4 data points (0 = outside the grid)
+    uint32_t numSamples;
+    uint32_t dataOffset;    // into the float pool
+    float scale, lambdaMin, lambdaMax, pad;
+};
+static_assert(sizeof(DevSpectrum) == 32, "DevSpectrum layout");
+
 // PerspectiveCamera constants (PerspectiveCamera.cpp:15-24) computed on the host with the same
 // libm the reference uses, so the device never evaluates tan/pow.
 struct DevCamera {

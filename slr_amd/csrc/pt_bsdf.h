@@ -8,21 +8,104 @@
 
 namespace slrhip {
 
+template <class S>
 struct Mat {
     uint32_t type;
     float param;
     float onA, onB;
-    RGB a, b, c, emittance;
+    S a, b, c;
 };
 
-SLR_DEV Mat loadMat(const DevMaterial* m) {
+// RGB mode: the material record holds the evaluated constants (RGBTemplate::evaluate returns itself, RGBTypes.h:124-126)
+SLR_DEV Mat<RGB> loadMat(const DevMaterial* m) {
     const float4* q = reinterpret_cast<const float4*>(m);
-    const float4 h = q[0], a = q[1], b = q[2], c = q[3], e = q[4];
-    Mat r;
+    const float4 h = q[0], a = q[1], b = q[2], c = q[3];
+    Mat<RGB> r;
     r.type = __float_as_uint(h.x);
     r.param = h.y;
     r.onA = h.z; r.onB = h.w;
-    r.a = RGB(a.x, a.y, a.z); r.b = RGB(b.x, b.y, b.z); r.c = RGB(c.x, c.y, c.z); r.emittance = RGB(e.x, e.y, e.z);
+    r.a = RGB(a.x, a.y, a.z); r.b = RGB(b.x, b.y, b.z); r.c = RGB(c.x, c.y, c.z);
+    return r;
+}
+SLR_DEV RGB loadEmittance(const DevMaterial* m) {
+    const float4 e = reinterpret_cast<const float4*>(m)[4];
+    return RGB(e.x, e.y, e.z);
+}
+
+// ---- spectral mode: ContinuousSpectrum::evaluate at the path's 16 wavelengths (per hit, like the reference) ------------
+// lambda_i of WavelengthSamples::createWithEqualOffsets, SpectrumTypes.h:54-64
+SLR_DEV float wavelengthOf(int i, float offset) { return 360.0f + (830.0f - 360.0f) * ((float)i + offset) / 16.0f; }
+
+SLR_DEV Spec16 evalSpectrum(const DevSpectrum* spectra, const float* __restrict__ pool, int32_t idx, float wlOffset) {
+    const DevSpectrum sp = spectra[idx];
+    const float* data = pool + sp.dataOffset;
+    switch (sp.kind) {
+    case SLRHIP_SPECTRUM_REGULAR: {
+        // RegularContinuousSpectrumTemplate::evaluate, SpectrumTypes.h:90-109
+        const uint32_t numSamples = sp.numSamples;
+        return Spec16::make([&](int i) {
+            float binF = (wavelengthOf(i, wlOffset) - sp.lambdaMin) / (sp.lambdaMax - sp.lambdaMin) * (float)(numSamples - 1);
+            if (binF <= 0.0f) return data[0];
+            if (binF >= (float)(numSamples - 1)) return data[numSamples - 1];
+            int32_t bin = (int32_t)binF;
+            float t = binF - (float)bin;
+            return (1 - t) * data[bin] + t * data[bin + 1];
+        });
+    }
+    case SLRHIP_SPECTRUM_IRREGULAR: {
+        // IrregularContinuousSpectrumTemplate::evaluate, SpectrumTypes.h:139-160.  std::lower_bound restricted to
+        // [searchBase, n) equals the unrestricted one because the wavelengths ascend, so each component searches alone.
+        const int32_t n = (int32_t)sp.numSamples;
+        const float* lambdas = data;
+        const float* values = data + n;
+        return Spec16::make([&](int i) {
+            const float wl = wavelengthOf(i, wlOffset);
+            int32_t lo = 0, hi = n;                       // first index with lambdas[idx] >= wl
+            while (lo < hi) { int32_t mid = (lo + hi) >> 1; if (lambdas[mid] < wl) lo = mid + 1; else hi = mid; }
+            int32_t lowIdx = max(lo - 1, 0);
+            if (lowIdx >= n - 1) return values[n - 1];
+            float t = (wl - lambdas[lowIdx]) / (lambdas[lowIdx + 1] - lambdas[lowIdx]);
+            if (t <= 0.0f) return values[0];
+            return (1 - t) * values[lowIdx] + t * values[lowIdx + 1];
+        });
+    }
+    case SLRHIP_SPECTRUM_UPSAMPLED: {
+        // UpsampledContinuousSpectrumTemplate::evaluate, SpectrumTypes.h:314-338: the wavelength loop; the cell lookup and
+        // the weights (:241-312) are constants of the spectrum, resolved on the host (slr_amd/spectra.py).
+        const uint32_t numPoints = sp.numPoints;
+        if (numPoints == 0) return Spec16();
+        const uint32_t nw = sp.numSamples;                // 95
+        const float w0 = data[0], w1 = data[1], w2 = data[2], w3 = data[3];
+        const float* t0 = data + 4;
+        Spec16 ret = Spec16::make([&](int i) {
+            float p = (wavelengthOf(i, wlOffset) - 360.0f) / (830.0f - 360.0f);
+            float sBinF = p * (float)(nw - 1);
+            uint32_t sBin = (uint32_t)sBinF;
+            uint32_t sBinNext = (sBin + 1 < nw) ? (sBin + 1) : (nw - 1);
+            float t = sBinF - (float)sBin;
+            float r = 0.0f;
+            r += w0 * (t0[sBin] * (1 - t) + t0[sBinNext] * t);
+            r += w1 * (t0[nw + sBin] * (1 - t) + t0[nw + sBinNext] * t);
+            r += w2 * (t0[2 * nw + sBin] * (1 - t) + t0[2 * nw + sBinNext] * t);
+            if (numPoints == 4) r += w3 * (t0[3 * nw + sBin] * (1 - t) + t0[3 * nw + sBinNext] * t);
+            return r;
+        });
+        return ret * sp.scale;
+    }
+    default:
+        return Spec16();
+    }
+}
+
+// SurfaceMaterial::getBSDF in spectral mode (basic_SurfaceMaterials.cpp:15-43, MicrofacetSurfaceMaterial.cpp:14-28):
+// evaluate the constant spectra the lobe needs at this path's wavelengths.
+SLR_DEV Mat<Spec16> loadMatSpectral(const DevMaterialS* mats, uint32_t idx, const DevSpectrum* spectra, const float* pool, float wlOffset) {
+    const DevMaterialS m = mats[idx];
+    Mat<Spec16> r;
+    r.type = m.type; r.param = m.param; r.onA = m.onA; r.onB = m.onB;
+    if (m.spec[0] >= 0) r.a = 1.0f * evalSpectrum(spectra, pool, m.spec[0], wlOffset);     // scale * spectrum, scale = 1
+    if (m.spec[1] >= 0) r.b = evalSpectrum(spectra, pool, m.spec[1], wlOffset);
+    if (m.spec[2] >= 0) r.c = evalSpectrum(spectra, pool, m.spec[2], wlOffset);
     return r;
 }
 
@@ -34,7 +117,8 @@ SLR_DEV float stdmax(float a, float b) { return (a < b) ? b : a; }
 SLR_DEV float stdmin(float a, float b) { return (b < a) ? b : a; }
 
 // OrenNayerBRDF (BSDFs/OrenNayerBRDF.cpp:19-27,46-53): "sin" terms are 1 - z^2 without the square root
-SLR_DEV RGB orenNayar(const Mat& m, V3 dirI, V3 dirO, bool guardNonFinite) {
+template <class S>
+SLR_DEV S orenNayar(const Mat<S>& m, V3 dirI, V3 dirO, bool guardNonFinite) {
     float sinThetaI = 1.0f - dirI.z * dirI.z;
     float sinThetaO = 1.0f - dirO.z * dirO.z;
     float absTanThetaI = sinThetaI / fabsf(dirI.z);
@@ -112,7 +196,8 @@ struct GGX {
 };
 
 // FresnelDielectric::evaluate(cosEnter, wlIdx), DDF.cpp:113-129
-SLR_DEV float fresnelDielectricWl(RGB etaExt, RGB etaInt, float cosEnter, uint32_t wl) {
+template <class S>
+SLR_DEV float fresnelDielectricWl(const S& etaExt, const S& etaInt, float cosEnter, uint32_t wl) {
     cosEnter = fminf(1.0f, fmaxf(-1.0f, cosEnter));
     bool entering = cosEnter > 0.0f;
     const float eEnter = entering ? etaExt.comp(wl) : etaInt.comp(wl);
@@ -121,7 +206,8 @@ SLR_DEV float fresnelDielectricWl(RGB etaExt, RGB etaInt, float cosEnter, uint32
 }
 
 // One wavelength of the Walter-07 transmission term (MicrofacetBSDF.cpp:170-181, :225-236)
-SLR_DEV float mfTransmissionWl(const GGX& D_, const Mat& m, RGB eEnter, RGB eExit, V3 dirOut, V3 dir, uint32_t wl) {
+template <class S>
+SLR_DEV float mfTransmissionWl(const GGX& D_, const Mat<S>& m, const S& eEnter, const S& eExit, V3 dirOut, V3 dir, uint32_t wl) {
     const float ee = eEnter.comp(wl), ex = eExit.comp(wl);
     V3 m_wl = normalize(-(ee * dirOut + ex * dir));
     float dotHV_wl = dot(dirOut, m_wl);
@@ -154,12 +240,12 @@ SLR_DEV uint32_t bsdfType(uint32_t matType, uint32_t wlFlags) {
 
 // BSDF::sample (DDF.h:231-246) over sampleInternal of LambertianBRDF / SpecularBRDF / SpecularBSDF
 // (BSDFs/basic_BSDFs.cpp:12-26, 61-71, 95-149); query.flags = All, adjoint = false.
-template <bool MF>
-SLR_DEV RGB bsdfSample(const Mat& m, uint32_t type, V3 dirOut, V3 gNorm, uint32_t wl, float uComp, float u0, float u1, BsdfSample* res) {
+template <class S, bool MF>
+SLR_DEV S bsdfSample(const Mat<S>& m, uint32_t type, V3 dirOut, V3 gNorm, uint32_t wl, float uComp, float u0, float u1, BsdfSample* res) {
     res->dirPDF = 0.0f;
     res->dirType = 0;
-    if (!dtMatches(type, DT_All)) return RGB();
-    RGB fs_sn;
+    if (!dtMatches(type, DT_All)) return S();
+    S fs_sn;
     switch (m.type) {
     case SLRHIP_MATERIAL_MATTE: {
         // LambertianBRDF basic_BSDFs.cpp:12-26 / OrenNayerBRDF.cpp:12-34: same cosine sample, different value
@@ -171,7 +257,7 @@ SLR_DEV RGB bsdfSample(const Mat& m, uint32_t type, V3 dirOut, V3 gNorm, uint32_
         break;
     }
     case SLRHIP_MATERIAL_MICROFACET_METAL: {
-        if (!MF) return RGB();      // kernels instantiated for scenes without microfacet lobes carry none of this code
+        if (!MF) return S();      // kernels instantiated for scenes without microfacet lobes carry none of this code
         // MicrofacetBRDF::sampleInternal, BSDFs/MicrofacetBSDF.cpp:11-45
         GGX D_ = {m.param};
         bool entering = dirOut.z >= 0.0f;
@@ -179,34 +265,34 @@ SLR_DEV RGB bsdfSample(const Mat& m, uint32_t type, V3 dirOut, V3 gNorm, uint32_
         V3 mm; float mPDF;
         float D = D_.sample(sign * dirOut, u0, u1, &mm, &mPDF);
         float dotHV = dot(dirOut, mm);
-        if (dotHV * sign <= 0) return RGB();
+        if (dotHV * sign <= 0) return S();
         res->dir_sn = 2 * dotHV * mm - dirOut;
-        if (res->dir_sn.z * dirOut.z <= 0) return RGB();
+        if (res->dir_sn.z * dirOut.z <= 0) return S();
         float commonPDFTerm = 1.0f / (4 * dotHV * sign);
         res->dirPDF = commonPDFTerm * mPDF;
         res->dirType = type;
-        RGB F = fresnelConductor(m.b, m.c, dotHV);
+        S F = fresnelConductor(m.b, m.c, dotHV);
         float G = D_.evaluateSmithG1(dirOut, mm) * D_.evaluateSmithG1(res->dir_sn, mm);
         fs_sn = F * D * G / (4 * dirOut.z * res->dir_sn.z);
         break;
     }
     case SLRHIP_MATERIAL_MICROFACET_GLASS: {
-        if (!MF) return RGB();
+        if (!MF) return S();
         // MicrofacetBSDF::sampleInternal, MicrofacetBSDF.cpp:113-196 (flags = All, adjoint = false)
         GGX D_ = {m.param};
         bool entering = dirOut.z >= 0.0f;
         float sign = entering ? 1.0f : -1.0f;
-        RGB eEnter = entering ? m.b : m.c;
-        RGB eExit = entering ? m.c : m.b;
+        const S& eEnter = entering ? m.b : m.c;
+        const S& eExit = entering ? m.c : m.b;
         V3 mm; float mPDF;
         float D = D_.sample(sign * dirOut, u0, u1, &mm, &mPDF);
         float dotHV = dot(dirOut, mm);
-        if (dotHV * sign <= 0 || isnan(D)) return RGB();
-        RGB F = fresnelDielectric(m.b, m.c, dotHV);
+        if (dotHV * sign <= 0 || isnan(D)) return S();
+        S F = fresnelDielectric(m.b, m.c, dotHV);
         float reflectProb = importance(F, wl);
         if (uComp < reflectProb) {
             res->dir_sn = 2 * dotHV * mm - dirOut;
-            if (res->dir_sn.z * dirOut.z <= 0) return RGB();
+            if (res->dir_sn.z * dirOut.z <= 0) return S();
             float commonPDFTerm = reflectProb / (4 * dotHV * sign);
             res->dirPDF = commonPDFTerm * mPDF;
             res->dirType = DT_Reflection | DT_HighFreq;
@@ -217,15 +303,15 @@ SLR_DEV RGB bsdfSample(const Mat& m, uint32_t type, V3 dirOut, V3 gNorm, uint32_
             float ee = eEnter.comp(wl), ex = eExit.comp(wl);
             float recRelIOR = ee / ex;
             float innerRoot = 1 + recRelIOR * recRelIOR * (dotHV * dotHV - 1);
-            if (innerRoot < 0) return RGB();
+            if (innerRoot < 0) return S();
             res->dir_sn = (recRelIOR * dotHV - sign * sqrtf(innerRoot)) * mm - recRelIOR * dirOut;
-            if (res->dir_sn.z * dirOut.z >= 0) return RGB();
+            if (res->dir_sn.z * dirOut.z >= 0) return S();
             float dotHL = dot(res->dir_sn, mm);
             double den = (double)(ee * dotHV + ex * dotHL);
             float commonPDFTerm = (float)((double)(1 - reflectProb) / (den * den));
             float pdf = commonPDFTerm * mPDF * ex * ex * fabsf(dotHL);
-            RGB ret(mfTransmissionWl(D_, m, eEnter, eExit, dirOut, res->dir_sn, 0), mfTransmissionWl(D_, m, eEnter, eExit, dirOut, res->dir_sn, 1),
-                    mfTransmissionWl(D_, m, eEnter, eExit, dirOut, res->dir_sn, 2));
+            const V3 dirT = res->dir_sn;
+            S ret = S::make([&](int i) { return mfTransmissionWl(D_, m, eEnter, eExit, dirOut, dirT, (uint32_t)i); });
             ret = ret / fabsf(dirOut.z * res->dir_sn.z);
             ret = ret * (eEnter * eEnter);
             res->dirPDF = pdf;
@@ -242,10 +328,10 @@ SLR_DEV RGB bsdfSample(const Mat& m, uint32_t type, V3 dirOut, V3 gNorm, uint32_
         break;
     }
     case SLRHIP_MATERIAL_GLASS: {
-        RGB F = fresnelDielectric(m.b, m.c, dirOut.z);
+        S F = fresnelDielectric(m.b, m.c, dirOut.z);
         float reflectProb = importance(F, wl);
         if (uComp < reflectProb) {
-            if (dirOut.z == 0.0f) return RGB();
+            if (dirOut.z == 0.0f) return S();
             res->dir_sn = V3(-dirOut.x, -dirOut.y, dirOut.z);
             res->dirPDF = reflectProb;
             res->dirType = DT_Reflection | DT_Delta0D;
@@ -259,7 +345,7 @@ SLR_DEV RGB bsdfSample(const Mat& m, uint32_t type, V3 dirOut, V3 gNorm, uint32_
             float sinEnter2 = 1.0f - dirOut.z * dirOut.z;
             float rrEta = eEnter / eExit;
             float sinExit2 = rrEta * rrEta * sinEnter2;
-            if (sinExit2 >= 1.0f) return RGB();
+            if (sinExit2 >= 1.0f) return S();
             float cosExit = sqrtf(fmaxf(0.0f, 1.0f - sinExit2));
             if (entering) cosExit = -cosExit;
             res->dir_sn = V3(rrEta * -dirOut.x, rrEta * -dirOut.y, cosExit);
@@ -267,22 +353,22 @@ SLR_DEV RGB bsdfSample(const Mat& m, uint32_t type, V3 dirOut, V3 gNorm, uint32_
             res->dirType = DT_Transmission | DT_Delta0D | ((type & DT_Dispersive) ? (uint32_t)DT_Dispersive : 0u);
             float v = m.a.comp(wl) * (1.0f - F.comp(wl));
             v *= (eEnter * eEnter) / (eExit * eExit);
-            RGB ret(wl == 0 ? v : 0.0f, wl == 1 ? v : 0.0f, wl == 2 ? v : 0.0f);
+            S ret = S::make([&](int i) { return (uint32_t)i == wl ? v : 0.0f; });
             fs_sn = ret / fabsf(cosExit);
         }
         break;
     }
     default:
-        return RGB();
+        return S();
     }
-    if (res->dirPDF == 0.0f) return RGB();
+    if (res->dirPDF == 0.0f) return S();
     float snCorrection = fabsf(res->dir_sn.z / dot(res->dir_sn, gNorm));
     return fs_sn * snCorrection;
 }
 
 // BSDF::evaluatePDF (DDF.h:268-279; query.flags = All) of the lobes that have a non-delta component.
-template <bool MF>
-SLR_DEV float bsdfEvaluatePDF(const Mat& m, uint32_t type, V3 dirOut, V3 dir, uint32_t wl) {
+template <class S, bool MF>
+SLR_DEV float bsdfEvaluatePDF(const Mat<S>& m, uint32_t type, V3 dirOut, V3 dir, uint32_t wl) {
     if (!dtMatches(type, DT_All)) return 0.0f;
     switch (m.type) {
     case SLRHIP_MATERIAL_MATTE:
@@ -310,14 +396,14 @@ SLR_DEV float bsdfEvaluatePDF(const Mat& m, uint32_t type, V3 dirOut, V3 dir, ui
         float sign = entering ? 1.0f : -1.0f;
         float dotNVdotNL = dir.z * dirOut.z;
         if (dotNVdotNL == 0) return 0.0f;
-        float ee = (entering ? m.b : m.c).comp(wl), ex = (entering ? m.c : m.b).comp(wl);
+        float ee = entering ? m.b.comp(wl) : m.c.comp(wl), ex = entering ? m.c.comp(wl) : m.b.comp(wl);
         V3 mm;
         if (dotNVdotNL > 0) mm = sign * normalize(dirOut + dir);
         else mm = normalize(-(ee * dirOut + ex * dir));
         float dotHV = dot(dirOut, mm);
         if (dotHV * sign <= 0) return 0.0f;
         float mPDF = D_.evaluatePDF(sign * dirOut, mm);
-        RGB F = fresnelDielectric(m.b, m.c, dotHV);
+        S F = fresnelDielectric(m.b, m.c, dotHV);
         float reflectProb = importance(F, wl);
         if (dotNVdotNL > 0) {
             float commonPDFTerm = reflectProb / (4 * dotHV * sign);
@@ -334,17 +420,17 @@ SLR_DEV float bsdfEvaluatePDF(const Mat& m, uint32_t type, V3 dirOut, V3 dir, ui
 }
 
 // BSDF::evaluate (DDF.h:247-267) + evaluatePDF for the NEE direction.
-template <bool MF>
-SLR_DEV RGB bsdfEvaluate(const Mat& m, uint32_t type, V3 dirOut, V3 gNorm, V3 dir, uint32_t wl, float* pdf) {
-    *pdf = bsdfEvaluatePDF<MF>(m, type, dirOut, dir, wl);
+template <class S, bool MF>
+SLR_DEV S bsdfEvaluate(const Mat<S>& m, uint32_t type, V3 dirOut, V3 gNorm, V3 dir, uint32_t wl, float* pdf) {
+    *pdf = bsdfEvaluatePDF<S, MF>(m, type, dirOut, dir, wl);
     bool reflect = dot(gNorm, dirOut) * dot(gNorm, dir) > 0;                       // sideTest DDF.h:213-216
     uint32_t flags = DT_All & (DT_AllFreq | (reflect ? DT_Reflection : DT_Transmission));
-    if (!dtMatches(type, flags)) return RGB();
-    RGB fs_sn;
+    if (!dtMatches(type, flags)) return S();
+    S fs_sn;
     switch (m.type) {
     case SLRHIP_MATERIAL_MATTE:
         // LambertianBRDF::evaluateInternal basic_BSDFs.cpp:28-39 / OrenNayerBRDF.cpp:36-56
-        if (dirOut.z * dir.z <= 0.0f) fs_sn = RGB();
+        if (dirOut.z * dir.z <= 0.0f) fs_sn = S();
         else if (m.param >= 0.0f) fs_sn = orenNayar(m, dir, dirOut, false);
         else fs_sn = m.a / (float)kPi;
         break;
@@ -357,7 +443,7 @@ SLR_DEV RGB bsdfEvaluate(const Mat& m, uint32_t type, V3 dirOut, V3 gNorm, V3 di
         V3 mm = sign * normalize(dirOut + dir);
         float dotHV = dot(dirOut, mm);
         float D = D_.evaluate(mm);
-        RGB F = fresnelConductor(m.b, m.c, dotHV);
+        S F = fresnelConductor(m.b, m.c, dotHV);
         float G = D_.evaluateSmithG1(dirOut, mm) * D_.evaluateSmithG1(dir, mm);
         fs_sn = F * D * G / (4 * dirOut.z * dir.z);
         break;
@@ -373,15 +459,14 @@ SLR_DEV RGB bsdfEvaluate(const Mat& m, uint32_t type, V3 dirOut, V3 gNorm, V3 di
             V3 mm = sign * normalize(dirOut + dir);
             float dotHV = dot(dirOut, mm);
             float D = D_.evaluate(mm);
-            RGB F = fresnelDielectric(m.b, m.c, dotHV);
+            S F = fresnelDielectric(m.b, m.c, dotHV);
             float G = D_.evaluateSmithG1(dirOut, mm) * D_.evaluateSmithG1(dir, mm);
             fs_sn = F * D * G / (4 * dotNVdotNL);
         }
         else if (dotNVdotNL < 0 && dtMatches(flags, DT_Transmission | DT_AllFreq)) {
-            RGB eEnter = entering ? m.b : m.c;
-            RGB eExit = entering ? m.c : m.b;
-            RGB ret(mfTransmissionWl(D_, m, eEnter, eExit, dirOut, dir, 0), mfTransmissionWl(D_, m, eEnter, eExit, dirOut, dir, 1),
-                    mfTransmissionWl(D_, m, eEnter, eExit, dirOut, dir, 2));
+            const S& eEnter = entering ? m.b : m.c;
+            const S& eExit = entering ? m.c : m.b;
+            S ret = S::make([&](int i) { return mfTransmissionWl(D_, m, eEnter, eExit, dirOut, dir, (uint32_t)i); });
             ret = ret / fabsf(dotNVdotNL);
             fs_sn = ret * (eEnter * eEnter);
         }

@@ -61,6 +61,10 @@ struct RGB {
     SLR_DEV RGB(float rr, float gg, float bb) : r(rr), g(gg), b(bb) {}
     SLR_DEV float comp(uint32_t i) const { return i == 0 ? r : (i == 1 ? g : b); }
     SLR_DEV bool isZero() const { return r == 0.0f && g == 0.0f && b == 0.0f; }
+    // generic spectrum interface shared with Spec16
+    static constexpr int N = 3;
+    template <class F> SLR_DEV static RGB make(F f) { return RGB(f(0), f(1), f(2)); }
+    SLR_DEV float sum() const { return r + g + b; }                      // 0 + r is exact: same bits as a running sum from 0
 };
 SLR_DEV RGB operator+(RGB a, RGB b) { return RGB(a.r + b.r, a.g + b.g, a.b + b.b); }
 SLR_DEV RGB operator-(RGB a, RGB b) { return RGB(a.r - b.r, a.g - b.g, a.b - b.b); }
@@ -73,18 +77,75 @@ SLR_DEV RGB operator+(RGB a, float s) { return a + RGB(s); }
 SLR_DEV RGB operator-(RGB a, float s) { return a - RGB(s); }
 SLR_DEV RGB rgb4(const float* p) { return RGB(p[0], p[1], p[2]); }
 
-// RGBTypes.h:103-108
-SLR_DEV float importance(RGB s, uint32_t selectedLambda) {
-    float sum = s.r + s.g + s.b;
+// ---- SampledSpectrumTemplate<float, 16>, BasicTypes/SpectrumTypes.h:348-554 ------------------------------
+// Component access with a run-time index goes through a select chain so that the array stays in registers.
+struct Spec16 {
+    float c[16];
+    static constexpr int N = 16;
+    SLR_DEV Spec16() {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) c[i] = 0.0f;
+    }
+    SLR_DEV explicit Spec16(float v) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) c[i] = v;
+    }
+    template <class F> SLR_DEV static Spec16 make(F f) {
+        Spec16 r;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) r.c[i] = f(i);
+        return r;
+    }
+    SLR_DEV float comp(uint32_t idx) const {
+        float v = c[0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) v = (idx == (uint32_t)i) ? c[i] : v;
+        return v;
+    }
+    SLR_DEV bool isZero() const {
+        bool z = true;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) z = z && (c[i] == 0.0f);
+        return z;
+    }
+    SLR_DEV float sum() const {                                          // SpectrumTypes.h:516-518: running sum from 0
+        float s = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s += c[i];
+        return s;
+    }
+};
+#define SLR_SPEC16_OP(op)                                                                                   \
+    SLR_DEV Spec16 operator op(const Spec16& a, const Spec16& b) {                                          \
+        Spec16 r;                                                                                           \
+        _Pragma("unroll") for (int i = 0; i < 16; ++i) r.c[i] = a.c[i] op b.c[i];                           \
+        return r;                                                                                           \
+    }
+SLR_SPEC16_OP(+)
+SLR_SPEC16_OP(-)
+SLR_SPEC16_OP(*)
+SLR_SPEC16_OP(/)
+#undef SLR_SPEC16_OP
+SLR_DEV Spec16 operator*(const Spec16& a, float s) { return Spec16::make([&](int i) { return a.c[i] * s; }); }
+SLR_DEV Spec16 operator*(float s, const Spec16& a) { return Spec16::make([&](int i) { return a.c[i] * s; }); }   // SpectrumTypes.h:400-405: c.values[i] * s
+SLR_DEV Spec16 operator/(const Spec16& a, float s) { float r = 1 / s; return Spec16::make([&](int i) { return a.c[i] * r; }); }   // :393-399
+SLR_DEV Spec16 operator+(const Spec16& a, float s) { return a + Spec16(s); }
+SLR_DEV Spec16 operator-(const Spec16& a, float s) { return a - Spec16(s); }
+
+// importance(): RGBTypes.h:103-108 / SpectrumTypes.h:512-526 (marginal = (1 - primary) / (N - 1); N = 3 gives / 2)
+template <class S>
+SLR_DEV float importance(const S& s, uint32_t selectedLambda) {
+    float sum = s.sum();
     const float primary = 0.9f;
-    const float marginal = (1 - primary) / 2;
+    const float marginal = (1 - primary) / (S::N - 1);
     return sum * marginal + s.comp(selectedLambda) * (primary - marginal);
 }
 
 // BasicTypes/CompensatedSum.h:24-30
-SLR_DEV void kahanAdd(RGB& result, RGB& comp, RGB value) {
-    RGB cInput = value - comp;
-    RGB sumTemp = result + cInput;
+template <class S>
+SLR_DEV void kahanAdd(S& result, S& comp, const S& value) {
+    S cInput = value - comp;
+    S sumTemp = result + cInput;
     comp = (sumTemp - result) - cInput;
     result = sumTemp;
 }
@@ -180,14 +241,15 @@ SLR_DEV V3 cosineSampleHemisphere(float u0, float u1) {
 }
 
 // ---- Fresnel, Core/directional_distribution_functions.cpp:68-159 -------------------------------------
-SLR_DEV RGB fresnelConductor(RGB eta, RGB k, float cosEnter) {   // :68-78
+template <class S>
+SLR_DEV S fresnelConductor(const S& eta, const S& k, float cosEnter) {   // :68-78
     cosEnter = fabsf(cosEnter);
     float cosEnter2 = cosEnter * cosEnter;
-    RGB _2EtaCosEnter = 2.0f * eta * cosEnter;
-    RGB tmp_f = eta * eta + k * k;
-    RGB tmp = tmp_f * cosEnter2;
-    RGB Rparl2 = (tmp - _2EtaCosEnter + 1.0f) / (tmp + _2EtaCosEnter + 1.0f);
-    RGB Rperp2 = (tmp_f - _2EtaCosEnter + cosEnter2) / (tmp_f + _2EtaCosEnter + cosEnter2);
+    S _2EtaCosEnter = (2.0f * eta) * cosEnter;
+    S tmp_f = eta * eta + k * k;
+    S tmp = tmp_f * cosEnter2;
+    S Rparl2 = (tmp - _2EtaCosEnter + 1.0f) / (tmp + _2EtaCosEnter + 1.0f);
+    S Rperp2 = (tmp_f - _2EtaCosEnter + cosEnter2) / (tmp_f + _2EtaCosEnter + cosEnter2);
     return (Rparl2 + Rperp2) / 2.0f;
 }
 SLR_DEV float fresnelEvalF(float etaEnter, float etaExit, float cosEnter, float cosExit) {   // :155-159
@@ -201,15 +263,17 @@ SLR_DEV float fresnelDielectric1(float eEnter, float eExit, float sinTerm, float
     float cosExit = sqrtf(fmaxf(0.0f, 1.0f - sinExit * sinExit));
     return fresnelEvalF(eEnter, eExit, cosEnterAbs, cosExit);
 }
-SLR_DEV RGB fresnelDielectric(RGB etaExt, RGB etaInt, float cosEnter) {   // :90-111
+template <class S>
+SLR_DEV S fresnelDielectric(const S& etaExt, const S& etaInt, float cosEnter) {   // :90-111
     cosEnter = fminf(1.0f, fmaxf(-1.0f, cosEnter));
     bool entering = cosEnter > 0.0f;
-    RGB eEnter = entering ? etaExt : etaInt;
-    RGB eExit = entering ? etaInt : etaExt;
     float sinTerm = sqrtf(fmaxf(0.0f, 1.0f - cosEnter * cosEnter));
     float c = fabsf(cosEnter);
-    return RGB(fresnelDielectric1(eEnter.r, eExit.r, sinTerm, c), fresnelDielectric1(eEnter.g, eExit.g, sinTerm, c),
-               fresnelDielectric1(eEnter.b, eExit.b, sinTerm, c));
+    return S::make([&](int i) {
+        float eEnter = entering ? etaExt.comp(i) : etaInt.comp(i);
+        float eExit = entering ? etaInt.comp(i) : etaExt.comp(i);
+        return fresnelDielectric1(eEnter, eExit, sinTerm, c);
+    });
 }
 
 // ---- DirectionType flags, Core/directional_distribution_functions.h:18-91 ------------------------------

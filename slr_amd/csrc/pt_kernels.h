@@ -13,7 +13,10 @@ struct DevScene {
     const float4* leafTris;       // LeafTri as 3 x float4
     const ShadeTri* shadeTris;    // indexed by scene triangle index
     const LightTri* lightTris;    // indexed by light index
-    const DevMaterial* materials;
+    const DevMaterial* materials;  // RGB mode
+    const DevMaterialS* materialsS; // spectral mode: spectrum indices instead of constants
+    const DevSpectrum* spectra;
+    const float* spectrumPool;
     const float* lightPMF;        // RegularConstantDiscrete1D of the aggregate's light list
     const float* lightCDF;        // numLights + 1 entries
     uint32_t numNodes;
@@ -51,13 +54,17 @@ struct PathBuffers {
     float4* rayOrg;               // extension / shadow ray origin, w = distMin
     float4* rayDir;               // extension ray direction, w = distMax
     float4* hit;                  // x = triangle (bits), y = t, z = b0, w = b1
-    float4* alpha;                // path throughput, w = pdf of the sampled direction
-    float4* spR;                  // path radiance Kahan sum (sp), w = camera weight
+    // spectrum-valued records: RGB = one float4 per slot (scalar in .w); spectral = 4 planes of numSlots float4
+    float4* alpha;                // path throughput (+ pdf of the sampled direction)
+    float4* spR;                  // path radiance Kahan sum (sp) (+ camera weight)
     float4* spC;                  // its compensation
     float4* accR;                 // pixel accumulator Kahan sum (the ImageSensor pixel)
     float4* accC;
     float4* nee;                  // pending next-event contribution
     float4* shadowDir;            // shadow ray direction, w = distMax
+    float* pdfPrev;               // spectral mode only: the scalars that ride in .w in RGB mode
+    float* camWeight;
+    float* wlOffset;              // spectral mode: the sample's wavelength offset (lambda_i = 360 + 470 (i + offset) / 16)
     uint32_t* flags;
     uint32_t* sampleIdx;
     uint32_t* visible;            // result of the shadow ray
@@ -77,6 +84,7 @@ struct RenderParams {
     uint32_t imageWidth, imageHeight;
     uint32_t countSlots;          // SLRHIP_FLAG_COUNT_TRAVERSAL: also count live slots per logic launch
     uint32_t shardCapacity;       // entries per queue region = ceil(numBlocks / kShards) * 256
+    uint32_t spectral;            // 0 = RGB (3 components), 1 = 16 wavelength samples
 };
 
 void launchResetSlots(const PathBuffers& pb, const RenderParams& rp, bool clearAccumulators, hipStream_t stream);

@@ -32,21 +32,73 @@ enum : uint32_t {
     ST_NEXT_HIT = 3,        // BSDF-sampled ray in flight  (:225)
     ST_FINISH = 4           // path ended while a shadow ray was still pending
 };
-// flags word: [2:0] state | [9:3] pathLength | [11:10] selectedLambda | [12] wlFlags.LambdaIsSelected
-//             | [13] previous direction was delta | [14] shadow ray pending | [15] a finished path awaits accumulation
+// flags word: [2:0] state | [9:3] pathLength | [12] wlFlags.LambdaIsSelected | [13] previous direction was delta
+//             | [14] shadow ray pending | [15] a finished path awaits accumulation | [19:16] selectedLambda
 #define F_STATE(f) ((f) & 7u)
 #define F_PATHLEN(f) (((f) >> 3) & 127u)
-#define F_WL(f) (((f) >> 10) & 3u)
+#define F_WL(f) (((f) >> 16) & 15u)
 #define F_WLSEL(f) (((f) >> 12) & 1u)
 #define F_DELTA(f) (((f) >> 13) & 1u)
 #define F_SHADOW(f) (((f) >> 14) & 1u)
 #define F_HASPATH(f) (((f) >> 15) & 1u)
 #define F_MAKE(state, len, wl, wlsel, delta, shadow) \
-    ((state) | ((len) << 3) | ((wl) << 10) | ((wlsel) << 12) | ((delta) << 13) | ((shadow) << 14))
+    ((state) | ((len) << 3) | ((wl) << 16) | ((wlsel) << 12) | ((delta) << 13) | ((shadow) << 14))
 
 static const int kShadeBlock = 256;
 static const int kLdsMaterials = 32;
 static const int kLdsLights = 16;
+
+// Spectrum-valued path state in HBM.  RGB: one float4 per slot, the scalar that travels with it in .w.
+// Spectral: four float4 planes per array (plane p of slot i at [p * numSlots + i], so every plane is a coalesced
+// stream) and the scalar in an array of its own.
+template <class S> struct SpecIO;
+template <> struct SpecIO<RGB> {
+    static __device__ __forceinline__ void load(const float4* a, const float* /*scalars*/, uint32_t slot, uint32_t /*n*/, RGB& v, float& w) {
+        const float4 q = a[slot];
+        v = RGB(q.x, q.y, q.z); w = q.w;
+    }
+    static __device__ __forceinline__ void store(float4* a, float* /*scalars*/, uint32_t slot, uint32_t /*n*/, const RGB& v, float w) {
+        a[slot] = make_float4(v.r, v.g, v.b, w);
+    }
+};
+template <> struct SpecIO<Spec16> {
+    static __device__ __forceinline__ void load(const float4* a, const float* scalars, uint32_t slot, uint32_t n, Spec16& v, float& w) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const float4 q = a[(size_t)p * n + slot];
+            v.c[4 * p] = q.x; v.c[4 * p + 1] = q.y; v.c[4 * p + 2] = q.z; v.c[4 * p + 3] = q.w;
+        }
+        w = scalars ? scalars[slot] : 0.0f;
+    }
+    static __device__ __forceinline__ void store(float4* a, float* scalars, uint32_t slot, uint32_t n, const Spec16& v, float w) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) a[(size_t)p * n + slot] = make_float4(v.c[4 * p], v.c[4 * p + 1], v.c[4 * p + 2], v.c[4 * p + 3]);
+        if (scalars) scalars[slot] = w;
+    }
+};
+
+// Material access per mode
+template <class S> struct MatIO;
+template <> struct MatIO<RGB> {
+    template <bool LDS>
+    static __device__ __forceinline__ Mat<RGB> load(const DevScene& sc, const float4* ldsMats, uint32_t idx, float) {
+        return loadMat(LDS ? reinterpret_cast<const DevMaterial*>(ldsMats) + idx : sc.materials + idx);
+    }
+    template <bool LDS>
+    static __device__ __forceinline__ RGB emittance(const DevScene& sc, const float4* ldsMats, uint32_t idx, float) {
+        return loadEmittance(LDS ? reinterpret_cast<const DevMaterial*>(ldsMats) + idx : sc.materials + idx);
+    }
+};
+template <> struct MatIO<Spec16> {
+    template <bool LDS>
+    static __device__ __forceinline__ Mat<Spec16> load(const DevScene& sc, const float4*, uint32_t idx, float wlOffset) {
+        return loadMatSpectral(sc.materialsS, idx, sc.spectra, sc.spectrumPool, wlOffset);
+    }
+    template <bool LDS>
+    static __device__ __forceinline__ Spec16 emittance(const DevScene& sc, const float4*, uint32_t idx, float wlOffset) {
+        return evalSpectrum(sc.spectra, sc.spectrumPool, sc.materialsS[idx].spec[3], wlOffset);
+    }
+};
 
 // Append `slot` to the workgroup's region of up to two queues: wave ballots + popcount prefixes, the four
 // wave counts meet in LDS, ONE atomic per queue per workgroup (on the region's own counter line).
@@ -106,13 +158,15 @@ struct ShadeLds {
     float lightCDF[kLdsLights + 1];
 };
 
-template <bool LDS_TABLES, bool MF>
+template <class S, bool LDS_TABLES, bool MF>
 __global__ __launch_bounds__(kShadeBlock) void k_logic(DevScene sc, PathBuffers pb, RenderParams rp, uint32_t parity) {
     __shared__ ShadeLds lds;
     __shared__ PushLds pushLds;
     if (LDS_TABLES) {
-        const float4* gm = reinterpret_cast<const float4*>(sc.materials);
-        for (uint32_t i = threadIdx.x; i < sc.numMaterials * 5; i += kShadeBlock) lds.mats[i] = gm[i];
+        if (S::N == 3) {
+            const float4* gm = reinterpret_cast<const float4*>(sc.materials);
+            for (uint32_t i = threadIdx.x; i < sc.numMaterials * 5; i += kShadeBlock) lds.mats[i] = gm[i];
+        }
         const float4* gl = reinterpret_cast<const float4*>(sc.lightTris);
         for (uint32_t i = threadIdx.x; i < sc.numLights * 9; i += kShadeBlock) lds.lights[i] = gl[i];
         if (threadIdx.x < sc.numLights) lds.lightPMF[threadIdx.x] = sc.lightPMF[threadIdx.x];
@@ -130,21 +184,21 @@ __global__ __launch_bounds__(kShadeBlock) void k_logic(DevScene sc, PathBuffers 
         // ---- all state loads up front: one memory round trip instead of a dependent chain -----------
         uint32_t flags = pb.flags[slot];
         const uint4 r4 = pb.rng[slot];
-        const float4 ao = pb.alpha[slot];
-        const float4 s0 = pb.spR[slot], s1 = pb.spC[slot];
+        S alpha, spR, spC, neeC;
+        float bsdfPDFprev, camWeight, unusedW;
+        SpecIO<S>::load(pb.alpha, pb.pdfPrev, slot, rp.numSlots, alpha, bsdfPDFprev);
+        SpecIO<S>::load(pb.spR, pb.camWeight, slot, rp.numSlots, spR, camWeight);
+        SpecIO<S>::load(pb.spC, nullptr, slot, rp.numSlots, spC, unusedW);
+        SpecIO<S>::load(pb.nee, nullptr, slot, rp.numSlots, neeC, unusedW);
         const float4 h = pb.hit[slot];
         const float4 o4 = pb.rayOrg[slot], d4 = pb.rayDir[slot];
-        const float4 neeC = pb.nee[slot];
         const uint32_t vis = pb.visible[slot];
+        const float wlOffset = S::N == 3 ? 0.0f : pb.wlOffset[slot];
 
         const uint32_t state = F_STATE(flags);
         if (state == ST_FIRST_HIT || state == ST_NEXT_HIT || state == ST_FINISH) {
             Rng rng;
             rng.s0 = r4.x; rng.s1 = r4.y; rng.s2 = r4.z; rng.s3 = r4.w;
-            RGB alpha(ao.x, ao.y, ao.z);
-            float bsdfPDFprev = ao.w;
-            RGB spR(s0.x, s0.y, s0.z), spC(s1.x, s1.y, s1.z);
-            const float camWeight = s0.w;
             uint32_t pathLength = F_PATHLEN(flags), wlSel = F_WLSEL(flags);
             const uint32_t wl = F_WL(flags);
             V3 rayOrg(o4.x, o4.y, o4.z), rayDir(d4.x, d4.y, d4.z);
@@ -164,10 +218,10 @@ __global__ __launch_bounds__(kShadeBlock) void k_logic(DevScene sc, PathBuffers 
             }
 
             // ---- 1. resolve the pending next-event estimate (:180,202) ---------------------------------
-            if (F_SHADOW(flags) && vis) kahanAdd(spR, spC, RGB(neeC.x, neeC.y, neeC.z));
+            if (F_SHADOW(flags) && vis) kahanAdd(spR, spC, neeC);
 
             // ---- 2. the hit that just came back ------------------------------------------------------------
-            Mat m;
+            Mat<S> m;
             if (!hasHit) {
                 finish = true;                      // ST_FINISH, or a miss: :148 return Zero / :226 break
             }
@@ -178,7 +232,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_logic(DevScene sc, PathBuffers 
                 surf.material = __float_as_uint(q0.w);
                 surf.light = (int32_t)__float_as_uint(q1.w);
                 surf.areaPDF = q2.w;
-                m = loadMat(LDS_TABLES ? reinterpret_cast<const DevMaterial*>(lds.mats) + surf.material : sc.materials + surf.material);
+                m = MatIO<S>::template load<LDS_TABLES>(sc, lds.mats, surf.material, wlOffset);
                 const float b0 = h.z, b1 = h.w;
                 const float b2 = 1.0f - b0 - b1;
                 surf.frame.z = normalize(b0 * xyz(q0) + b1 * xyz(q1) + b2 * xyz(q2));
@@ -189,7 +243,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_logic(DevScene sc, PathBuffers 
                 haveSurf = true;
                 dirOut_sn = surf.frame.toLocal(-rayDir);
                 if (surf.light >= 0) {
-                    RGB Le = m.emittance * RGB(diffuseEDF(dirOut_sn));
+                    S Le = MatIO<S>::template emittance<LDS_TABLES>(sc, lds.mats, surf.material, wlOffset) * S(diffuseEDF(dirOut_sn));
                     if (state == ST_FIRST_HIT) {
                         kahanAdd(spR, spC, alpha * Le);                        // :152-156
                     }
@@ -206,7 +260,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_logic(DevScene sc, PathBuffers 
                 }
                 if (state == ST_NEXT_HIT) {
                     // Russian roulette :254-258 (initY = importance(One) evaluated like the reference)
-                    float initY = importance(RGB(1.0f), wl);
+                    float initY = importance(S(1.0f), wl);
                     float continueProb = fminf(importance(alpha, wl) / initY, 1.0f);
                     if (rng.nextFloat() < continueProb) alpha = alpha / continueProb;
                     else finish = true;
@@ -243,7 +297,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_logic(DevScene sc, PathBuffers 
                         lf.y = cross(lf.z, lf.x);
                         float areaPDF = l2.w;
                         const uint32_t lmat = __float_as_uint(l1.w);
-                        RGB M = loadMat(LDS_TABLES ? reinterpret_cast<const DevMaterial*>(lds.mats) + lmat : sc.materials + lmat).emittance;
+                        S M = MatIO<S>::template emittance<LDS_TABLES>(sc, lds.mats, lmat, wlOffset);
                         // shadow ray of Scene::testVisibility SurfaceObject.cpp:425-426
                         float dist = length(surf.p - lp);
                         V3 sdir = (lp - surf.p) / dist;
@@ -255,30 +309,30 @@ __global__ __launch_bounds__(kShadeBlock) void k_logic(DevScene sc, PathBuffers 
                         V3 shadowDir = dvec / sqrtf(dist2);
                         V3 shadowDir_l = lf.toLocal(-shadowDir);
                         V3 shadowDir_sn = surf.frame.toLocal(shadowDir);
-                        RGB Le = M * RGB(diffuseEDF(shadowDir_l));
+                        S Le = M * S(diffuseEDF(shadowDir_l));
                         float lightPDF = lightProb * areaPDF;
                         float pdfDir;
-                        RGB fs = bsdfEvaluate<MF>(m, type, dirOut_sn, gNorm_sn, shadowDir_sn, wl, &pdfDir);
+                        S fs = bsdfEvaluate<S, MF>(m, type, dirOut_sn, gNorm_sn, shadowDir_sn, wl, &pdfDir);
                         float cosLight = absDot(-shadowDir, lgn);
                         float bsdfPDF = pdfDir * cosLight / dist2;
                         float MISWeight = 1.0f;
                         if (!isinf(areaPDF))
                             MISWeight = (lightPDF * lightPDF) / (lightPDF * lightPDF + bsdfPDF * bsdfPDF);
                         float G = absDot(shadowDir_sn, gNorm_sn) * cosLight / dist2;
-                        RGB contrib = alpha * Le * fs * (G * MISWeight / lightPDF);
-                        pb.nee[slot] = make_float4(contrib.r, contrib.g, contrib.b, 0.0f);
+                        S contrib = alpha * Le * fs * (G * MISWeight / lightPDF);
+                        SpecIO<S>::store(pb.nee, nullptr, slot, rp.numSlots, contrib, 0.0f);
                     }
                     float uComp = rng.nextFloat();
                     float u0 = rng.nextFloat();
                     float u1 = rng.nextFloat();
                     BsdfSample bs;
-                    RGB fs = bsdfSample<MF>(m, type, dirOut_sn, gNorm_sn, wl, uComp, u0, u1, &bs);
+                    S fs = bsdfSample<S, MF>(m, type, dirOut_sn, gNorm_sn, wl, uComp, u0, u1, &bs);
                     if (fs.isZero() || bs.dirPDF == 0.0f) {
                         finish = true;                                         // :209
                     }
                     else {
                         if (bs.dirType & DT_Dispersive) {                      // :211-214
-                            bs.dirPDF /= 3;
+                            bs.dirPDF /= S::N;                                 // WavelengthSamples::NumComponents
                             wlSel = 1;
                         }
                         alpha = alpha * (fs * absDot(bs.dir_sn, gNorm_sn) / bs.dirPDF);     // :215
@@ -306,11 +360,11 @@ __global__ __launch_bounds__(kShadeBlock) void k_logic(DevScene sc, PathBuffers 
 
             // ---- store path state ---------------------------------------------------------------------------
             pb.flags[slot] = flags;
-            pb.spR[slot] = make_float4(spR.r, spR.g, spR.b, camWeight);
+            SpecIO<S>::store(pb.spR, pb.camWeight, slot, rp.numSlots, spR, camWeight);
             if (!emitRegen) {
-                pb.spC[slot] = make_float4(spC.r, spC.g, spC.b, 0.0f);
+                SpecIO<S>::store(pb.spC, nullptr, slot, rp.numSlots, spC, 0.0f);
                 pb.rng[slot] = make_uint4(rng.s0, rng.s1, rng.s2, rng.s3);
-                pb.alpha[slot] = make_float4(alpha.r, alpha.g, alpha.b, bsdfPDFprev);
+                SpecIO<S>::store(pb.alpha, pb.pdfPrev, slot, rp.numSlots, alpha, bsdfPDFprev);
             }
             if (emitExt) {
                 pb.rayOrg[slot] = make_float4(rayOrg.x, rayOrg.y, rayOrg.z, rayTmin);
@@ -331,6 +385,24 @@ __global__ __launch_bounds__(kShadeBlock) void k_logic(DevScene sc, PathBuffers 
 
 // Finished (or brand-new) slots, dense: sensor->add + the camera-ray half of Job::kernel.
 // Workgroup b serves chunk b / kShards of queue region b % kShards; surplus workgroups exit at once.
+// SpectrumStorage::add.  RGB: the sample is Kahan-added to the pixel (RGBTypes.h:176-179).  Spectral: every component goes
+// to the storage bin of its wavelength scaled by the reciprocal bin width, then the 16-bin addend is Kahan-added
+// (SpectrumTypes.h:818-836).  Bin selection through compare-selects keeps the addend in registers.
+__device__ __forceinline__ RGB storageAddend(const RGB& val, float) { return val; }
+__device__ __forceinline__ Spec16 storageAddend(const Spec16& val, float wlOffset) {
+    const float recBinWidth = 16 / (830.0f - 360.0f);
+    Spec16 addend;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const uint32_t sBin = min((uint32_t)((wavelengthOf(i, wlOffset) - 360.0f) / (830.0f - 360.0f) * 16), 15u);
+        const float v = val.c[i] * recBinWidth;
+#pragma unroll
+        for (int b = 0; b < 16; ++b) addend.c[b] = (sBin == (uint32_t)b) ? addend.c[b] + v : addend.c[b];
+    }
+    return addend;
+}
+
+template <class S>
 __global__ __launch_bounds__(kShadeBlock) void k_regen(DevScene sc, PathBuffers pb, RenderParams rp, uint32_t parity) {
     const uint32_t shard = blockIdx.x % kShards;
     const uint32_t n = pb.queueCount[queueCounterIndex(parity, Q_REGEN, shard)];
@@ -344,13 +416,15 @@ __global__ __launch_bounds__(kShadeBlock) void k_regen(DevScene sc, PathBuffers 
         uint32_t sampleIdx = pb.sampleIdx[slot];
         if (F_HASPATH(flags)) {
             // sensor->add(p.x, p.y, wls, weight * C)  PathTracingRenderer.cpp:126-130
-            const float4 s0 = pb.spR[slot];
-            const float4 a0 = pb.accR[slot], a1 = pb.accC[slot];
-            RGB accR(a0.x, a0.y, a0.z), accC(a1.x, a1.y, a1.z);
-            const RGB weight = (RGB(1.0f) * RGB(1.0f)) * s0.w;
-            kahanAdd(accR, accC, weight * RGB(s0.x, s0.y, s0.z));
-            pb.accR[slot] = make_float4(accR.r, accR.g, accR.b, 0.0f);
-            pb.accC[slot] = make_float4(accC.r, accC.g, accC.b, 0.0f);
+            S C, accR, accC;
+            float camW, unusedW;
+            SpecIO<S>::load(pb.spR, pb.camWeight, slot, rp.numSlots, C, camW);
+            SpecIO<S>::load(pb.accR, nullptr, slot, rp.numSlots, accR, unusedW);
+            SpecIO<S>::load(pb.accC, nullptr, slot, rp.numSlots, accC, unusedW);
+            const S weight = (S(1.0f) * S(1.0f)) * camW;
+            kahanAdd(accR, accC, storageAddend(weight * C, S::N == 3 ? 0.0f : pb.wlOffset[slot]));
+            SpecIO<S>::store(pb.accR, nullptr, slot, rp.numSlots, accR, 0.0f);
+            SpecIO<S>::store(pb.accC, nullptr, slot, rp.numSlots, accC, 0.0f);
             ++sampleIdx;
         }
         const uint32_t stripe = slot / rp.numPixels;
@@ -371,9 +445,11 @@ __global__ __launch_bounds__(kShadeBlock) void k_regen(DevScene sc, PathBuffers 
             (void)time;
             float pxx = px + rng.nextFloat();
             float pyy = py + rng.nextFloat();
-            rng.nextFloat();                                           // wavelength offset (unused in RGB, RGBTypes.h:37-45)
+            // createWithEqualOffsets: RGBTypes.h:37-45 (offset unused, PDF 1) / SpectrumTypes.h:54-64 (PDF N / 470)
+            const float wlOffset = rng.nextFloat();
             float uLambda = rng.nextFloat();
-            const uint32_t wl = min((uint32_t)(uint16_t)(3 * uLambda), 2u);
+            const uint32_t wl = min((uint32_t)(uint16_t)(S::N * uLambda), (uint32_t)(S::N - 1));
+            const float selectWLPDF = S::N == 3 ? 1.0f : S::N / (830.0f - 360.0f);
             float lu0 = rng.nextFloat();
             float lu1 = rng.nextFloat();
             // PerspectiveCamera::sample PerspectiveCamera.cpp:33-57
@@ -394,13 +470,14 @@ __global__ __launch_bounds__(kShadeBlock) void k_regen(DevScene sc, PathBuffers 
             float dirPDF = sc.camera.imgPlaneDistance * sc.camera.imgPlaneDistance /
                            ((dirLocal.z * dirLocal.z * dirLocal.z) * sc.camera.imgPlaneArea);
             V3 rayDir = lf.fromLocal(dirLocal);
-            // weight :126 (selectWLPDF = 1 in RGB mode)
-            float camWeight = absDot(rayDir, lensN) / (sc.camera.areaPDF * dirPDF * 1.0f);
+            // weight :126
+            float camWeight = absDot(rayDir, lensN) / (sc.camera.areaPDF * dirPDF * selectWLPDF);
             pb.flags[slot] = F_MAKE((uint32_t)ST_FIRST_HIT, 0u, wl, 0u, 0u, 0u);
             pb.rng[slot] = make_uint4(rng.s0, rng.s1, rng.s2, rng.s3);
-            pb.alpha[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
-            pb.spR[slot] = make_float4(0.0f, 0.0f, 0.0f, camWeight);
-            pb.spC[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            SpecIO<S>::store(pb.alpha, pb.pdfPrev, slot, rp.numSlots, S(1.0f), 0.0f);
+            SpecIO<S>::store(pb.spR, pb.camWeight, slot, rp.numSlots, S(), camWeight);
+            SpecIO<S>::store(pb.spC, nullptr, slot, rp.numSlots, S(), 0.0f);
+            if (S::N != 3) pb.wlOffset[slot] = wlOffset;
             pb.rayOrg[slot] = make_float4(lensP.x, lensP.y, lensP.z, 0.0f);
             pb.rayDir[slot] = make_float4(rayDir.x, rayDir.y, rayDir.z, INFINITY);
         }
@@ -413,6 +490,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_regen(DevScene sc, PathBuffers 
 
 // Start of a render() call: every slot of the shard enters the regen queue with sample counter 0
 // (accumulators are kept unless asked: render() continues the image begun by render_begin()).
+template <class S>
 __global__ void k_reset_slots(PathBuffers pb, RenderParams rp, uint32_t clearAccumulators) {
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;     // blockDim == kShadeBlock
     if (slot < rp.numSlots) {
@@ -422,8 +500,8 @@ __global__ void k_reset_slots(PathBuffers pb, RenderParams rp, uint32_t clearAcc
         // slot block b goes to region b % kShards at chunk b / kShards, exactly as k_logic would append it
         pb.regenQueue[(size_t)(blockIdx.x % kShards) * rp.shardCapacity + (blockIdx.x / kShards) * kShadeBlock + threadIdx.x] = slot;
         if (clearAccumulators) {
-            pb.accR[slot] = make_float4(0, 0, 0, 0);
-            pb.accC[slot] = make_float4(0, 0, 0, 0);
+            SpecIO<S>::store(pb.accR, nullptr, slot, rp.numSlots, S(), 0.0f);
+            SpecIO<S>::store(pb.accC, nullptr, slot, rp.numSlots, S(), 0.0f);
         }
     }
     if (blockIdx.x == 0) {
@@ -446,42 +524,58 @@ __global__ void k_reset_slots(PathBuffers pb, RenderParams rp, uint32_t clearAcc
     }
 }
 
-// ImageSensor read-out: [H][W][3] linear sums; stripes of one pixel are added in stripe order.
+// ImageSensor read-out: [H][W][N] linear sums; stripes of one pixel are added in stripe order.
+template <class S>
 __global__ void k_resolve(PathBuffers pb, RenderParams rp, float* dst) {
     const uint32_t pix = blockIdx.x * blockDim.x + threadIdx.x;
     if (pix >= rp.numPixels) return;
     const uint32_t xy = pb.pixelXY[pix];
     const uint32_t px = xy & 0xFFFFu, py = xy >> 16;
-    float4 a = pb.accR[pix];
-    RGB sum(a.x, a.y, a.z);
-    for (uint32_t s = 1; s < rp.stripes; ++s) {
-        float4 b = pb.accR[(size_t)s * rp.numPixels + pix];
-        sum = sum + RGB(b.x, b.y, b.z);
+    S sum;
+    float unusedW;
+    SpecIO<S>::load(pb.accR, nullptr, pix, rp.numSlots, sum, unusedW);
+    for (uint32_t st = 1; st < rp.stripes; ++st) {
+        S b;
+        SpecIO<S>::load(pb.accR, nullptr, st * rp.numPixels + pix, rp.numSlots, b, unusedW);
+        sum = sum + b;
     }
-    float* o = dst + ((size_t)py * rp.imageWidth + px) * 3;
-    o[0] = sum.r; o[1] = sum.g; o[2] = sum.b;
+    float* o = dst + ((size_t)py * rp.imageWidth + px) * S::N;
+#pragma unroll
+    for (int i = 0; i < S::N; ++i) o[i] = sum.comp(i);
 }
 
 // ---- host-callable launchers -----------------------------------------------------------------------------------
 void launchResetSlots(const PathBuffers& pb, const RenderParams& rp, bool clearAcc, hipStream_t stream) {
-    hipLaunchKernelGGL(k_reset_slots, dim3((rp.numSlots + kShadeBlock - 1) / kShadeBlock), dim3(kShadeBlock), 0, stream, pb, rp,
-                       clearAcc ? 1u : 0u);
+    const dim3 grid((rp.numSlots + kShadeBlock - 1) / kShadeBlock), block(kShadeBlock);
+    if (rp.spectral) hipLaunchKernelGGL(k_reset_slots<Spec16>, grid, block, 0, stream, pb, rp, clearAcc ? 1u : 0u);
+    else hipLaunchKernelGGL(k_reset_slots<RGB>, grid, block, 0, stream, pb, rp, clearAcc ? 1u : 0u);
 }
 void launchRegen(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, hipStream_t stream) {
     // queue lengths are only known on the device: launch for the worst case, surplus workgroups exit at once
-    hipLaunchKernelGGL(k_regen, dim3(rp.shardCapacity / kShadeBlock * kShards), dim3(kShadeBlock), 0, stream, sc, pb, rp, parity);
+    const dim3 grid(rp.shardCapacity / kShadeBlock * kShards), block(kShadeBlock);
+    if (rp.spectral) hipLaunchKernelGGL(k_regen<Spec16>, grid, block, 0, stream, sc, pb, rp, parity);
+    else hipLaunchKernelGGL(k_regen<RGB>, grid, block, 0, stream, sc, pb, rp, parity);
 }
 void launchLogic(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, hipStream_t stream) {
     const dim3 grid((rp.numSlots + kShadeBlock - 1) / kShadeBlock), block(kShadeBlock);
     const bool ldsTables = sc.numMaterials <= (uint32_t)kLdsMaterials && sc.numLights <= (uint32_t)kLdsLights;
-    // four instantiations: the microfacet (GGX) code costs ~45 VGPRs, so scenes without such lobes get a kernel without it
-    if (ldsTables && !sc.hasMicrofacet) hipLaunchKernelGGL((k_logic<true, false>), grid, block, 0, stream, sc, pb, rp, parity);
-    else if (ldsTables) hipLaunchKernelGGL((k_logic<true, true>), grid, block, 0, stream, sc, pb, rp, parity);
-    else if (!sc.hasMicrofacet) hipLaunchKernelGGL((k_logic<false, false>), grid, block, 0, stream, sc, pb, rp, parity);
-    else hipLaunchKernelGGL((k_logic<false, true>), grid, block, 0, stream, sc, pb, rp, parity);
+    // The microfacet (GGX) code costs ~45 VGPRs, so scenes without such lobes get kernels without it.
+    if (rp.spectral) {
+        if (ldsTables && !sc.hasMicrofacet) hipLaunchKernelGGL((k_logic<Spec16, true, false>), grid, block, 0, stream, sc, pb, rp, parity);
+        else if (ldsTables) hipLaunchKernelGGL((k_logic<Spec16, true, true>), grid, block, 0, stream, sc, pb, rp, parity);
+        else if (!sc.hasMicrofacet) hipLaunchKernelGGL((k_logic<Spec16, false, false>), grid, block, 0, stream, sc, pb, rp, parity);
+        else hipLaunchKernelGGL((k_logic<Spec16, false, true>), grid, block, 0, stream, sc, pb, rp, parity);
+        return;
+    }
+    if (ldsTables && !sc.hasMicrofacet) hipLaunchKernelGGL((k_logic<RGB, true, false>), grid, block, 0, stream, sc, pb, rp, parity);
+    else if (ldsTables) hipLaunchKernelGGL((k_logic<RGB, true, true>), grid, block, 0, stream, sc, pb, rp, parity);
+    else if (!sc.hasMicrofacet) hipLaunchKernelGGL((k_logic<RGB, false, false>), grid, block, 0, stream, sc, pb, rp, parity);
+    else hipLaunchKernelGGL((k_logic<RGB, false, true>), grid, block, 0, stream, sc, pb, rp, parity);
 }
 void launchResolve(const PathBuffers& pb, const RenderParams& rp, float* dst, hipStream_t stream) {
-    hipLaunchKernelGGL(k_resolve, dim3((rp.numPixels + 255) / 256), dim3(256), 0, stream, pb, rp, dst);
+    const dim3 grid((rp.numPixels + 255) / 256), block(256);
+    if (rp.spectral) hipLaunchKernelGGL(k_resolve<Spec16>, grid, block, 0, stream, pb, rp, dst);
+    else hipLaunchKernelGGL(k_resolve<RGB>, grid, block, 0, stream, pb, rp, dst);
 }
 
 } // namespace slrhip

@@ -99,6 +99,9 @@ struct slrhip_ctx {
     DevArray<ShadeTri> shadeTris;
     DevArray<LightTri> lightTris;
     DevArray<DevMaterial> materials;
+    DevArray<DevMaterialS> materialsS;
+    DevArray<DevSpectrum> spectra;
+    DevArray<float> spectrumPool;
     DevArray<float> lightPMF, lightCDF;
     DevScene scene;
     uint32_t bvhDepth = 0;
@@ -111,6 +114,7 @@ struct slrhip_ctx {
     DevArray<uint32_t> pixelXY;
     DevArray<uint4> rng;
     DevArray<float4> rayOrg, rayDir, hit, alpha, spR, spC, accR, accC, nee, shadowDir;
+    DevArray<float> pdfPrev, camWeight, wlOffset;
     DevArray<uint32_t> flags, sampleIdx, visible, shadowQueue, regenQueue, queueCount, activeSlots;
     DevArray<uint64_t> totals;
     DevArray<float> resolveScratch;
@@ -147,8 +151,8 @@ int slrhip_version(void) { return SLRHIP_VERSION; }
 int slrhip_create(const slrhip_config* config, slrhip_ctx** out) {
     if (!config || !out) return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_create: null argument");
     *out = nullptr;
-    if (config->mode != SLRHIP_MODE_RGB)
-        return fail(SLRHIP_ERR_UNSUPPORTED, "slrhip_create: only SLRHIP_MODE_RGB is implemented in this build");
+    if (config->mode != SLRHIP_MODE_RGB && config->mode != SLRHIP_MODE_SPECTRAL)
+        return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_create: unknown mode");
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0)
@@ -189,7 +193,9 @@ int slrhip_upload_scene(slrhip_ctx* ctx, const slrhip_scene_desc* d) {
         if (t.v[0] >= d->num_vertices || t.v[1] >= d->num_vertices || t.v[2] >= d->num_vertices || t.material >= d->num_materials)
             return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: triangle index out of range");
     }
+    const bool spectral = ctx->config.mode == SLRHIP_MODE_SPECTRAL;
     std::vector<DevMaterial> mats(d->num_materials);
+    std::vector<DevMaterialS> matsS(d->num_materials);
     std::vector<char> emitting(d->num_materials, 0);
     for (uint32_t i = 0; i < d->num_materials; ++i) {
         const slrhip_material& m = d->materials[i];
@@ -222,6 +228,34 @@ int slrhip_upload_scene(slrhip_ctx* ctx, const slrhip_scene_desc* d) {
             return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: material without its eta / k spectra");
         emitting[i] = m.emittance >= 0;
         mats[i] = dm;
+        DevMaterialS ds;
+        ds.type = dm.type; ds.param = dm.param; ds.onA = dm.onA; ds.onB = dm.onB;
+        ds.spec[0] = m.spectrum[0]; ds.spec[1] = m.spectrum[1]; ds.spec[2] = m.spectrum[2]; ds.spec[3] = m.emittance;
+        matsS[i] = ds;
+        if (spectral)
+            for (int k = 0; k < 4; ++k)
+                if (ds.spec[k] >= 0 && d->spectra[ds.spec[k]].kind == SLRHIP_SPECTRUM_RGB_ONLY)
+                    return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: spectral mode needs a spectral descriptor for every spectrum in use");
+    }
+    // spectrum table (spectral mode): descriptors + the float pool, bounds-checked here because the kernels index it
+    std::vector<DevSpectrum> devSpectra(d->num_spectra);
+    for (uint32_t i = 0; i < d->num_spectra && spectral; ++i) {
+        const slrhip_spectrum& sp = d->spectra[i];
+        DevSpectrum ds;
+        std::memset(&ds, 0, sizeof(ds));
+        ds.kind = sp.kind; ds.numPoints = sp.reserved; ds.numSamples = sp.num_samples; ds.dataOffset = sp.data_offset;
+        ds.scale = sp.scale; ds.lambdaMin = sp.lambda_min; ds.lambdaMax = sp.lambda_max;
+        size_t need = 0;
+        if (sp.kind == SLRHIP_SPECTRUM_REGULAR) need = sp.num_samples;
+        else if (sp.kind == SLRHIP_SPECTRUM_IRREGULAR) need = 2 * (size_t)sp.num_samples;
+        else if (sp.kind == SLRHIP_SPECTRUM_UPSAMPLED) need = 4 + 4 * (size_t)sp.num_samples;
+        if (sp.kind != SLRHIP_SPECTRUM_RGB_ONLY) {
+            if (sp.num_samples < 2 || (size_t)sp.data_offset + need > d->num_spectrum_data || !d->spectrum_data)
+                return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: spectrum data out of range");
+            if (sp.kind == SLRHIP_SPECTRUM_UPSAMPLED && sp.reserved != 0 && sp.reserved != 3 && sp.reserved != 4)
+                return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: upsampled spectrum must resolve to 0, 3 or 4 points");
+        }
+        devSpectra[i] = ds;
     }
 
     // --- accelerator -------------------------------------------------------------------------------
@@ -302,6 +336,13 @@ int slrhip_upload_scene(slrhip_ctx* ctx, const slrhip_scene_desc* d) {
     HIP_TRY(ctx->shadeTris.upload(shade));
     HIP_TRY(ctx->lightTris.upload(lights));
     HIP_TRY(ctx->materials.upload(mats));
+    HIP_TRY(ctx->materialsS.upload(matsS));
+    HIP_TRY(ctx->spectra.upload(devSpectra));
+    {
+        std::vector<float> pool;
+        if (spectral && d->spectrum_data) pool.assign(d->spectrum_data, d->spectrum_data + d->num_spectrum_data);
+        HIP_TRY(ctx->spectrumPool.upload(pool));
+    }
     HIP_TRY(ctx->lightPMF.upload(pmf));
     HIP_TRY(ctx->lightCDF.upload(cdf));
     DevScene& sc = ctx->scene;
@@ -310,6 +351,9 @@ int slrhip_upload_scene(slrhip_ctx* ctx, const slrhip_scene_desc* d) {
     sc.shadeTris = ctx->shadeTris.ptr;
     sc.lightTris = ctx->lightTris.ptr;
     sc.materials = ctx->materials.ptr;
+    sc.materialsS = ctx->materialsS.ptr;
+    sc.spectra = ctx->spectra.ptr;
+    sc.spectrumPool = ctx->spectrumPool.ptr;
     sc.lightPMF = ctx->lightPMF.ptr;
     sc.lightCDF = ctx->lightCDF.ptr;
     sc.numNodes = (uint32_t)bvh.nodes.size();
@@ -363,12 +407,16 @@ int slrhip_render_begin(slrhip_ctx* ctx, const slrhip_render_settings* st, slrhi
     const size_t numSlots = (size_t)numPixels * stripes;
     if (numSlots > 0x7FFFFFFFull) return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_render_begin: too many path slots");
 
+    const bool spectral = ctx->config.mode == SLRHIP_MODE_SPECTRAL;
+    const size_t planes = spectral ? 4 : 1;
     HIP_TRY(ctx->pixelXY.upload(pixels));
     HIP_TRY(ctx->rng.alloc(numSlots, true));
     HIP_TRY(ctx->rayOrg.alloc(numSlots, true)); HIP_TRY(ctx->rayDir.alloc(numSlots, true)); HIP_TRY(ctx->hit.alloc(numSlots, true));
-    HIP_TRY(ctx->alpha.alloc(numSlots, true)); HIP_TRY(ctx->spR.alloc(numSlots, true)); HIP_TRY(ctx->spC.alloc(numSlots, true));
-    HIP_TRY(ctx->accR.alloc(numSlots, true)); HIP_TRY(ctx->accC.alloc(numSlots, true)); HIP_TRY(ctx->nee.alloc(numSlots, true));
+    HIP_TRY(ctx->alpha.alloc(numSlots * planes, true)); HIP_TRY(ctx->spR.alloc(numSlots * planes, true)); HIP_TRY(ctx->spC.alloc(numSlots * planes, true));
+    HIP_TRY(ctx->accR.alloc(numSlots * planes, true)); HIP_TRY(ctx->accC.alloc(numSlots * planes, true)); HIP_TRY(ctx->nee.alloc(numSlots * planes, true));
     HIP_TRY(ctx->shadowDir.alloc(numSlots, true));
+    HIP_TRY(ctx->pdfPrev.alloc(spectral ? numSlots : 1, true)); HIP_TRY(ctx->camWeight.alloc(spectral ? numSlots : 1, true));
+    HIP_TRY(ctx->wlOffset.alloc(spectral ? numSlots : 1, true));
     HIP_TRY(ctx->flags.alloc(numSlots, true)); HIP_TRY(ctx->sampleIdx.alloc(numSlots, true)); HIP_TRY(ctx->visible.alloc(numSlots, true));
     // queue regions: slot block b appends to region b % kShards, so a region holds at most ceil(numBlocks / kShards) blocks
     const uint32_t numBlocks = (uint32_t)((numSlots + 255) / 256);
@@ -382,7 +430,8 @@ int slrhip_render_begin(slrhip_ctx* ctx, const slrhip_render_settings* st, slrhi
     PathBuffers& pb = ctx->buffers;
     pb.rng = ctx->rng.ptr; pb.rayOrg = ctx->rayOrg.ptr; pb.rayDir = ctx->rayDir.ptr; pb.hit = ctx->hit.ptr;
     pb.alpha = ctx->alpha.ptr; pb.spR = ctx->spR.ptr; pb.spC = ctx->spC.ptr; pb.accR = ctx->accR.ptr; pb.accC = ctx->accC.ptr;
-    pb.nee = ctx->nee.ptr; pb.shadowDir = ctx->shadowDir.ptr; pb.flags = ctx->flags.ptr; pb.sampleIdx = ctx->sampleIdx.ptr;
+    pb.nee = ctx->nee.ptr;
+    pb.pdfPrev = spectral ? ctx->pdfPrev.ptr : nullptr; pb.camWeight = spectral ? ctx->camWeight.ptr : nullptr; pb.wlOffset = ctx->wlOffset.ptr; pb.shadowDir = ctx->shadowDir.ptr; pb.flags = ctx->flags.ptr; pb.sampleIdx = ctx->sampleIdx.ptr;
     pb.visible = ctx->visible.ptr; pb.shadowQueue = ctx->shadowQueue.ptr; pb.regenQueue = ctx->regenQueue.ptr;
     pb.queueCount = ctx->queueCount.ptr; pb.activeSlots = ctx->activeSlots.ptr; pb.totals = ctx->totals.ptr;
     pb.pixelXY = ctx->pixelXY.ptr;
@@ -394,6 +443,7 @@ int slrhip_render_begin(slrhip_ctx* ctx, const slrhip_render_settings* st, slrhi
     rp.imageWidth = W; rp.imageHeight = H;
     rp.countSlots = (ctx->config.flags & SLRHIP_FLAG_COUNT_TRAVERSAL) ? 1u : 0u;
     rp.shardCapacity = shardCapacity;
+    rp.spectral = spectral ? 1u : 0u;
     ctx->samplesDone = 0;
     ctx->settings = *st;
     ctx->shard = shard;
@@ -472,7 +522,7 @@ int slrhip_resolve_framebuffer(slrhip_ctx* ctx, float* deviceDst, size_t numFloa
     if (!ctx || !deviceDst) return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_resolve_framebuffer: null argument");
     if (!ctx->haveRender) return fail(SLRHIP_ERR_NO_SCENE, "slrhip_resolve_framebuffer: nothing rendered");
     const RenderParams& rp = ctx->params;
-    const size_t need = (size_t)rp.imageWidth * rp.imageHeight * 3;
+    const size_t need = (size_t)rp.imageWidth * rp.imageHeight * (rp.spectral ? 16 : 3);
     if (numFloats < need) return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_resolve_framebuffer: destination too small");
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t stream = (hipStream_t)streamPtr;
@@ -486,7 +536,7 @@ int slrhip_read_framebuffer(slrhip_ctx* ctx, float* hostDst, size_t numFloats) {
     if (!ctx || !hostDst) return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_read_framebuffer: null argument");
     if (!ctx->haveRender) return fail(SLRHIP_ERR_NO_SCENE, "slrhip_read_framebuffer: nothing rendered");
     const RenderParams& rp = ctx->params;
-    const size_t need = (size_t)rp.imageWidth * rp.imageHeight * 3;
+    const size_t need = (size_t)rp.imageWidth * rp.imageHeight * (rp.spectral ? 16 : 3);
     if (numFloats < need) return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_read_framebuffer: destination too small");
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(ctx->resolveScratch.alloc(need));

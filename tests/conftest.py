@@ -26,3 +26,19 @@ def ref_rgb():
     if lib is None:
         pytest.skip("oracle/_ref not built (no /root/reference on this machine)")
     return lib
+
+
+@pytest.fixture(scope="session")
+def oracle_spectral():
+    from oracle import binding
+    from slr_amd import abi
+    return binding.load("oracle", abi.MODE_SPECTRAL)
+
+
+@pytest.fixture(scope="session")
+def ref_spectral():
+    from oracle import binding
+    lib = binding.load("ref_spectral")
+    if lib is None:
+        pytest.skip("oracle/_ref not built (no /root/reference on this machine)")
+    return lib

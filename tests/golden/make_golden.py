@@ -41,6 +41,8 @@ def random_rays(rng, n):
 
 
 def make(name, sc, lib, width, height, spp, serial_spp):
+    if lib is None:
+        raise SystemExit("reference library for %s not built" % name)
     ref = lib.scene(sc)
     st = ob.settings(width, height)
     fb, _ = ref.render(st, spp, threads=0)
@@ -89,6 +91,12 @@ def main():
     make("rgb_oren_nayar", scenes.cornell_lobes("oren_nayar"), lib, 40, 40, 8, 2)
     make("rgb_ggx_metal", scenes.cornell_lobes("ggx_metal"), lib, 40, 40, 8, 2)
     make("rgb_ggx_glass", scenes.cornell_lobes("ggx_glass"), lib, 40, 40, 8, 2)
+    spec = ob.load("ref_spectral")
+    make("spectral_cornell_glass", scenes.cornell_box_spheres(1.0, 12, 6, "glass"), spec, 32, 32, 8, 2)
+    make("spectral_cornell_matte", scenes.cornell_box_spheres(1.0, 12, 6, "matte"), spec, 32, 32, 8, 2)
+    make("spectral_oren_nayar", scenes.cornell_lobes("oren_nayar", segments=10, rings=5), spec, 32, 32, 8, 2)
+    make("spectral_ggx_metal", scenes.cornell_lobes("ggx_metal", segments=10, rings=5), spec, 32, 32, 8, 2)
+    make("spectral_ggx_glass", scenes.cornell_lobes("ggx_glass", segments=10, rings=5), spec, 32, 32, 8, 2)
     make("rgb_cornell_matte", scenes.cornell_box_spheres(4.0 / 3.0, 16, 8, "matte"), lib, 48, 36, 8, 2)
 
 

@@ -157,3 +157,43 @@ def test_boxes_scene_against_oracle(ctx, oracle_rgb):
     assert np.isclose(fb, want, rtol=1e-4, atol=1e-9).mean() >= 0.95
     c = ctx.counters()
     assert abs(int(c.extension_rays) - int(ctr.extension_rays)) <= ctr.extension_rays * 1e-3
+
+
+@pytest.fixture(scope="module")
+def sctx():
+    c = Context(device=0, mode=abi.MODE_SPECTRAL, stripes=1)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("name", ["spectral_cornell_glass", "spectral_cornell_matte", "spectral_oren_nayar"])
+def test_spectral_frame_matches_reference_golden(sctx, name):
+    """Spectral mode (16 wavelengths, 16-bin framebuffer) without float-libm lobes: expected bit-exact."""
+    g = load_golden(name)
+    st = ob.settings(int(g["width"]), int(g["height"]), int(g["seed"]))
+    fb = sctx.render_image(scene_from_golden(g), st, int(g["spp"]))
+    assert fb.shape == g["framebuffer"].shape
+    s = frame_stats(fb, g["framebuffer"])
+    assert s["exact_fraction"] >= 0.999, s
+    assert s["rmse"] <= 1e-3 * max(s["mean"], 1e-9), s
+
+
+@pytest.mark.parametrize("name", ["spectral_ggx_metal", "spectral_ggx_glass"])
+def test_spectral_ggx_within_tolerance(sctx, name):
+    g = load_golden(name)
+    st = ob.settings(int(g["width"]), int(g["height"]), int(g["seed"]))
+    fb = sctx.render_image(scene_from_golden(g), st, int(g["spp"]))
+    want = g["framebuffer"]
+    s = frame_stats(fb, want)
+    assert s["rmse"] <= 1e-3 * s["mean"], s
+    assert np.isclose(fb, want, rtol=1e-4, atol=1e-9).mean() >= 0.90
+    assert np.isfinite(fb).all()
+
+
+def test_spectral_mode_rejects_rgb_only_spectra(sctx):
+    from slr_amd.binding import SlrHipError
+    b = scenes.SceneBuilder()
+    scenes.cornell_walls(b)
+    b.add_uv_sphere(8, 4, b.matte(b.spectrum_rgb(0.5, 0.5, 0.5)), scenes._translate(0, 0.5, 0) @ scenes._scale(0.4))
+    with pytest.raises(SlrHipError):
+        sctx.upload_scene(b.build(scenes.cornell_camera(1.0)))

@@ -106,3 +106,23 @@ def test_rejects_bad_scene(oracle_rgb):
     sc = scene_from_golden(g)
     with pytest.raises(ValueError):
         abi.Scene(sc.vertices[:2], sc.triangles, sc.materials, sc.spectra, sc.spectrum_data, sc.camera)
+
+
+SPECTRAL_SCENES = ["spectral_cornell_glass", "spectral_cornell_matte", "spectral_oren_nayar", "spectral_ggx_metal", "spectral_ggx_glass"]
+
+
+@pytest.mark.parametrize("name", SPECTRAL_SCENES)
+def test_spectral_frame_matches_reference(oracle_spectral, name):
+    """16 wavelength samples, upsampled / regular / irregular input spectra, 16-bin storage: every float of the frame."""
+    g = load_golden(name)
+    sc = oracle_spectral.scene(scene_from_golden(g))
+    assert sc.components == 16
+    st = ob.settings(int(g["width"]), int(g["height"]), int(g["seed"]))
+    fb, _ = sc.render(st, int(g["spp"]), threads=0)
+    assert fb.shape[2] == 16
+    assert_bit_equal(fb, g["framebuffer"], name + " framebuffer")
+    for (x, y, p), want in zip(g["sample_picks"][:24], g["sample_values"][:24]):
+        assert_bit_equal(sc.sample(st, int(x), int(y), int(p)), want, "%s sample (%d,%d,%d)" % (name, x, y, p))
+    st2 = ob.settings(int(g["serial_width"]), int(g["serial_height"]), int(g["seed"]))
+    fs, _ = sc.render_serial(st2, int(g["serial_spp"]))
+    assert_bit_equal(fs, g["serial_framebuffer"], name + " serial")

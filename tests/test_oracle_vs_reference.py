@@ -64,3 +64,38 @@ def test_boxes_scene_bit_exact(oracle_rgb, ref_rgb):
     fo, _ = so.render(st, 8)
     fr, _ = sr.render(st, 8)
     assert_bit_equal(fo, fr, "cornell_box_boxes")
+
+
+def test_spectrum_construction_and_evaluation_bit_exact(oracle_spectral, ref_spectral):
+    """a27 + a16: UpsampledContinuousSpectrum constructor (slr_amd/spectra.py) and the per-hit evaluation of all three kinds."""
+    import ctypes as C
+    from slr_amd import abi, spectra
+    up = ref_spectral.lib.slr_ref_upsample
+    up.argtypes = [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p]
+    rng = np.random.default_rng(0)
+    for _ in range(500):
+        e = rng.random(3).astype(np.float32)
+        spt, space = int(rng.integers(0, 2)), int(rng.integers(0, 2))
+        out = np.zeros(3, np.float32)
+        assert up(spt, space, float(e[0]), float(e[1]), float(e[2]), out.ctypes.data) == 0
+        assert_bit_equal(np.array(spectra.upsample(spt, space, *e), np.float32), out, "upsample")
+    sc = scenes.cornell_box_spheres(1.0, 8, 4, "glass")
+    d = sc.desc()
+    fr, fo = ref_spectral.lib.slr_ref_eval_spectrum, oracle_spectral.lib.slr_oracle_eval_spectrum
+    fr.argtypes = fo.argtypes = [C.POINTER(abi.SceneDesc), C.c_uint32, C.c_float, C.c_void_p]
+    assert set(sc.spectra["kind"]) == {abi.SPEC_UPSAMPLED, abi.SPEC_REGULAR, abi.SPEC_IRREGULAR}
+    for idx in range(len(sc.spectra)):
+        for off in rng.random(40).astype(np.float32):
+            a, b = np.zeros(16, np.float32), np.zeros(16, np.float32)
+            assert fr(C.byref(d), idx, float(off), a.ctypes.data) == 0 and fo(C.byref(d), idx, float(off), b.ctypes.data) == 0
+            assert_bit_equal(a, b, "spectrum %d" % idx)
+
+
+@pytest.mark.parametrize("right", ["glass", "matte"])
+def test_spectral_cornell_frame_bit_exact(oracle_spectral, ref_spectral, right):
+    sc = scenes.cornell_box_spheres(4.0 / 3.0, 24, 12, right)
+    so, sr = oracle_spectral.scene(sc), ref_spectral.scene(sc)
+    st = ob.settings(48, 36, seed=4242)
+    fo, _ = so.render(st, 8)
+    fr, _ = sr.render(st, 8)
+    assert_bit_equal(fo, fr, "spectral cornell " + right)
