@@ -141,15 +141,21 @@ typedef struct slrhip_camera {
 } slrhip_camera;
 
 /* ---- environment light ------------------------------------------------------------ */
-/* InfiniteSphereSurfaceObject + IBLEmission (SurfaceObject.cpp:137-222,
- * SurfaceMaterials/IBLEmission.cpp:15-25): a lat-long radiance map, `scale`, and the
- * importance map the reference derives from it (image_textures.cpp:81-134) is rebuilt
- * by the library.  rgb: width*height*3 floats, row-major, row 0 = theta 0 (+Y).
- * In spectral mode `uvs` (width*height*3: u, v, scale per texel) replaces rgb.        */
+/* InfiniteSphereSurfaceObject + IBLEmission over an image texture (SurfaceObject.cpp:137-222,
+ * SurfaceMaterials/IBLEmission.cpp:15-25, Textures/image_textures.cpp:13-79): a lat-long radiance map looked up
+ * at the nearest texel (row 0 = theta 0 = +Y; u = phi / 2 pi), times `scale`, times pi.  RGB mode only.
+ *   texels     : width * height * 3 floats, row-major (the reference stores RGBA16F: use half-representable values)
+ *   importance : map_width * map_height floats = the area-averaged luminance of each map cell, i.e. what
+ *                ImageSpectrumTexture::createIBLImportanceMap's pickFunc computes BEFORE the sin(theta) factor
+ *                (image_textures.cpp:81-132; map = quarter resolution).  It is an input because it is image
+ *                preprocessing (Image2D::areaAverage, Core/Image.cpp:19-120); the library applies sin(theta) and
+ *                builds the RegularConstantContinuous2D exactly like Core/distributions.cpp:127-224.            */
 typedef struct slrhip_envmap {
     uint32_t width, height;
     const float* texels;
     float scale;
+    uint32_t map_width, map_height;
+    const float* importance;
 } slrhip_envmap;
 
 /* ---- scene ----------------------------------------------------------------------- */

@@ -39,7 +39,9 @@
 #include "RNGs/XORShiftRNG.h"
 #include "Renderers/PathTracingRenderer.h"
 #include "Surface/TriangleMesh.h"
+#include "Core/distributions.h"
 #include "SurfaceMaterials/DiffuseEmission.h"
+#include "SurfaceMaterials/IBLEmission.h"
 #include "SurfaceMaterials/MicrofacetSurfaceMaterial.h"
 #include "SurfaceMaterials/basic_SurfaceMaterials.h"
 #include "Textures/constant_textures.h"
@@ -58,7 +60,49 @@ unsigned int std::thread::hardware_concurrency() noexcept {
     return n > 0 ? (unsigned)n : 1u;
 }
 
+// The reference's image texture (Textures/image_textures.cpp) needs OpenEXR's half.h and is not in this build, so the
+// environment map enters libSLR through its public SpectrumTexture interface: nearest-texel lookup written the way
+// ImageSpectrumTexture::evaluate does it (image_textures.cpp:13-20,57-63) over a float array, and the importance map
+// handed to the reference's own RegularConstantContinuous2D with the pick function of image_textures.cpp:131.
+// Everything downstream (InfiniteSphereSurfaceObject, IBLEmission, IBLEDF, Scene::selectLight, the integrator) is
+// reference code.
+class ArrayEnvTexture : public SpectrumTexture {
+    uint32_t m_width, m_height, m_mapWidth, m_mapHeight;
+    std::vector<float> m_texels, m_importance;
+public:
+    ArrayEnvTexture(const slrhip_envmap& e) : m_width(e.width), m_height(e.height), m_mapWidth(e.map_width), m_mapHeight(e.map_height),
+        m_texels(e.texels, e.texels + (size_t)e.width * e.height * 3), m_importance(e.importance, e.importance + (size_t)e.map_width * e.map_height) {}
+    SampledSpectrum evaluate(const SurfacePoint &surfPt, const WavelengthSamples &wls) const override {
+        float u = std::fmod(surfPt.texCoord.u, 1.0f);
+        float v = std::fmod(surfPt.texCoord.v, 1.0f);
+        u += u < 0 ? 1.0f : 0.0f;
+        v += v < 0 ? 1.0f : 0.0f;
+        uint32_t px = std::min((uint32_t)(m_width * u), m_width - 1);
+        uint32_t py = std::min((uint32_t)(m_height * v), m_height - 1);
+        const float* t = &m_texels[((size_t)py * m_width + px) * 3];
+        SampledSpectrum ret;
+#ifndef Use_Spectral_Representation
+        ret.r = t[0]; ret.g = t[1]; ret.b = t[2];
+#else
+        (void)t;
+#endif
+        return ret;
+    }
+    RegularConstantContinuous2D* createIBLImportanceMap() const override {
+        uint32_t mapHeight = m_mapHeight, mapWidth = m_mapWidth;
+        const float* imp = m_importance.data();
+        std::function<float(uint32_t, uint32_t)> pickFunc = [imp, mapHeight, mapWidth](uint32_t x, uint32_t y) -> float {
+            float luminance = imp[(size_t)y * mapWidth + x];
+            return std::sin(M_PI * (y + 0.5f) / mapHeight) * luminance;
+        };
+        return new RegularConstantContinuous2D(mapWidth, mapHeight, pickFunc);
+    }
+};
+
 struct slr_oracle_scene {
+    ArrayEnvTexture* envTexture = nullptr;
+    IBLEmission* envEmission = nullptr;
+    InfiniteSphereSurfaceObject* envSphere = nullptr;
     std::vector<Vertex> vertices;
     std::vector<Triangle> triangles;
     std::vector<SurfaceObject*> objs;
@@ -112,6 +156,8 @@ static InputSpectrum* makeSpectrum(const slrhip_scene_desc* d, const slrhip_spec
 }
 
 extern "C" {
+
+void slr_ref_destroy(slr_oracle_scene* s);
 
 slr_oracle_scene* slr_ref_create(const slrhip_scene_desc* d, int mode) {
     if (!d || d->num_triangles == 0) return nullptr;
@@ -195,12 +241,21 @@ slr_oracle_scene* slr_ref_create(const slrhip_scene_desc* d, int mode) {
     for (int i = 0; i < 16; ++i) { m[i] = c.local_to_world[i]; mi[i] = c.world_to_local[i]; }
     s->cameraTF = new StaticTransform(Matrix4x4(m), Matrix4x4(mi));
     s->camera->setTransform(s->cameraTF);
-    s->scene.build(s->aggregate, nullptr, s->camera);
+    if (d->env) {
+        if (kComponents != 3 || !d->env->texels || !d->env->importance) { slr_ref_destroy(s); return nullptr; }
+        s->envTexture = new ArrayEnvTexture(*d->env);
+        s->envEmission = new IBLEmission(&s->scene, s->envTexture, d->env->scale);      // setEnvironment, API.cpp
+        s->envSphere = new InfiniteSphereSurfaceObject(&s->scene, s->envEmission);
+    }
+    s->scene.build(s->aggregate, s->envSphere, s->camera);
     return s;
 }
 
 void slr_ref_destroy(slr_oracle_scene* s) {
     if (!s) return;
+    delete s->envSphere;
+    delete s->envEmission;
+    delete s->envTexture;
     delete s->camera;
     delete s->cameraTF;
     delete s->aggregate;

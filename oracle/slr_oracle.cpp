@@ -223,6 +223,59 @@ struct Discrete1D {
     }
 };
 
+// Core/distributions.cpp:127-184  RegularConstantContinuous1D (constructed from a pick function)
+struct Continuous1D {
+    std::vector<float> PDF, CDF;
+    float integral = 0.0f;
+    uint32_t numValues = 0;
+    void build(const std::vector<float>& values) {
+        numValues = (uint32_t)values.size();
+        PDF = values;
+        CDF.assign(numValues + 1, 0.0f);
+        Kahan<float> sum;
+        for (uint32_t i = 0; i < numValues; ++i) { sum.add(PDF[i] / numValues); CDF[i + 1] = sum.result; }
+        integral = sum.result;
+        for (uint32_t i = 0; i < numValues; ++i) { PDF[i] /= sum.result; CDF[i + 1] /= sum.result; }
+    }
+    float sample(float u, float* pdf) const {
+        int idx = (int)numValues;
+        for (int d = (int)prevPowerOf2(numValues); d > 0; d >>= 1)
+            if (idx - d > 0 && CDF[idx - d] >= u) idx -= d;
+        --idx;
+        *pdf = PDF[idx];
+        float t = (u - CDF[idx]) / (CDF[idx + 1] - CDF[idx]);
+        return (idx + t) / numValues;
+    }
+    float evaluatePDF(float smp) const { return PDF[(int32_t)(smp * numValues)]; }
+};
+// Core/distributions.cpp:186-224  RegularConstantContinuous2D
+struct Continuous2D {
+    std::vector<Continuous1D> rows;
+    Continuous1D top;
+    void build(uint32_t numD1, uint32_t numD2, const std::vector<float>& values /* [numD2][numD1] */) {
+        rows.resize(numD2);
+        std::vector<float> integrals(numD2);
+        for (uint32_t i = 0; i < numD2; ++i) {
+            rows[i].build(std::vector<float>(values.begin() + (size_t)i * numD1, values.begin() + (size_t)(i + 1) * numD1));
+            integrals[i] = rows[i].integral;
+        }
+        top.build(integrals);
+    }
+    void sample(float u0, float u1, float* d0, float* d1, float* pdf) const {
+        float topPDF;
+        *d1 = top.sample(u1, &topPDF);
+        uint32_t num = (uint32_t)rows.size();
+        uint32_t idx1D = std::min(uint32_t(num * *d1), num - 1);
+        *d0 = rows[idx1D].sample(u0, pdf);
+        *pdf *= topPDF;
+    }
+    float evaluatePDF(float d0, float d1) const {
+        uint32_t num = (uint32_t)rows.size();
+        uint32_t idx1D = std::min(uint32_t(num * d1), num - 1);
+        return top.evaluatePDF(d1) * rows[idx1D].evaluatePDF(d0);
+    }
+};
+
 // ------------------------------------------------------------------------------------------
 // Scene data
 // ------------------------------------------------------------------------------------------
@@ -253,8 +306,10 @@ struct SurfPt {            // Core/geometry.h:239-258
     V3 gNormal;
     float u, v;
     Frame frame;
-    uint32_t tri;          // obj
+    uint32_t tri;          // obj; kEnvObject = the environment sphere
+    float texU, texV;      // texCoord (only the environment texture reads it)
 };
+static const uint32_t kEnvObject = 0xFFFFFFFEu;
 
 struct BVHNode {
     float bmin[3], bmax[3];
@@ -284,6 +339,11 @@ struct slr_oracle_scene {
     std::vector<BVHNode> nodes;
     std::vector<uint32_t> triOrder;
     bool hasEnv;
+    // InfiniteSphereSurfaceObject (SurfaceObject.cpp:137-141): texture, scale, importance distribution
+    uint32_t envWidth = 0, envHeight = 0;
+    std::vector<float> envTexels;
+    float envScale = 1.0f;
+    Continuous2D envDist;
 };
 
 namespace {
@@ -424,18 +484,65 @@ bool aggregateIntersect(const Scene& s, Ray& ray, Isect* isect, slr_oracle_count
     return any;
 }
 
-// Surface/InfiniteSphere.cpp:34-46 is added with the environment light (SLRHIP env, later row).
-
-// Core/SurfaceObject.cpp:408-416  Scene::intersect
+// Core/SurfaceObject.cpp:408-416  Scene::intersect; Surface/InfiniteSphere.cpp:34-46  InfiniteSphere::intersect
 bool sceneIntersect(const Scene& s, Ray& ray, Isect* isect, slr_oracle_counters* ctr) {
     if (ctr) ++ctr->extension_rays;
     if (aggregateIntersect(s, ray, isect, ctr)) return true;
+    if (s.hasEnv) {
+        if (!std::isinf(ray.distMax)) return false;
+        // Vector3::toPolarYUp, BasicTypes/Vector3.h:72-75
+        float theta = std::acos(std::min(1.0f, std::max(-1.0f, ray.dir.y)));
+        float phi = std::fmod((float)(std::atan2(-ray.dir.x, ray.dir.z) + 2 * M_PI), (float)(2 * M_PI));
+        isect->dist = INFINITY;
+        isect->p = ray.dir;
+        isect->gNormal = -ray.dir;
+        isect->u = phi;
+        isect->v = theta;
+        isect->tri = kEnvObject;
+        isect->atInfinity = true;
+        return true;
+    }
     return false;
 }
+
+// ImageSpectrumTexture::evaluate (Textures/image_textures.cpp:13-20,57-63): nearest texel, wrap by fmod
+Spec<3> envTexture(const Scene& s, float tcU, float tcV) {
+    float u = std::fmod(tcU, 1.0f);
+    float v = std::fmod(tcV, 1.0f);
+    u += u < 0 ? 1.0f : 0.0f;
+    v += v < 0 ? 1.0f : 0.0f;
+    uint32_t px = std::min((uint32_t)(s.envWidth * u), s.envWidth - 1);
+    uint32_t py = std::min((uint32_t)(s.envHeight * v), s.envHeight - 1);
+    const float* t = &s.envTexels[((size_t)py * s.envWidth + px) * 3];
+    Spec<3> r; r.c[0] = t[0]; r.c[1] = t[1]; r.c[2] = t[2];
+    return r;
+}
+// IBLEmission::emittance, SurfaceMaterials/IBLEmission.cpp:15-17: M_PI * tex * scale
+Spec<3> envEmittance(const Scene& s, float tcU, float tcV) { return ((float)M_PI * envTexture(s, tcU, tcV)) * s.envScale; }
+Spec<16> envEmittance16(const Scene&, float, float) { return Spec<16>(0.0f); }   // spectral environment maps: not in scope this round
+template <int N> Spec<N> envEmittanceT(const Scene& s, float u, float v);
+template <> Spec<3> envEmittanceT<3>(const Scene& s, float u, float v) { return envEmittance(s, u, v); }
+template <> Spec<16> envEmittanceT<16>(const Scene& s, float u, float v) { return envEmittance16(s, u, v); }
 
 // Surface/TriangleMesh.cpp:180-215  Triangle::getSurfacePoint (+ SingleSurfaceObject :60-63).
 // texCoord / texCoord0Dir are not restated: no texture or anisotropic lobe on this path reads them.
 void getSurfacePoint(const Scene& s, const Isect& isect, SurfPt* sp) {
+    if (isect.tri == kEnvObject) {
+        // InfiniteSphere::getSurfacePoint, Surface/InfiniteSphere.cpp:48-59; texCoord from intersect :43
+        sp->p = isect.p;
+        sp->atInfinity = true;
+        sp->gNormal = isect.gNormal;
+        sp->u = isect.u;
+        sp->v = isect.v;
+        sp->texU = (float)(isect.u / (2 * M_PI));
+        sp->texV = (float)(isect.v / M_PI);
+        V3 tc0(-std::cos(sp->u), 0.0f, -std::sin(sp->u));
+        sp->frame.x = tc0;
+        sp->frame.z = sp->gNormal;
+        sp->frame.y = cross(sp->frame.z, sp->frame.x);
+        sp->tri = kEnvObject;
+        return;
+    }
     sp->p = isect.p;
     sp->atInfinity = false;
     sp->gNormal = isect.gNormal;
@@ -1072,9 +1179,16 @@ BSDF<N> createBSDF(const Scene& s, const SurfPt& sp, const Wls<N>& wls) {
     return f;
 }
 
-inline bool isEmitting(const Scene& s, uint32_t tri) { return s.materials[s.tris[tri].material].emittance >= 0; }
+inline bool isEmitting(const Scene& s, uint32_t tri) { return tri == kEnvObject || s.materials[s.tris[tri].material].emittance >= 0; }
 template <int N>
 inline Spec<N> emittance(const Scene& s, uint32_t tri, const Wls<N>& wls) { return EvalSpectrum<N>::eval(s, s.materials[s.tris[tri].material].emittance, wls); }
+// SurfacePoint::emittance x EDF::evaluate for either kind of emitter: DiffuseEDF (basic_EDFs.cpp:19-23) for triangles,
+// IBLEDF::evaluate (EDFs/IBLEDF.cpp:19-23: 1 / pi in every direction) for the environment sphere.
+template <int N>
+inline Spec<N> emittedRadiance(const Scene& s, const SurfPt& sp, const Wls<N>& wls, V3 dirLocal) {
+    if (sp.tri == kEnvObject) return envEmittanceT<N>(s, sp.texU, sp.texV) * Spec<N>((float)(1.0f / M_PI));
+    return emittance(s, sp.tri, wls) * Spec<N>(dirLocal.z > 0.0f ? (float)(1.0f / M_PI) : 0.0f);
+}
 // EDFs/basic_EDFs.cpp:19-23  DiffuseEDF::evaluate: `dir.z > 0 ? 1.0f / M_PI : 0.0f` (double) -> SampledSpectrum(float)
 template <int N>
 inline Spec<N> diffuseEDFEvaluate(V3 dir) { return Spec<N>(dir.z > 0.0f ? (float)(1.0f / M_PI) : 0.0f); }
@@ -1113,15 +1227,74 @@ inline V3 mulNormal(const float* mi, V3 n) {  // Transform.h:47-52 (rows of the 
 // ------------------------------------------------------------------------------------------
 // Scene light selection (Core/SurfaceObject.cpp:279-299, 432-466)
 // ------------------------------------------------------------------------------------------
-inline uint32_t selectLight(const Scene& s, float u, float* prob) {
+inline uint32_t aggregateSelectLight(const Scene& s, float u, float* prob) {   // SurfaceObject.cpp:279-286
     uint32_t lIdx = s.lightDist.sample(u, prob);      // remapped u is unused by SingleSurfaceObject::selectLight
     *prob *= 1.0f;                                    // cProb = 1 (SurfaceObject.cpp:73-76)
     return s.lightTris[lIdx];
 }
+// Scene::selectLight, SurfaceObject.cpp:432-450.  Returns a triangle index or kEnvObject.
+inline uint32_t selectLight(const Scene& s, float u, float* prob) {
+    if (s.hasEnv) {
+        const float aggImp = s.lightDist.integral, envImp = 1.0f;      // importance(): :275-277, :154-156
+        float sumImps = aggImp + envImp;
+        float su = sumImps * u;
+        if (su < aggImp) {
+            u = u / (aggImp / sumImps);
+            uint32_t t = aggregateSelectLight(s, u, prob);
+            *prob *= aggImp / sumImps;
+            return t;
+        }
+        else {
+            // u = (u - aggImp) / (envImp / sumImps): the reference's (un-normalised) remap is unused by the sphere
+            *prob = 1.0f;                              // SingleSurfaceObject::selectLight :73-76
+            *prob *= envImp / sumImps;
+            return kEnvObject;
+        }
+    }
+    return aggregateSelectLight(s, u, prob);
+}
+// Scene::evaluateProb, SurfaceObject.cpp:452-466
 inline float evaluateLightProb(const Scene& s, uint32_t tri) {
+    if (s.hasEnv) {
+        const float aggImp = s.lightDist.integral, envImp = 1.0f;
+        float sumImps = aggImp + envImp;
+        if (tri == kEnvObject) return envImp / sumImps;
+        int32_t li = s.tris[tri].lightIndex;
+        float aggProb = li < 0 ? 0.0f : s.lightDist.PMF[li] * 1.0f;
+        return aggImp / sumImps * aggProb;
+    }
     int32_t li = s.tris[tri].lightIndex;
     if (li < 0) return 0.0f;
     return s.lightDist.PMF[li] * 1.0f;
+}
+
+// InfiniteSphereSurfaceObject::sample, SurfaceObject.cpp:158-185 (returns the emittance M)
+template <int N>
+Spec<N> envSample(const Scene& s, float u0, float u1, SurfPt* sp, float* areaPDF) {
+    float uvPDF, theta, phi;
+    s.envDist.sample(u0, u1, &phi, &theta, &uvPDF);
+    phi = (float)(phi * (2 * M_PI));
+    theta = (float)(theta * M_PI);
+    sp->p = V3(-std::sin(phi) * std::sin(theta), std::cos(theta), std::cos(phi) * std::sin(theta));
+    sp->atInfinity = true;
+    sp->gNormal = -sp->p;
+    sp->u = phi;
+    sp->v = theta;
+    sp->texU = (float)(phi / (2 * M_PI));
+    sp->texV = (float)(theta / M_PI);
+    V3 tc0 = normalize(V3(-std::cos(phi), 0.0f, -std::sin(phi)));
+    sp->frame.x = tc0;
+    sp->frame.z = sp->gNormal;
+    sp->frame.y = cross(sp->frame.z, sp->frame.x);
+    sp->tri = kEnvObject;
+    *areaPDF = (float)(uvPDF / (2 * M_PI * M_PI * std::sin(theta)));
+    return envEmittanceT<N>(s, sp->texU, sp->texV);
+}
+// InfiniteSphereSurfaceObject::evaluateAreaPDF, SurfaceObject.cpp:217-222
+inline float envEvaluateAreaPDF(const Scene& s, const SurfPt& sp) {
+    float phi = sp.u, theta = sp.v;
+    float uvPDF = s.envDist.evaluatePDF((float)(phi / (2 * M_PI)), (float)(theta / M_PI));
+    return (float)(uvPDF / (2 * M_PI * M_PI * std::sin(theta)));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1144,7 +1317,7 @@ Spec<N> contribution(const Scene& scene, const Wls<N>& initWLs, const Ray& initR
 
     V3 dirOut_sn = surfPt.frame.toLocal(-ray.dir);
     if (isEmitting(scene, surfPt.tri)) {
-        Spec<N> Le = emittance(scene, surfPt.tri, wls) * diffuseEDFEvaluate<N>(dirOut_sn);
+        Spec<N> Le = emittedRadiance(scene, surfPt, wls, dirOut_sn);
         sp.add(alpha * Le);
     }
     if (surfPt.atInfinity) return sp.result;
@@ -1165,18 +1338,27 @@ Spec<N> contribution(const Scene& scene, const Wls<N>& initWLs, const Ray& initR
             float lu0 = rng.getFloat0cTo1o();
             float lu1 = rng.getFloat0cTo1o();
             SurfPt lp; float areaPDF;
-            triSample(scene, lightTri, lu0, lu1, &lp, &areaPDF);
-            Spec<N> M = emittance(scene, lightTri, wls);                    // SingleSurfaceObject::sample :82-91
+            Spec<N> M;
+            if (lightTri == kEnvObject) M = envSample<N>(scene, lu0, lu1, &lp, &areaPDF);
+            else {
+                triSample(scene, lightTri, lu0, lu1, &lp, &areaPDF);
+                M = emittance(scene, lightTri, wls);                       // SingleSurfaceObject::sample :82-91
+            }
 
             if (testVisibility(scene, surfPt, lp, ctr)) {
                 // SurfacePoint::getDirectionFrom geometry.cpp:32-43
-                V3 d = lp.p - surfPt.p;
-                float dist2 = sqLength(d);
-                V3 shadowDir = d / std::sqrt(dist2);
+                float dist2;
+                V3 shadowDir;
+                if (lp.atInfinity) { dist2 = 1.0f; shadowDir = normalize(lp.p); }
+                else {
+                    V3 d = lp.p - surfPt.p;
+                    dist2 = sqLength(d);
+                    shadowDir = d / std::sqrt(dist2);
+                }
                 V3 shadowDir_l = lp.frame.toLocal(-shadowDir);
                 V3 shadowDir_sn = surfPt.frame.toLocal(shadowDir);
 
-                Spec<N> Le = M * diffuseEDFEvaluate<N>(shadowDir_l);
+                Spec<N> Le = lp.atInfinity ? M * Spec<N>((float)(1.0f / M_PI)) : M * diffuseEDFEvaluate<N>(shadowDir_l);
                 float lightPDF = lightProb * areaPDF;
 
                 Spec<N> fs = bsdfEvaluate(bsdf, fsQuery, shadowDir_sn);
@@ -1218,10 +1400,11 @@ Spec<N> contribution(const Scene& scene, const Wls<N>& initWLs, const Ray& initR
         // implicit light sampling :232-249
         if (isEmitting(scene, surfPt.tri)) {
             float bsdfPDF = fsResult.dirPDF;
-            Spec<N> Le = emittance(scene, surfPt.tri, wls) * diffuseEDFEvaluate<N>(dirOut_sn);
+            Spec<N> Le = emittedRadiance(scene, surfPt, wls, dirOut_sn);
             float lightProb = evaluateLightProb(scene, surfPt.tri);
-            float dist2 = sqLength(ray.org - surfPt.p);                    // sqDistance(p, shadingPoint)
-            float lightPDF = lightProb * (1.0f / triArea(scene, surfPt.tri)) * dist2 / absDot(ray.dir, surfPt.gNormal);
+            float dist2 = surfPt.atInfinity ? 1.0f : sqLength(ray.org - surfPt.p);   // getSquaredDistance geometry.h:249
+            float areaPDFhit = surfPt.atInfinity ? envEvaluateAreaPDF(scene, surfPt) : (1.0f / triArea(scene, surfPt.tri));
+            float lightPDF = lightProb * areaPDFhit * dist2 / absDot(ray.dir, surfPt.gNormal);
             float MISWeight = 1.0f;
             if (!dtIsDelta(fsResult.dirType))
                 MISWeight = (bsdfPDF * bsdfPDF) / (lightPDF * lightPDF + bsdfPDF * bsdfPDF);
@@ -1357,6 +1540,22 @@ slr_oracle_scene* slr_oracle_create(const slrhip_scene_desc* d, int mode) {
     }
     s->lightDist.build(importances);
     s->hasEnv = d->env != nullptr;
+    if (d->env) {
+        const slrhip_envmap& e = *d->env;
+        if (mode != SLRHIP_MODE_RGB || !e.texels || !e.importance || e.width == 0 || e.height == 0 || e.map_width == 0 || e.map_height == 0) {
+            delete s;
+            return nullptr;
+        }
+        s->envWidth = e.width; s->envHeight = e.height; s->envScale = e.scale;
+        s->envTexels.assign(e.texels, e.texels + (size_t)e.width * e.height * 3);
+        // createIBLImportanceMap's pickFunc, image_textures.cpp:131: sin(M_PI * (y + 0.5f) / mapHeight) * luminance
+        std::vector<float> values((size_t)e.map_width * e.map_height);
+        for (uint32_t y = 0; y < e.map_height; ++y)
+            for (uint32_t x = 0; x < e.map_width; ++x)
+                values[(size_t)y * e.map_width + x] =
+                    (float)(std::sin(M_PI * (y + 0.5f) / e.map_height) * e.importance[(size_t)y * e.map_width + x]);
+        s->envDist.build(e.map_width, e.map_height, values);
+    }
     setupCamera(s->camera, d->camera);
     buildBVH(*s);
     return s;

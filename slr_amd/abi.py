@@ -35,7 +35,8 @@ class Camera(C.Structure):
 
 
 class EnvMap(C.Structure):
-    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("texels", C.c_void_p), ("scale", C.c_float)]
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("texels", C.c_void_p), ("scale", C.c_float),
+                ("map_width", C.c_uint32), ("map_height", C.c_uint32), ("importance", C.c_void_p)]
 
 
 class SceneDesc(C.Structure):
@@ -91,10 +92,12 @@ class Scene:
         self.env_texels = None
         self.env = None
         if env is not None:
-            texels, scale = env
+            texels, scale, importance = env
             self.env_texels = np.ascontiguousarray(texels, dtype=np.float32)
-            self.env = EnvMap(self.env_texels.shape[1], self.env_texels.shape[0],
-                              self.env_texels.ctypes.data, float(scale))
+            self.env_importance = np.ascontiguousarray(importance, dtype=np.float32)
+            self.env_scale = float(scale)
+            self.env = EnvMap(self.env_texels.shape[1], self.env_texels.shape[0], self.env_texels.ctypes.data, float(scale),
+                              self.env_importance.shape[1], self.env_importance.shape[0], self.env_importance.ctypes.data)
         self.name = name
         self._validate()
 
@@ -102,6 +105,8 @@ class Scene:
         nv, nm, ns = len(self.vertices), len(self.materials), len(self.spectra)
         if len(self.triangles) == 0:
             raise ValueError("scene has no triangles")
+        if self.env is not None and (self.env_texels.ndim != 3 or self.env_texels.shape[2] != 3):
+            raise ValueError("environment texels must be [height][width][3]")
         if self.triangles["v"].max() >= nv:
             raise ValueError("triangle references a vertex out of range")
         if self.triangles["material"].max() >= nm:

@@ -24,6 +24,16 @@ struct DevScene {
     uint32_t numLights;
     uint32_t lightPow2;           // prevPowerOf2(numLights)
     uint32_t hasMicrofacet;       // any SLRHIP_MATERIAL_MICROFACET_* in the scene
+    // environment sphere (InfiniteSphereSurfaceObject, SurfaceObject.cpp:137-222); RGB mode
+    uint32_t hasEnv;
+    uint32_t envWidth, envHeight, envMapWidth, envMapHeight;
+    float envScale;
+    float aggImportance;          // SurfaceObjectAggregate::importance() = integral of the light list distribution
+    const float* envTexels;       // [height][width][3]
+    const float* envTopPDF;       // RegularConstantContinuous2D: top distribution over rows (mapHeight, +1 for the CDF)
+    const float* envTopCDF;
+    const float* envRowPDF;       // [mapHeight][mapWidth]
+    const float* envRowCDF;       // [mapHeight][mapWidth + 1]
     DevCamera camera;
 };
 

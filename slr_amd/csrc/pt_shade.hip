@@ -151,6 +151,44 @@ __device__ __forceinline__ uint32_t selectLight(const DevScene& sc, const float*
     return (uint32_t)idx;
 }
 
+// ---- environment sphere (RGB mode) ---------------------------------------------------------------------------------------
+// RegularConstantContinuous1D::sample, Core/distributions.cpp:168-179
+__device__ __forceinline__ float sampleContinuous1D(const float* cdf, const float* pdfTable, uint32_t numValues, float u, float* pdf) {
+    int idx = (int)numValues;
+    uint32_t p2 = numValues;
+    p2 |= p2 >> 1; p2 |= p2 >> 2; p2 |= p2 >> 4; p2 |= p2 >> 8; p2 |= p2 >> 16; p2 -= p2 >> 1;       // prevPowerOf2
+    for (int d = (int)p2; d > 0; d >>= 1)
+        if (idx - d > 0 && cdf[idx - d] >= u) idx -= d;
+    --idx;
+    *pdf = pdfTable[idx];
+    float t = (u - cdf[idx]) / (cdf[idx + 1] - cdf[idx]);
+    return ((float)idx + t) / (float)numValues;
+}
+// ImageSpectrumTexture::evaluate (Textures/image_textures.cpp:13-20,57-63) + IBLEmission::emittance (IBLEmission.cpp:15-17)
+__device__ __forceinline__ RGB envEmittance(const DevScene& sc, float tcU, float tcV) {
+    float u = fmodf(tcU, 1.0f);
+    float v = fmodf(tcV, 1.0f);
+    u += u < 0 ? 1.0f : 0.0f;
+    v += v < 0 ? 1.0f : 0.0f;
+    uint32_t px = min((uint32_t)((float)sc.envWidth * u), sc.envWidth - 1);
+    uint32_t py = min((uint32_t)((float)sc.envHeight * v), sc.envHeight - 1);
+    const float* t = sc.envTexels + ((size_t)py * sc.envWidth + px) * 3;
+    return ((float)kPi * RGB(t[0], t[1], t[2])) * sc.envScale;
+}
+template <class S> __device__ __forceinline__ S envEmittanceS(const DevScene& sc, float u, float v);
+template <> __device__ __forceinline__ RGB envEmittanceS<RGB>(const DevScene& sc, float u, float v) { return envEmittance(sc, u, v); }
+template <> __device__ __forceinline__ Spec16 envEmittanceS<Spec16>(const DevScene&, float, float) { return Spec16(); }   // rejected at upload
+// InfiniteSphereSurfaceObject::evaluateAreaPDF, SurfaceObject.cpp:217-222 (RegularConstantContinuous2D::evaluatePDF :218-224)
+__device__ __forceinline__ float envAreaPDF(const DevScene& sc, float phi, float theta) {
+    float d0 = (float)((double)phi / (2 * kPi)), d1 = (float)((double)theta / kPi);
+    uint32_t idx1D = min((uint32_t)((float)sc.envMapHeight * d1), sc.envMapHeight - 1);
+    // the reference indexes with no clamp; phi / 2pi can round up to 1.0f, which would read past the table
+    uint32_t iTop = min((uint32_t)(int32_t)(d1 * (float)sc.envMapHeight), sc.envMapHeight - 1);
+    uint32_t iRow = min((uint32_t)(int32_t)(d0 * (float)sc.envMapWidth), sc.envMapWidth - 1);
+    float uvPDF = sc.envTopPDF[iTop] * sc.envRowPDF[(size_t)idx1D * sc.envMapWidth + iRow];
+    return (float)((double)uvPDF / (2 * kPi * kPi * (double)sinf(theta)));
+}
+
 struct ShadeLds {
     float4 mats[kLdsMaterials * 5];        // DevMaterial = 5 x float4
     float4 lights[kLdsLights * 9];         // LightTri   = 9 x float4
@@ -224,6 +262,29 @@ __global__ __launch_bounds__(kShadeBlock) void k_logic(DevScene sc, PathBuffers 
             Mat<S> m;
             if (!hasHit) {
                 finish = true;                      // ST_FINISH, or a miss: :148 return Zero / :226 break
+                if (state != ST_FINISH && sc.hasEnv) {
+                    // the ray left the scene: Scene::intersect falls through to the environment sphere (SurfaceObject.cpp:411-414).
+                    // InfiniteSphere::intersect / getSurfacePoint (Surface/InfiniteSphere.cpp:34-59), Vector3::toPolarYUp (Vector3.h:72-75)
+                    float theta = acosf(fminf(1.0f, fmaxf(-1.0f, rayDir.y)));
+                    float phi = fmodf((float)((double)atan2f(-rayDir.x, rayDir.z) + 2 * kPi), (float)(2 * kPi));
+                    float texU = (float)((double)phi / (2 * kPi)), texV = (float)((double)theta / kPi);
+                    // emittance x IBLEDF::evaluate = 1 / pi (EDFs/IBLEDF.cpp:19-23)
+                    S Le = envEmittanceS<S>(sc, texU, texV) * S((float)(1.0 / kPi));
+                    if (state == ST_FIRST_HIT) {
+                        kahanAdd(spR, spC, alpha * Le);                        // :152-157, atInfinity -> return sp
+                    }
+                    else {
+                        // implicit light sampling :232-250; the path ends at infinity before Russian roulette
+                        float sumImps = sc.aggImportance + 1.0f;
+                        float lightProb = 1.0f / sumImps;                        // Scene::evaluateProb SurfaceObject.cpp:456-457
+                        V3 gN = -rayDir;
+                        float lightPDF = lightProb * envAreaPDF(sc, phi, theta) * 1.0f / absDot(rayDir, gN);
+                        float MISWeight = 1.0f;
+                        if (!F_DELTA(flags))
+                            MISWeight = (bsdfPDFprev * bsdfPDFprev) / (lightPDF * lightPDF + bsdfPDFprev * bsdfPDFprev);
+                        kahanAdd(spR, spC, alpha * Le * MISWeight);
+                    }
+                }
             }
             else {
                 // Triangle::getSurfacePoint, Surface/TriangleMesh.cpp:180-215.  isect.p = org + dir * t (:170)
@@ -250,6 +311,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_logic(DevScene sc, PathBuffers 
                     else {
                         // implicit light sampling with MIS :232-249
                         float lightProb = lightPMF[surf.light] * 1.0f;          // SurfaceObject.cpp:295-298, :78-80
+                        if (sc.hasEnv) lightProb = sc.aggImportance / (sc.aggImportance + 1.0f) * lightProb;   // Scene::evaluateProb :459
                         float dist2 = sqLength(rayOrg - surf.p);
                         float lightPDF = lightProb * surf.areaPDF * dist2 / absDot(rayDir, surf.gNormal);
                         float MISWeight = 1.0f;
@@ -277,39 +339,83 @@ __global__ __launch_bounds__(kShadeBlock) void k_logic(DevScene sc, PathBuffers 
                     V3 gNorm_sn = surf.frame.toLocal(surf.gNormal);
                     uint32_t type = bsdfType(m.type, wlSel);
                     if (dtMatches(type, DT_WholeSphere | DT_NonDelta)) {
+                        // Scene::selectLight, SurfaceObject.cpp:432-450 (+ aggregate :279-286)
                         float lightProb;
-                        uint32_t li = selectLight(sc, lightCDF, lightPMF, rng.nextFloat(), &lightProb);
-                        lightProb *= 1.0f;
+                        float uSel = rng.nextFloat();
+                        bool pickEnv = false;
+                        if (sc.hasEnv) {
+                            float sumImps = sc.aggImportance + 1.0f;
+                            float su = sumImps * uSel;
+                            if (su < sc.aggImportance) uSel = uSel / (sc.aggImportance / sumImps);
+                            else pickEnv = true;
+                        }
                         float lu0 = rng.nextFloat();
                         float lu1 = rng.nextFloat();
-                        // Triangle::sample TriangleMesh.cpp:224-255
-                        const float4* lt = (LDS_TABLES ? lds.lights : reinterpret_cast<const float4*>(sc.lightTris)) + (size_t)li * 9;
-                        float4 l0 = lt[0], l1 = lt[1], l2 = lt[2], l3 = lt[3], l4 = lt[4], l5 = lt[5], l6 = lt[6], l7 = lt[7], l8 = lt[8];
-                        float su1 = sqrtf(lu0);
-                        float b0 = 1.0f - su1;
-                        float b1 = lu1 * su1;
-                        float b2 = 1.0f - b0 - b1;
-                        V3 lp = b0 * xyz(l0) + b1 * xyz(l1) + b2 * xyz(l2);
-                        V3 lgn(l3.w, l4.w, l5.w);
+                        V3 lp, lgn;
                         Frame lf;
-                        lf.z = normalize(b0 * xyz(l3) + b1 * xyz(l4) + b2 * xyz(l5));
-                        lf.x = normalize(b0 * xyz(l6) + b1 * xyz(l7) + b2 * xyz(l8));
-                        lf.y = cross(lf.z, lf.x);
-                        float areaPDF = l2.w;
-                        const uint32_t lmat = __float_as_uint(l1.w);
-                        S M = MatIO<S>::template emittance<LDS_TABLES>(sc, lds.mats, lmat, wlOffset);
-                        // shadow ray of Scene::testVisibility SurfaceObject.cpp:425-426
-                        float dist = length(surf.p - lp);
-                        V3 sdir = (lp - surf.p) / dist;
-                        pb.shadowDir[slot] = make_float4(sdir.x, sdir.y, sdir.z, dist * (1 - kRayEpsilon));
+                        float areaPDF;
+                        S M;
+                        float shadowTmax;
+                        V3 sdir;
+                        if (pickEnv) {
+                            lightProb = 1.0f * (1.0f / (sc.aggImportance + 1.0f));
+                            // InfiniteSphereSurfaceObject::sample, SurfaceObject.cpp:158-185
+                            float topPDF, rowPDF;
+                            float d1 = sampleContinuous1D(sc.envTopCDF, sc.envTopPDF, sc.envMapHeight, lu1, &topPDF);
+                            uint32_t idx1D = min((uint32_t)((float)sc.envMapHeight * d1), sc.envMapHeight - 1);
+                            float d0 = sampleContinuous1D(sc.envRowCDF + (size_t)idx1D * (sc.envMapWidth + 1), sc.envRowPDF + (size_t)idx1D * sc.envMapWidth,
+                                                          sc.envMapWidth, lu0, &rowPDF);
+                            float uvPDF = rowPDF * topPDF;
+                            float phi = (float)((double)d0 * (2 * kPi));
+                            float theta = (float)((double)d1 * kPi);
+                            lp = V3(-sinf(phi) * sinf(theta), cosf(theta), cosf(phi) * sinf(theta));
+                            lgn = -lp;
+                            lf.x = normalize(V3(-cosf(phi), 0.0f, -sinf(phi)));
+                            lf.z = lgn;
+                            lf.y = cross(lf.z, lf.x);
+                            areaPDF = (float)((double)uvPDF / (2 * kPi * kPi * (double)sinf(theta)));
+                            M = envEmittanceS<S>(sc, (float)((double)phi / (2 * kPi)), (float)((double)theta / kPi));
+                            sdir = normalize(lp);                              // Scene::testVisibility :421-423: [eps, FLT_MAX]
+                            shadowTmax = 3.402823466e+38f;
+                        }
+                        else {
+                            uint32_t li = selectLight(sc, lightCDF, lightPMF, uSel, &lightProb);
+                            lightProb *= 1.0f;
+                            if (sc.hasEnv) lightProb *= sc.aggImportance / (sc.aggImportance + 1.0f);
+                            // Triangle::sample TriangleMesh.cpp:224-255
+                            const float4* lt = (LDS_TABLES ? lds.lights : reinterpret_cast<const float4*>(sc.lightTris)) + (size_t)li * 9;
+                            float4 l0 = lt[0], l1 = lt[1], l2 = lt[2], l3 = lt[3], l4 = lt[4], l5 = lt[5], l6 = lt[6], l7 = lt[7], l8 = lt[8];
+                            float su1 = sqrtf(lu0);
+                            float b0 = 1.0f - su1;
+                            float b1 = lu1 * su1;
+                            float b2 = 1.0f - b0 - b1;
+                            lp = b0 * xyz(l0) + b1 * xyz(l1) + b2 * xyz(l2);
+                            lgn = V3(l3.w, l4.w, l5.w);
+                            lf.z = normalize(b0 * xyz(l3) + b1 * xyz(l4) + b2 * xyz(l5));
+                            lf.x = normalize(b0 * xyz(l6) + b1 * xyz(l7) + b2 * xyz(l8));
+                            lf.y = cross(lf.z, lf.x);
+                            areaPDF = l2.w;
+                            const uint32_t lmat = __float_as_uint(l1.w);
+                            M = MatIO<S>::template emittance<LDS_TABLES>(sc, lds.mats, lmat, wlOffset);
+                            // shadow ray of Scene::testVisibility SurfaceObject.cpp:425-426
+                            float dist = length(surf.p - lp);
+                            sdir = (lp - surf.p) / dist;
+                            shadowTmax = dist * (1 - kRayEpsilon);
+                        }
+                        pb.shadowDir[slot] = make_float4(sdir.x, sdir.y, sdir.z, shadowTmax);
                         emitShadow = true;
                         // contribution if visible :181-202
-                        V3 dvec = lp - surf.p;
-                        float dist2 = sqLength(dvec);
-                        V3 shadowDir = dvec / sqrtf(dist2);
+                        float dist2;
+                        V3 shadowDir;
+                        if (pickEnv) { dist2 = 1.0f; shadowDir = normalize(lp); }   // SurfacePoint::getDirectionFrom geometry.cpp:32-37
+                        else {
+                            V3 dvec = lp - surf.p;
+                            dist2 = sqLength(dvec);
+                            shadowDir = dvec / sqrtf(dist2);
+                        }
                         V3 shadowDir_l = lf.toLocal(-shadowDir);
                         V3 shadowDir_sn = surf.frame.toLocal(shadowDir);
-                        S Le = M * S(diffuseEDF(shadowDir_l));
+                        S Le = M * S(pickEnv ? (float)(1.0 / kPi) : diffuseEDF(shadowDir_l));
                         float lightPDF = lightProb * areaPDF;
                         float pdfDir;
                         S fs = bsdfEvaluate<S, MF>(m, type, dirOut_sn, gNorm_sn, shadowDir_sn, wl, &pdfDir);

@@ -103,6 +103,7 @@ struct slrhip_ctx {
     DevArray<DevSpectrum> spectra;
     DevArray<float> spectrumPool;
     DevArray<float> lightPMF, lightCDF;
+    DevArray<float> envTexels, envTopPDF, envTopCDF, envRowPDF, envRowCDF;
     DevScene scene;
     uint32_t bvhDepth = 0;
     double buildSeconds = 0.0;
@@ -183,7 +184,14 @@ int slrhip_upload_scene(slrhip_ctx* ctx, const slrhip_scene_desc* d) {
     if (!ctx || !d) return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: null argument");
     if (!d->vertices || !d->triangles || !d->materials || !d->spectra || d->num_triangles == 0 || d->num_vertices == 0)
         return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: empty scene");
-    if (d->env) return fail(SLRHIP_ERR_UNSUPPORTED, "slrhip_upload_scene: environment light not implemented in this build");
+    if (d->env) {
+        const slrhip_envmap& e = *d->env;
+        if (ctx->config.mode != SLRHIP_MODE_RGB)
+            return fail(SLRHIP_ERR_UNSUPPORTED, "slrhip_upload_scene: the environment light is implemented for RGB mode only");
+        if (!e.texels || !e.importance || e.width == 0 || e.height == 0 || e.map_width == 0 || e.map_height == 0 ||
+            e.width > 32768 || e.height > 32768 || e.map_width > 32768 || e.map_height > 32768)
+            return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: bad environment map");
+    }
     HIP_TRY(hipSetDevice(ctx->device));
     auto t0 = std::chrono::steady_clock::now();
 
@@ -269,6 +277,7 @@ int slrhip_upload_scene(slrhip_ctx* ctx, const slrhip_scene_desc* d) {
     std::vector<ShadeTri> shade(d->num_triangles);
     std::vector<LightTri> lights;
     std::vector<float> importances;
+    float lightIntegral = 0.0f;
     for (uint32_t i = 0; i < d->num_triangles; ++i) {
         const slrhip_triangle& t = d->triangles[i];
         const slrhip_vertex &v0 = d->vertices[t.v[0]], &v1 = d->vertices[t.v[1]], &v2 = d->vertices[t.v[2]];
@@ -305,7 +314,7 @@ int slrhip_upload_scene(slrhip_ctx* ctx, const slrhip_scene_desc* d) {
         }
         shade[i] = s;
     }
-    if (lights.empty()) return fail(SLRHIP_ERR_UNSUPPORTED, "slrhip_upload_scene: scene has no emitting triangle");
+    if (lights.empty() && !d->env) return fail(SLRHIP_ERR_UNSUPPORTED, "slrhip_upload_scene: scene has no emitting triangle and no environment light");
 
     // RegularConstantDiscrete1D ctor, Core/distributions.cpp:76-95
     std::vector<float> pmf = importances, cdf(importances.size() + 1, 0.0f);
@@ -313,7 +322,38 @@ int slrhip_upload_scene(slrhip_ctx* ctx, const slrhip_scene_desc* d) {
         KahanF sum;
         for (size_t i = 0; i < pmf.size(); ++i) { sum.add(pmf[i]); cdf[i + 1] = sum.result; }
         float integral = sum.result;
+        lightIntegral = integral;
         for (size_t i = 0; i < pmf.size(); ++i) { pmf[i] /= integral; cdf[i + 1] /= integral; }
+    }
+
+    // --- environment sphere: texels + the importance distribution -------------------------------------------
+    // InfiniteSphereSurfaceObject ctor (SurfaceObject.cpp:137-141) -> IBLEmission::createIBLImportanceMap
+    // (IBLEmission.cpp:11-13) -> RegularConstantContinuous2D (Core/distributions.cpp:186-212) over
+    // sin(pi (y + 0.5) / mapHeight) * importance (Textures/image_textures.cpp:126-133).
+    std::vector<float> envTexels, envTopPDF, envTopCDF, envRowPDF, envRowCDF;
+    if (d->env) {
+        const slrhip_envmap& e = *d->env;
+        const uint32_t mw = e.map_width, mh = e.map_height;
+        envTexels.assign(e.texels, e.texels + (size_t)e.width * e.height * 3);
+        envRowPDF.resize((size_t)mw * mh);
+        envRowCDF.assign((size_t)(mw + 1) * mh, 0.0f);
+        envTopPDF.resize(mh);
+        envTopCDF.assign(mh + 1, 0.0f);
+        // RegularConstantContinuous1D ctor, distributions.cpp:127-147
+        auto build1D = [](float* PDF, float* CDF, uint32_t n) -> float {
+            KahanF sum;
+            CDF[0] = 0.0f;
+            for (uint32_t i = 0; i < n; ++i) { sum.add(PDF[i] / n); CDF[i + 1] = sum.result; }
+            for (uint32_t i = 0; i < n; ++i) { PDF[i] /= sum.result; CDF[i + 1] /= sum.result; }
+            return sum.result;
+        };
+        for (uint32_t y = 0; y < mh; ++y) {
+            float* row = envRowPDF.data() + (size_t)y * mw;
+            for (uint32_t x = 0; x < mw; ++x)
+                row[x] = (float)(std::sin(M_PI * (y + 0.5f) / mh) * e.importance[(size_t)y * mw + x]);
+            envTopPDF[y] = build1D(row, envRowCDF.data() + (size_t)y * (mw + 1), mw);
+        }
+        build1D(envTopPDF.data(), envTopCDF.data(), mh);
     }
 
     // --- camera constants, PerspectiveCamera.cpp:15-24, :55 -------------------------------------------------
@@ -345,6 +385,9 @@ int slrhip_upload_scene(slrhip_ctx* ctx, const slrhip_scene_desc* d) {
     }
     HIP_TRY(ctx->lightPMF.upload(pmf));
     HIP_TRY(ctx->lightCDF.upload(cdf));
+    HIP_TRY(ctx->envTexels.upload(envTexels));
+    HIP_TRY(ctx->envTopPDF.upload(envTopPDF)); HIP_TRY(ctx->envTopCDF.upload(envTopCDF));
+    HIP_TRY(ctx->envRowPDF.upload(envRowPDF)); HIP_TRY(ctx->envRowCDF.upload(envRowCDF));
     DevScene& sc = ctx->scene;
     sc.nodes = reinterpret_cast<const float4*>(ctx->nodes.ptr);
     sc.leafTris = reinterpret_cast<const float4*>(ctx->leafTris.ptr);
@@ -363,6 +406,16 @@ int slrhip_upload_scene(slrhip_ctx* ctx, const slrhip_scene_desc* d) {
     for (const DevMaterial& dm : mats)
         if (dm.type == SLRHIP_MATERIAL_MICROFACET_METAL || dm.type == SLRHIP_MATERIAL_MICROFACET_GLASS) sc.hasMicrofacet = 1;
     sc.lightPow2 = prevPowerOf2(sc.numLights);
+    sc.hasEnv = d->env ? 1u : 0u;
+    sc.aggImportance = lightIntegral;
+    if (d->env) {
+        sc.envWidth = d->env->width; sc.envHeight = d->env->height;
+        sc.envMapWidth = d->env->map_width; sc.envMapHeight = d->env->map_height;
+        sc.envScale = d->env->scale;
+    }
+    sc.envTexels = ctx->envTexels.ptr;
+    sc.envTopPDF = ctx->envTopPDF.ptr; sc.envTopCDF = ctx->envTopCDF.ptr;
+    sc.envRowPDF = ctx->envRowPDF.ptr; sc.envRowCDF = ctx->envRowCDF.ptr;
     sc.camera = cam;
     ctx->bvhDepth = bvh.depth;
     ctx->haveScene = true;

@@ -260,3 +260,76 @@ def cornell_box_boxes(aspect=1.0):
     b.add_box(ti, tall)
     b.add_box(white, short)
     return b.build(cornell_camera(aspect), name="cornell_box_boxes")
+
+
+# ---- image-based environment light (BASELINE configs[3], IBL_Test-shaped) ------------------------------------------
+def synthetic_sky(width=512, height=256):
+    """A fixed-formula lat-long radiance map: horizon-to-zenith gradient, dim ground, and a small bright sun disc.
+    Values are rounded to IEEE binary16 because the reference stores environment maps as RGBA16F
+    (libSLR/Core/Image.h:38-40, image_textures.cpp:57-63).  Row 0 = theta 0 (+Y)."""
+    v = (np.arange(height) + 0.5) / height
+    u = (np.arange(width) + 0.5) / width
+    theta, phi = np.pi * v[:, None], 2 * np.pi * u[None, :]
+    d = np.stack([-np.sin(phi) * np.sin(theta), np.cos(theta) * np.ones_like(phi), np.cos(phi) * np.sin(theta)], axis=-1)
+    up = np.clip(d[..., 1], 0, 1)
+    sky = (0.25 + 0.75 * (1 - up) ** 3)[..., None] * np.array([0.35, 0.55, 1.0]) + (up ** 0.5)[..., None] * np.array([0.1, 0.15, 0.3])
+    ground = np.where(d[..., 1:2] < 0, 1.0, 0.0) * np.array([0.12, 0.1, 0.08])
+    img = np.where(d[..., 1:2] < 0, ground, sky)
+    sun_dir = np.array([0.45, 0.6, 0.66]); sun_dir /= np.linalg.norm(sun_dir)
+    cosang = d @ sun_dir
+    img = img + (cosang > math.cos(math.radians(3.0)))[..., None] * np.array([60.0, 55.0, 45.0])
+    return img.astype(np.float16).astype(np.float32)
+
+
+def ibl_importance(texels):
+    """ImageSpectrumTexture::createIBLImportanceMap before the sin(theta) factor (image_textures.cpp:81-108,131):
+    the map is quarter resolution; each cell is Image2D::areaAverage over its 4x4 texel block (Core/Image.cpp:19-120:
+    corner, edge and interior texels are Kahan-summed in that order with unit coefficients, divided by the area and
+    stored back as binary16), then luminance = 0.222485 r + 0.716905 g + 0.060610 b in float."""
+    h, w, _ = texels.shape
+    mw, mh = w // 4, h // 4
+    if w % 4 or h % 4:
+        raise ValueError("environment map size must be a multiple of 4")
+    out = np.zeros((mh, mw), np.float32)
+    f = np.float32
+    order = [(0, 0), (3, 0), (0, 3), (3, 3)]                                   # corners UL, UR, LL, LR (x, y)
+    for x in (1, 2):
+        order += [(x, 0), (x, 3)]                                               # top / bottom edges, interleaved
+    for y in (1, 2):
+        order += [(0, y), (3, y)]                                               # left / right edges
+    order += [(x, y) for y in (1, 2) for x in (1, 2)]                           # interior
+    for my in range(mh):
+        for mx in range(mw):
+            block = texels[4 * my:4 * my + 4, 4 * mx:4 * mx + 4]
+            avg = []
+            for c in range(3):
+                s, comp = f(0), f(0)
+                for (x, y) in order:                                            # CompensatedSum (FloatSum)
+                    val = f(f(1.0) * block[y, x, c])
+                    ci = f(val - comp); t = f(s + ci); comp = f(f(t - s) - ci); s = t
+                avg.append(np.float32(np.float16(f(s / f(16.0)))))
+            out[my, mx] = f(f(f(0.222485) * avg[0]) + f(f(0.716905) * avg[1])) + f(f(0.060610) * avg[2])
+    return out
+
+
+def ibl_test_scene(aspect=1.0, env_size=(256, 128), segments=24, rings=12, area_light=False):
+    """Config 4 of BASELINE.json, IBL_Test-shaped (TestScenes/IBL_Test.txt:34-70): a 6x4 checker floor of matte patches,
+    a mirror sphere of radius 0.4 standing on it, no area light: the only emitter is the environment sphere
+    (synthetic sky, scale 4 like `brightness 4`).  `area_light` adds a small emitting quad above the sphere so that
+    Scene::selectLight chooses between the triangle light list and the environment (SurfaceObject.cpp:432-450)."""
+    b = SceneBuilder()
+    rng = np.random.default_rng(24)
+    colours = rng.uniform(0.15, 0.85, size=(24, 3))
+    for j in range(4):
+        for i in range(6):
+            m = b.matte(b.spectrum_srgb_nonlinear(*colours[j * 6 + i]))
+            x0, z0 = -1.5 + 0.5 * i, -1.0 + 0.5 * j
+            b.add_quad([(x0, 0, z0 + 0.5), (x0 + 0.5, 0, z0 + 0.5), (x0 + 0.5, 0, z0), (x0, 0, z0)], (0, 1, 0), (1, 0, 0), m)
+    mirror = b.metal(b.spectrum_grey(1.0), b.spectrum_ior("Aluminium", 0, ALUMINIUM_ETA_RGB), b.spectrum_ior("Aluminium", 1, ALUMINIUM_K_RGB))
+    b.add_uv_sphere(segments, rings, mirror, _translate(0.0, 0.4, 0.0) @ _scale(0.4))
+    if area_light:
+        lm = b.matte(b.spectrum_grey(0.8), emittance=b.spectrum_d65(0.25, D65_RGB))
+        b.add_quad([(-0.3, 1.6, -0.3), (0.3, 1.6, -0.3), (0.3, 1.6, 0.3), (-0.3, 1.6, 0.3)], (0, -1, 0), (1, 0, 0), lm)
+    cam = make_camera(_translate(0.0, 0.9, 3.2) @ _rotate(3.1415926536, (0, 1, 0)) @ _rotate(0.2, (1, 0, 0)), aspect, 0.6, 0.02, 1.0, 3.2)
+    sky = synthetic_sky(*env_size)
+    return b.build(cam, env=(sky, 4.0, ibl_importance(sky)), name="ibl_test")

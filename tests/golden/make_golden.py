@@ -21,7 +21,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 def scene_arrays(sc):
     cam = sc.camera
-    return dict(vertices=sc.vertices, triangles=sc.triangles, materials=sc.materials, spectra=sc.spectra,
+    env = {}
+    if sc.env is not None:
+        # texels are binary16-exact (scenes.synthetic_sky): float16 storage is lossless
+        assert np.array_equal(sc.env_texels.astype(np.float16).astype(np.float32), sc.env_texels)
+        env = dict(env_texels=sc.env_texels.astype(np.float16), env_scale=np.float32(sc.env_scale), env_importance=sc.env_importance)
+    return dict(env, vertices=sc.vertices, triangles=sc.triangles, materials=sc.materials, spectra=sc.spectra,
                 spectrum_data=sc.spectrum_data,
                 camera=np.array(list(cam.local_to_world) + list(cam.world_to_local) +
                                 [cam.aspect, cam.fov_y, cam.lens_radius, cam.img_plane_distance,
@@ -63,6 +68,11 @@ def make(name, sc, lib, width, height, spp, serial_spp):
 
 
 def main():
+    only = sys.argv[1:]
+    if only:
+        global make
+        _make = make
+        make = lambda name, *a: _make(name, *a) if name in only else None
     lib = ob.load("ref_rgb")
     if lib is None:
         raise SystemExit("oracle/_ref is not built: run `make -C oracle ref` where /root/reference exists")
@@ -97,6 +107,8 @@ def main():
     make("spectral_oren_nayar", scenes.cornell_lobes("oren_nayar", segments=10, rings=5), spec, 32, 32, 8, 2)
     make("spectral_ggx_metal", scenes.cornell_lobes("ggx_metal", segments=10, rings=5), spec, 32, 32, 8, 2)
     make("spectral_ggx_glass", scenes.cornell_lobes("ggx_glass", segments=10, rings=5), spec, 32, 32, 8, 2)
+    make("rgb_ibl", scenes.ibl_test_scene(1.0, (128, 64), 12, 6), lib, 40, 40, 8, 2)
+    make("rgb_ibl_area", scenes.ibl_test_scene(1.0, (128, 64), 12, 6, area_light=True), lib, 40, 40, 8, 2)
     make("rgb_cornell_matte", scenes.cornell_box_spheres(4.0 / 3.0, 16, 8, "matte"), lib, 48, 36, 8, 2)
 
 

@@ -18,7 +18,10 @@ def scene_from_golden(g, name="golden"):
     cam.world_to_local[:] = c[16:32].tolist()
     (cam.aspect, cam.fov_y, cam.lens_radius, cam.img_plane_distance, cam.obj_plane_distance,
      cam.sensitivity) = [float(v) for v in c[32:38]]
-    return abi.Scene(g["vertices"], g["triangles"], g["materials"], g["spectra"], g["spectrum_data"], cam, None, name)
+    env = None
+    if "env_texels" in g.files:
+        env = (g["env_texels"].astype(np.float32), float(g["env_scale"]), g["env_importance"])
+    return abi.Scene(g["vertices"], g["triangles"], g["materials"], g["spectra"], g["spectrum_data"], cam, env, name)
 
 
 def bits(a):

@@ -146,6 +146,42 @@ def test_ggx_matches_reference_golden_within_tolerance(ctx, name):
     assert np.isfinite(fb).all()
 
 
+@pytest.mark.parametrize("name", ["rgb_ibl", "rgb_ibl_area"])
+def test_environment_light_matches_reference_golden_within_tolerance(ctx, name):
+    """Image-based environment light (BASELINE configs[3]): miss -> InfiniteSphere hit, importance-sampled NEE, MIS.
+    Float libm on the path (acosf, atan2f, fmodf, sinf, cosf) -> same tolerance as GGX; the sun texels are ~750x the
+    mean radiance, so the RMSE bound is taken on frames clipped at 10x the mean (a flipped sun sample is one float)."""
+    g = load_golden(name)
+    st = ob.settings(int(g["width"]), int(g["height"]), int(g["seed"]))
+    fb = ctx.render_image(scene_from_golden(g), st, int(g["spp"]))
+    want = g["framebuffer"]
+    s = frame_stats(fb, want)
+    close = np.isclose(fb, want, rtol=1e-4, atol=1e-9)
+    assert close.mean() >= 0.95, (close.mean(), s)
+    cap = 10 * float(want.mean())
+    sc = frame_stats(np.minimum(fb, cap), np.minimum(want, cap))
+    assert sc["rmse"] <= 1e-3 * sc["mean"], (sc, s)
+    assert np.isfinite(fb).all()
+    assert ctx.counters().samples == int(g["width"]) * int(g["height"]) * int(g["spp"])
+
+
+def test_environment_light_full_size_against_oracle(ctx, oracle_rgb):
+    sc = scenes.ibl_test_scene(16.0 / 9.0, (256, 128), 24, 12)
+    st = ob.settings(160, 90, seed=11)
+    want, ctr = oracle_rgb.scene(sc).render(st, 16)
+    fb = ctx.render_image(sc, st, 16)
+    assert np.isclose(fb, want, rtol=1e-4, atol=1e-9).mean() >= 0.95
+    c = ctx.counters()
+    assert abs(int(c.extension_rays) - int(ctr.extension_rays)) <= ctr.extension_rays * 1e-3
+    assert abs(int(c.shadow_rays) - int(ctr.shadow_rays)) <= ctr.shadow_rays * 1e-3
+
+
+def test_environment_light_is_rgb_only(sctx):
+    from slr_amd.binding import SlrHipError
+    with pytest.raises(SlrHipError):
+        sctx.upload_scene(scenes.ibl_test_scene(1.0, (64, 32), 8, 4))
+
+
 def test_boxes_scene_against_oracle(ctx, oracle_rgb):
     """BASELINE configs[2] geometry and lobes (GGX titanium box), RGB variant, at a size the oracle finishes in seconds."""
     sc = scenes.cornell_box_boxes()

@@ -7,7 +7,8 @@ from helpers import assert_bit_equal, load_golden, scene_from_golden
 from oracle import binding as ob
 from slr_amd import abi
 
-SCENES = ["rgb_tiny_box", "rgb_cornell_glass", "rgb_cornell_matte", "rgb_oren_nayar", "rgb_ggx_metal", "rgb_ggx_glass"]
+SCENES = ["rgb_tiny_box", "rgb_cornell_glass", "rgb_cornell_matte", "rgb_oren_nayar", "rgb_ggx_metal", "rgb_ggx_glass",
+          "rgb_ibl", "rgb_ibl_area"]     # environment sphere alone / next to a triangle light (Scene::selectLight)
 
 
 def test_rng_known_answers(oracle_rgb):
@@ -74,7 +75,7 @@ def test_closest_hits_match_reference(oracle_rgb, name):
     want = g["hits"]
     assert (hits["triangle"] == want["triangle"]).all()
     hit = want["triangle"] != 0xFFFFFFFF
-    assert hit.sum() > 100
+    assert hit.sum() > 50      # the open IBL scene (a floor and a sphere) stops 58 of the 512 rays
     for f in ("dist", "b0", "b1"):
         assert_bit_equal(hits[f][hit], want[f][hit], name + " " + f)
 
