@@ -55,12 +55,17 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--height", type=int, default=720)
-    ap.add_argument("--spp", type=int, default=1024)
+    ap.add_argument("--spp", type=int, default=0, help="0 = the workload's BASELINE value")
     ap.add_argument("--right-sphere", default="matte", choices=["matte", "glass"])
+    ap.add_argument("--workload", default="cornell", choices=["cornell", "boxes_spectral", "ibl", "grid10m"],
+                    help="cornell = BASELINE configs[1] (the headline metric); the others are configs[2..4], measured the same way")
+    ap.add_argument("--grid-n", type=int, default=2236, help="grid10m: cells per side (2 n^2 triangles)")
     ap.add_argument("--stripes", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"),
+                    help="per-kernel HBM traffic from separate rocprofv3 --pmc passes of this same command (tools/pmc_traffic.py)")
     return ap.parse_args()
 
 
@@ -83,13 +88,32 @@ def main():
     torch.cuda.set_device(local_rank)
     distributed.init("nccl")
 
-    W, H, spp = args.width, args.height, args.spp
-    scene = scenes.cornell_box_spheres(W / H, 48, 24, args.right_sphere)
+    W, H = args.width, args.height
+    mode, ref_name = abi.MODE_RGB, "ref_rgb"
+    if args.workload == "cornell":
+        spp = args.spp or 1024
+        scene = scenes.cornell_box_spheres(W / H, 48, 24, args.right_sphere)
+        what = ("BASELINE configs[1]: Cornell_Box_Spheres walls/light/camera (TestScenes/Cornell_Box_Spheres.txt:8-107,132-138) + two "
+                "tessellated spheres (aluminium mirror, %s)" % ("Lambert" if args.right_sphere == "matte" else "BK7 glass"))
+    elif args.workload == "boxes_spectral":
+        spp = args.spp or 1024
+        mode, ref_name = abi.MODE_SPECTRAL, "ref_spectral"
+        scene = scenes.cornell_box_boxes(W / H)
+        what = "BASELINE configs[2]: Cornell_Box_Boxes-shaped, GGX titanium box + matte box, 16-wavelength spectral mode"
+    elif args.workload == "ibl":
+        spp = args.spp or 2048
+        scene = scenes.ibl_test_scene(W / H, (2048, 1024), 48, 24)
+        what = "BASELINE configs[3]: IBL_Test-shaped, 24-patch floor + mirror sphere under a synthetic 2048x1024 binary16 sky (scale 4)"
+    else:
+        spp = args.spp or 4096
+        scene = scenes.displaced_grid(args.grid_n, W / H)
+        what = "BASELINE configs[4]: one displaced grid (hash-noise heightfield, seed 20240611), matte, one area light, thin lens r=0.025"
     settings = abi.RenderSettings(W, H, 0.0, 0.0, 1.0, abi.DEFAULT_SEED)
     flags = 0 if args.no_kernel_timing else abi.FLAG_TIME_KERNELS
-    ctx = Context(device=local_rank, mode=abi.MODE_RGB, stripes=args.stripes, flags=flags)
+    ctx = Context(device=local_rank, mode=mode, stripes=args.stripes, flags=flags)
     ctx.upload_scene(scene)
-    fb = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+    comps = 16 if mode == abi.MODE_SPECTRAL else 3
+    fb = torch.zeros((H, W, comps), dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
@@ -122,14 +146,13 @@ def main():
     value = total_samples / elapsed / 1e6
 
     out = {
-        "metric": "Msamples/sec @1024spp 1280x720 (unidirectional path tracing, Cornell_Box_Spheres-shaped scene)",
+        "metric": "Msamples/sec @1024spp 1280x720 (unidirectional path tracing, Cornell_Box_Spheres-shaped scene)" if args.workload == "cornell"
+                  else "Msamples/sec @%dspp %dx%d (unidirectional path tracing, workload %s)" % (spp, W, H, args.workload),
         "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 3), "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: Cornell_Box_Spheres walls/light/camera (TestScenes/Cornell_Box_Spheres.txt:8-107,"
-                               "132-138) + two tessellated spheres (aluminium mirror, %s), %d triangles, RGB mode, %dx%d, %d spp, "
-                               "seed %d" % ("Lambert" if args.right_sphere == "matte" else "BK7 glass", len(scene.triangles), W, H, spp,
-                                            abi.DEFAULT_SEED),
+        "config": {"workload": "%s, %d triangles, %s mode, %dx%d, %d spp, seed %d" % (
+                       what, len(scene.triangles), "spectral" if mode == abi.MODE_SPECTRAL else "RGB", W, H, spp, abi.DEFAULT_SEED),
                    "sharding": "8x8 tiles round-robin over %d rank(s), one RCCL reduce of the framebuffer per step" % world,
                    "stripes": int(args.stripes)},
     }
@@ -144,7 +167,7 @@ def main():
                 ms = prof1.milliseconds[k] - prof0.milliseconds[k]
                 kernels[name] = {"launches": int(n), "ms_total": round(ms, 3), "avg_us": round(ms / n * 1e3, 3) if n else None}
             # traversal statistics from an instrumented, untimed pass on this rank's shard
-            cctx = Context(device=local_rank, stripes=args.stripes, flags=abi.FLAG_COUNT_TRAVERSAL)
+            cctx = Context(device=local_rank, mode=mode, stripes=args.stripes, flags=abi.FLAG_COUNT_TRAVERSAL)
             cctx.upload_scene(scene)
             cctx.render_begin(settings, shard=(rank, world))
             cctx.render(0, min(spp, 16))
@@ -175,6 +198,15 @@ def main():
                     "per_ray": {"nodes_closest": round(nodes_c, 3), "tris_closest": round(tris_c, 3), "nodes_shadow": round(nodes_s, 3),
                                 "tris_shadow": round(tris_s, 3), "extension_rays_per_sample": round(ext_per_sample, 4),
                                 "shadow_rays_per_sample": round(shd_per_sample, 4)}}
+            # HBM bytes per launch of that kernel from the PMC passes (FETCH_SIZE x 2 + WRITE_SIZE, KiB; collected in their
+            # own rocprofv3 runs of this command and committed under profiles/) -- null when no pass covers this workload
+            try:
+                tr = json.load(open(args.traffic_json)).get("%s_%dx%d_%dspp" % (args.workload, W, H, spp), {}).get(dom)
+                if tr and world == 1:
+                    roof["traffic"] = round(tr["traffic_bytes_per_launch"])
+                    roof["traffic_source"] = os.path.relpath(args.traffic_json, ROOT)
+            except (OSError, ValueError):
+                pass
             # whole-sample algorithmic bytes (SURVEY 8d formula) for reference
             sample_bytes = (ext_per_sample * per_ray["trace_closest"] + shd_per_sample * per_ray["trace_shadow"] +
                             ext_per_sample * SHADE_SLOT_BYTES)
@@ -195,16 +227,16 @@ def main():
             from oracle import binding as ob
             # the GPU box gives a 1-GPU job a 16-CPU share; never start more workers than that
             cores = max(1, min(len(os.sched_getaffinity(0)), os.cpu_count() or 1, 16))
-            ref = ob.load("ref_rgb")
+            ref = ob.load(ref_name, mode) if len(scene.triangles) <= 1000000 else None   # the reference's SBVH build of 10 M triangles takes minutes
             if ref is not None:
                 rs = ref.scene(scene)
                 _, sec = ob.render_native(rs, settings, 1, cores)
                 n = int(max(1, min(64, args.cpu_seconds / max(sec, 1e-3))))
                 _, sec = ob.render_native(rs, settings, n, cores)
                 out["cpu_baseline"] = {"value": round(W * H * n / sec / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "reference",
-                                       "sample": "libSLR PathTracingRenderer::render unmodified (RGB build, SBVH), %dx%d x %d spp of the "
-                                                 "same scene, %d worker threads" % (W, H, n, cores)}
-            orc = ob.load("oracle").scene(scene)
+                                       "sample": "libSLR PathTracingRenderer::render unmodified (%s build, SBVH), %dx%d x %d spp of the "
+                                                 "same scene, %d worker threads" % ("spectral" if comps == 16 else "RGB", W, H, n, cores)}
+            orc = ob.load("oracle", mode).scene(scene)
             t = time.perf_counter()
             want, _ = orc.render(settings, 1, threads=cores)
             sec1 = time.perf_counter() - t
@@ -219,7 +251,7 @@ def main():
             else:
                 out["cpu_baseline_port"] = port
             if not args.no_parity:
-                pctx = Context(device=local_rank, stripes=1)
+                pctx = Context(device=local_rank, mode=mode, stripes=1)
                 got = pctx.render_image(scene, settings, n)
                 pctx.close()
                 exact = (got.view(np.uint32) == want.view(np.uint32)) | ((got == 0) & (want == 0))

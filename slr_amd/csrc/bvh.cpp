@@ -9,13 +9,32 @@
 // first K nodes are the top of the tree (the part the traversal kernel stages in LDS).
 #include "bvh.h"
 
+#include <sched.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <chrono>
+
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
 #include <cstring>
+#include <deque>
+#include <mutex>
 #include <queue>
+#include <thread>
 
 namespace slrhip {
 namespace {
+
+unsigned hostThreads() {
+    unsigned nt = std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) nt = (unsigned)CPU_COUNT(&set);
+    if (nt < 1) nt = 1;
+    return nt > 32 ? 32 : nt;
+}
 
 struct Box {
     float lo[3], hi[3];
@@ -51,16 +70,62 @@ struct Builder {
         }
     }
 
+    // Subtrees are independent once their primitive range is fixed (std::partition works inside [begin, end)), so
+    // jobs above kParallelGrain primitives go to a shared queue served by all host threads; smaller ones stay on the
+    // worker's own stack.  Nodes come from one pre-sized array through an atomic cursor.
+    std::atomic<uint32_t> nodeCursor{0};
+    struct Job { uint32_t node, begin, end; };
+    std::mutex queueMutex;
+    std::condition_variable queueCv;
+    std::deque<Job> shared;
+    uint32_t busy = 0;
+    static const uint32_t kParallelGrain = 1u << 14;
+
     void build() {
-        nodes.reserve(2 * prims.size());
-        nodes.push_back(BNode());
-        struct Job { uint32_t node, begin, end; };
+        nodes.resize(2 * prims.size());
+        nodeCursor = 1;
+        shared.push_back({0, 0, (uint32_t)prims.size()});
+        unsigned nt = hostThreads();
+        if (prims.size() < 4 * kParallelGrain) nt = 1;
+        std::vector<std::thread> pool;
+        for (unsigned i = 1; i < nt; ++i) pool.emplace_back([this] { worker(); });
+        worker();
+        for (std::thread& th : pool) th.join();
+        nodes.resize(nodeCursor.load());
+    }
+
+    void worker() {
+        for (;;) {
+            Job j;
+            {
+                std::unique_lock<std::mutex> lock(queueMutex);
+                queueCv.wait(lock, [this] { return !shared.empty() || busy == 0; });
+                if (shared.empty()) { queueCv.notify_all(); return; }
+                j = shared.front();
+                shared.pop_front();
+                ++busy;
+            }
+            run(j);
+            {
+                std::lock_guard<std::mutex> lock(queueMutex);
+                --busy;
+            }
+            queueCv.notify_all();
+        }
+    }
+
+    void run(Job first) {
         std::vector<Job> stack;
-        stack.push_back({0, 0, (uint32_t)prims.size()});
+        stack.push_back(first);
         const int kBins = 16;
         while (!stack.empty()) {
             Job j = stack.back();
             stack.pop_back();
+            if (j.end - j.begin > kParallelGrain && !(j.node == first.node)) {
+                { std::lock_guard<std::mutex> lock(queueMutex); shared.push_back(j); }
+                queueCv.notify_one();
+                continue;
+            }
             Box box, cbox;
             box.reset(); cbox.reset();
             for (uint32_t k = j.begin; k < j.end; ++k) {
@@ -129,11 +194,9 @@ struct Builder {
             }
             if (mid == j.begin || mid == j.end) mid = j.begin + n / 2;
             nd.count = 0;
-            nd.left = (uint32_t)nodes.size();
+            nd.left = nodeCursor.fetch_add(2);
             nd.right = nd.left + 1;
             nodes[j.node] = nd;
-            nodes.push_back(BNode());
-            nodes.push_back(BNode());
             stack.push_back({nd.right, mid, j.end});
             stack.push_back({nd.left, j.begin, mid});
         }
@@ -149,104 +212,136 @@ int buildQBVH(const slrhip_vertex* verts, const slrhip_triangle* tris, uint32_t 
         primBox[i].reset();
         for (int k = 0; k < 3; ++k) primBox[i].grow(verts[tris[i].v[k]].position);
     }
+    auto tA = std::chrono::steady_clock::now();
     Builder b(primBox);
+    auto tB = std::chrono::steady_clock::now();
     b.build();
+    auto tC = std::chrono::steady_clock::now();
+    if (getenv("SLRHIP_BVH_TIMING")) fprintf(stderr, "bvh: boxes+centroids %.2f s, binary build %.2f s\n",
+        std::chrono::duration<double>(tB - tA).count(), std::chrono::duration<double>(tC - tB).count());
 
     out->nodes.clear();
     out->leafTris.clear();
-    out->leafTris.reserve(numTris);
     out->depth = 0;
 
-    auto emitLeaf = [&](const BNode& leaf) -> uint32_t {
-        uint32_t first = (uint32_t)out->leafTris.size();
-        for (uint32_t k = 0; k < leaf.count; ++k) {
-            uint32_t t = b.prims[leaf.first + k];
-            const float* p0 = verts[tris[t].v[0]].position;
-            const float* p1 = verts[tris[t].v[1]].position;
-            const float* p2 = verts[tris[t].v[2]].position;
-            LeafTri lt;
-            std::memset(&lt, 0, sizeof(lt));
-            for (int a = 0; a < 3; ++a) {
-                lt.v0[a] = p0[a];
-                lt.e1[a] = p1[a] - p0[a];      // edge01, TriangleMesh.cpp:136
-                lt.e2[a] = p2[a] - p0[a];      // edge02, TriangleMesh.cpp:137
-            }
-            lt.tri = t;
-            out->leafTris.push_back(lt);
-        }
+    // Pass 1 (serial, touches only the binary nodes): collapse to 4-wide nodes in breadth-first order, number the
+    // nodes and the leaf packets.  Pass 2 (all host threads): fill the child boxes and the leaf triangles.
+    struct Kids { uint32_t b[4]; };
+    std::vector<Kids> kidsOf;
+    std::vector<uint32_t> depthOf;
+    uint32_t leafCursor = 0;
+    auto leafRef = [&](const BNode& leaf) -> uint32_t {
+        uint32_t first = leafCursor;
+        leafCursor += leaf.count;
         return kLeafFlag | (leaf.count << kLeafCountShift) | first;
     };
-
-    // breadth-first emission of 4-wide nodes
-    struct Pending { uint32_t bnode; uint32_t qnode; uint32_t depth; };
-    std::queue<Pending> q;
     const BNode& root = b.nodes[0];
-    out->nodes.push_back(QNode());
     if (root.count > 0) {
         // a single leaf: wrap it in one node
         QNode qn;
         std::memset(&qn, 0, sizeof(qn));
-        for (int c = 0; c < 4; ++c) {
-            qn.minx[c] = qn.miny[c] = qn.minz[c] = INFINITY;
-            qn.maxx[c] = qn.maxy[c] = qn.maxz[c] = -INFINITY;
-            qn.child[c] = kInvalidChild;
-        }
-        qn.minx[0] = root.box.lo[0]; qn.miny[0] = root.box.lo[1]; qn.minz[0] = root.box.lo[2];
-        qn.maxx[0] = root.box.hi[0]; qn.maxy[0] = root.box.hi[1]; qn.maxz[0] = root.box.hi[2];
-        qn.child[0] = emitLeaf(root);
-        out->nodes[0] = qn;
+        qn.child[0] = leafRef(root);
+        qn.child[1] = qn.child[2] = qn.child[3] = kInvalidChild;
+        out->nodes.push_back(qn);
+        kidsOf.push_back({{0, 0, 0, 0}});
         out->depth = 1;
     }
     else {
-        q.push({0, 0, 1});
-    }
-    while (!q.empty()) {
-        Pending p = q.front();
-        q.pop();
-        out->depth = std::max(out->depth, p.depth);
-        const BNode& bn = b.nodes[p.bnode];
-        uint32_t kids[4] = {bn.left, bn.right, 0, 0};
-        int nk = 2;
-        while (nk < 4) {
-            int best = -1;
-            float bestArea = -1.0f;
-            for (int i = 0; i < nk; ++i) {
-                const BNode& c = b.nodes[kids[i]];
-                if (c.count > 0) continue;
-                float a = c.box.area();
-                if (a > bestArea) { bestArea = a; best = i; }
+        out->nodes.reserve(b.nodes.size() / 2 + 1);
+        kidsOf.reserve(b.nodes.size() / 2 + 1);
+        out->nodes.push_back(QNode());
+        kidsOf.push_back({{0, 0, 0, 0}});
+        depthOf.push_back(1);
+        std::vector<uint32_t> bnodeOf(1, 0u);           // binary node each 4-wide node was made from
+        bnodeOf.reserve(b.nodes.size() / 2 + 1);
+        depthOf.reserve(b.nodes.size() / 2 + 1);
+        for (size_t qi = 0; qi < out->nodes.size(); ++qi) {     // the vector is the BFS queue
+            const BNode& bn = b.nodes[bnodeOf[qi]];
+            out->depth = std::max(out->depth, depthOf[qi]);
+            uint32_t kids[4] = {bn.left, bn.right, 0, 0};
+            int nk = 2;
+            while (nk < 4) {
+                int best = -1;
+                float bestArea = -1.0f;
+                for (int i = 0; i < nk; ++i) {
+                    const BNode& c = b.nodes[kids[i]];
+                    if (c.count > 0) continue;
+                    float a = c.box.area();
+                    if (a > bestArea) { bestArea = a; best = i; }
+                }
+                if (best < 0) break;
+                const BNode& c = b.nodes[kids[best]];
+                kids[best] = c.left;
+                kids[nk++] = c.right;
             }
-            if (best < 0) break;
-            const BNode& c = b.nodes[kids[best]];
-            kids[best] = c.left;
-            kids[nk++] = c.right;
-        }
-        QNode qn;
-        std::memset(&qn, 0, sizeof(qn));
-        for (int c = 0; c < 4; ++c) {
-            if (c < nk) {
+            QNode qn;
+            std::memset(&qn, 0, sizeof(qn));
+            Kids kd = {{0, 0, 0, 0}};
+            for (int c = 0; c < 4; ++c) {
+                if (c >= nk) { qn.child[c] = kInvalidChild; continue; }
                 const BNode& cn = b.nodes[kids[c]];
+                kd.b[c] = kids[c];
+                if (cn.count > 0) qn.child[c] = leafRef(cn);
+                else {
+                    qn.child[c] = (uint32_t)out->nodes.size();
+                    out->nodes.push_back(QNode());
+                    kidsOf.push_back({{0, 0, 0, 0}});
+                    bnodeOf.push_back(kids[c]);
+                    depthOf.push_back(depthOf[qi] + 1);
+                }
+            }
+            // children were appended after this node: re-index, the vector may have grown
+            std::memcpy(out->nodes[qi].child, qn.child, sizeof(qn.child));
+            kidsOf[qi] = kd;
+        }
+    }
+    auto tD = std::chrono::steady_clock::now();
+    out->leafTris.resize(leafCursor);
+
+    auto fill = [&](size_t lo, size_t hi) {
+        for (size_t qi = lo; qi < hi; ++qi) {
+            QNode& qn = out->nodes[qi];
+            for (int c = 0; c < 4; ++c) {
+                if (qn.child[c] == kInvalidChild) {
+                    // empty slot: an inverted box never passes the slab test
+                    qn.minx[c] = qn.miny[c] = qn.minz[c] = INFINITY;
+                    qn.maxx[c] = qn.maxy[c] = qn.maxz[c] = -INFINITY;
+                    continue;
+                }
+                const BNode& cn = b.nodes[kidsOf[qi].b[c]];
                 qn.minx[c] = cn.box.lo[0]; qn.miny[c] = cn.box.lo[1]; qn.minz[c] = cn.box.lo[2];
                 qn.maxx[c] = cn.box.hi[0]; qn.maxy[c] = cn.box.hi[1]; qn.maxz[c] = cn.box.hi[2];
-                if (cn.count > 0) {
-                    qn.child[c] = emitLeaf(cn);
+                if (!(qn.child[c] & kLeafFlag)) continue;
+                uint32_t first = qn.child[c] & kLeafIndexMask;
+                for (uint32_t k = 0; k < cn.count; ++k) {
+                    uint32_t t = b.prims[cn.first + k];
+                    const float* p0 = verts[tris[t].v[0]].position;
+                    const float* p1 = verts[tris[t].v[1]].position;
+                    const float* p2 = verts[tris[t].v[2]].position;
+                    LeafTri lt;
+                    std::memset(&lt, 0, sizeof(lt));
+                    for (int a = 0; a < 3; ++a) {
+                        lt.v0[a] = p0[a];
+                        lt.e1[a] = p1[a] - p0[a];      // edge01, TriangleMesh.cpp:136
+                        lt.e2[a] = p2[a] - p0[a];      // edge02, TriangleMesh.cpp:137
+                    }
+                    lt.tri = t;
+                    out->leafTris[first + k] = lt;
                 }
-                else {
-                    uint32_t idx = (uint32_t)out->nodes.size();
-                    out->nodes.push_back(QNode());
-                    qn.child[c] = idx;
-                    q.push({kids[c], idx, p.depth + 1});
-                }
-            }
-            else {
-                // empty slot: an inverted box never passes the slab test
-                qn.minx[c] = qn.miny[c] = qn.minz[c] = INFINITY;
-                qn.maxx[c] = qn.maxy[c] = qn.maxz[c] = -INFINITY;
-                qn.child[c] = kInvalidChild;
             }
         }
-        out->nodes[p.qnode] = qn;
+    };
+    {
+        const size_t nq = out->nodes.size();
+        unsigned nt = hostThreads();
+        if (nq < 65536) nt = 1;
+        std::vector<std::thread> pool;
+        for (unsigned i = 1; i < nt; ++i) pool.emplace_back(fill, nq * i / nt, nq * (i + 1) / nt);
+        fill(0, nq / nt);
+        for (std::thread& th : pool) th.join();
     }
+    if (getenv("SLRHIP_BVH_TIMING")) fprintf(stderr, "bvh: collapse %.2f s, emit %.2f s\n", std::chrono::duration<double>(tD - tC).count(),
+        std::chrono::duration<double>(std::chrono::steady_clock::now() - tD).count());
     return 0;
 }
 

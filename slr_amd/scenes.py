@@ -53,7 +53,8 @@ def make_camera(local_to_world, aspect, fov_y, lens_radius, img_dist, obj_dist, 
 
 class SceneBuilder:
     def __init__(self):
-        self.vertices, self.triangles, self.materials = [], [], []
+        self.vertices, self.triangles, self.materials = [], [], []     # vertices / triangles: lists of structured-array chunks
+        self.num_vertices = 0
         self.sset = spectra.SpectrumSet()     # every constant carries its RGB value and its spectral descriptor
 
     # --- spectra (the scene language's Spectrum(...) overloads, libSLRSceneGraph/API.cpp:286-441) -------
@@ -116,16 +117,16 @@ class SceneBuilder:
             n = n / np.linalg.norm(n, axis=1, keepdims=True)
             t = t @ m[:3, :3].T
             t = t / np.linalg.norm(t, axis=1, keepdims=True)
-        base = len(self.vertices)
-        for i in range(len(p)):
-            rec = np.zeros((), dtype=abi.vertex_dtype)
-            rec["position"], rec["normal"], rec["tangent"], rec["texcoord"] = p[i], n[i], t[i], texcoords[i]
-            self.vertices.append(rec)
-        for f in faces:
-            rec = np.zeros((), dtype=abi.triangle_dtype)
-            rec["v"] = (base + f[0], base + f[1], base + f[2])
-            rec["material"] = material
-            self.triangles.append(rec)
+        base = self.num_vertices
+        v = np.zeros(len(p), dtype=abi.vertex_dtype)
+        v["position"], v["normal"], v["tangent"], v["texcoord"] = p, n, t, np.asarray(texcoords, dtype=np.float64)
+        f = np.asarray(faces, dtype=np.int64).reshape(-1, 3)
+        tri = np.zeros(len(f), dtype=abi.triangle_dtype)
+        tri["v"] = f + base
+        tri["material"] = material
+        self.vertices.append(v)
+        self.triangles.append(tri)
+        self.num_vertices += len(p)
 
     def add_quad(self, corners, normal, tangent, material, transform=None):
         uv = [(0, 0), (1, 0), (1, 1), (0, 1)]
@@ -165,8 +166,7 @@ class SceneBuilder:
             self.add_quad(c, n, t, material, transform)
 
     def build(self, camera, env=None, name="scene"):
-        return abi.Scene(np.array(self.vertices, dtype=abi.vertex_dtype),
-                         np.array(self.triangles, dtype=abi.triangle_dtype),
+        return abi.Scene(np.concatenate(self.vertices), np.concatenate(self.triangles),
                          np.array(self.materials, dtype=abi.material_dtype),
                          np.array(self.sset.records, dtype=abi.spectrum_dtype),
                          np.array(self.sset.data, dtype=np.float32), camera, env, name)
@@ -333,3 +333,58 @@ def ibl_test_scene(aspect=1.0, env_size=(256, 128), segments=24, rings=12, area_
     cam = make_camera(_translate(0.0, 0.9, 3.2) @ _rotate(3.1415926536, (0, 1, 0)) @ _rotate(0.2, (1, 0, 0)), aspect, 0.6, 0.02, 1.0, 3.2)
     sky = synthetic_sky(*env_size)
     return b.build(cam, env=(sky, 4.0, ibl_importance(sky)), name="ibl_test")
+
+
+def _hash_lattice(ix, iz, seed):
+    """uint32 lattice hash -> [0, 1) (murmur3 finaliser over the two coordinates and the seed)."""
+    h = (ix.astype(np.uint32) * np.uint32(0x85EBCA77)) ^ (iz.astype(np.uint32) * np.uint32(0xC2B2AE3D)) ^ np.uint32(seed)
+    h ^= h >> np.uint32(16); h *= np.uint32(0x85EBCA6B); h ^= h >> np.uint32(13); h *= np.uint32(0xC2B2AE35); h ^= h >> np.uint32(16)
+    return (h >> np.uint32(8)).astype(np.float64) * (1.0 / 16777216.0)
+
+
+def hash_noise_heightfield(n, seed=20240611, octaves=6, base_cells=4):
+    """(n+1) x (n+1) heights in [0, ~1): `octaves` of smooth value noise, octave k on a base_cells * 2^k lattice with
+    amplitude 2^-k and its own seed (seed + k)."""
+    t = np.arange(n + 1, dtype=np.float64) / n
+    height = np.zeros((n + 1, n + 1))
+    for k in range(octaves):
+        cells = base_cells << k
+        g = t * cells
+        i0 = np.minimum(np.floor(g).astype(np.int64), cells - 1)
+        f = g - i0
+        w = f * f * (3 - 2 * f)
+        ix0, iz0 = np.meshgrid(i0, i0, indexing="xy")
+        wx, wz = np.meshgrid(w, w, indexing="xy")
+        v00, v10 = _hash_lattice(ix0, iz0, seed + k), _hash_lattice(ix0 + 1, iz0, seed + k)
+        v01, v11 = _hash_lattice(ix0, iz0 + 1, seed + k), _hash_lattice(ix0 + 1, iz0 + 1, seed + k)
+        height += ((v00 * (1 - wx) + v10 * wx) * (1 - wz) + (v01 * (1 - wx) + v11 * wx) * wz) * 0.5 ** k
+    return height / (2.0 - 0.5 ** (octaves - 1))
+
+
+def displaced_grid(n=2236, aspect=16.0 / 9.0, seed=20240611, extent=4.0, relief=0.9):
+    """Config 5 of BASELINE.json: ONE displaced grid of 2 n^2 triangles (n = 2236 -> 9 999 392), matte, one area light,
+    thin-lens camera r = 0.025.  Vertices come from a seeded hash-noise heightfield (seed above); normals are the
+    central-difference normals of the heightfield, tangents (1, dh/dx, 0) normalised (orthogonal to the normal)."""
+    h = hash_noise_heightfield(n, seed) * relief
+    t = np.linspace(-extent, extent, n + 1)
+    x, z = np.meshgrid(t, t, indexing="xy")
+    step = 2.0 * extent / n
+    dhdx = np.gradient(h, step, axis=1)
+    dhdz = np.gradient(h, step, axis=0)
+    nrm = np.stack([-dhdx, np.ones_like(h), -dhdz], axis=-1)
+    nrm /= np.linalg.norm(nrm, axis=-1, keepdims=True)
+    tan = np.stack([np.ones_like(h), dhdx, np.zeros_like(h)], axis=-1)
+    tan /= np.linalg.norm(tan, axis=-1, keepdims=True)
+    pos = np.stack([x, h, z], axis=-1).reshape(-1, 3)
+    uv = np.stack([(x + extent) / (2 * extent), (z + extent) / (2 * extent)], axis=-1).reshape(-1, 2)
+    idx = (np.arange(n)[:, None] * (n + 1) + np.arange(n)[None, :]).reshape(-1)
+    a, b_, c, d = idx, idx + 1, idx + n + 2, idx + n + 1
+    # counter-clockwise seen from +y: (a, d, c), (a, c, b)
+    faces = np.concatenate([np.stack([a, d, c], axis=1), np.stack([a, c, b_], axis=1)], axis=1).reshape(-1, 3)
+    b = SceneBuilder()
+    ground = b.matte(b.spectrum_srgb_nonlinear(0.72, 0.64, 0.5))
+    b.add_mesh(pos, nrm.reshape(-1, 3), tan.reshape(-1, 3), uv, faces, ground)
+    lm = b.matte(b.spectrum_grey(0.8), emittance=b.spectrum_d65(1.0, D65_RGB))
+    b.add_quad([(-1.0, 3.0, -1.0), (1.0, 3.0, -1.0), (1.0, 3.0, 1.0), (-1.0, 3.0, 1.0)], (0, -1, 0), (1, 0, 0), lm)
+    cam = make_camera(_translate(0.0, 2.4, 5.2) @ _rotate(3.1415926536, (0, 1, 0)) @ _rotate(0.42, (1, 0, 0)), aspect, 0.6, 0.025, 1.0, 5.4)
+    return b.build(cam, name="displaced_grid_%d" % (2 * n * n))
