@@ -76,7 +76,13 @@ typedef struct slrhip_triangle {
  *   kind REGULAR   : RegularContinuousSpectrum(min,max,values) SpectrumTypes.h:70-118
  *   kind IRREGULAR : IrregularContinuousSpectrum(lambdas,values) SpectrumTypes.h:121-170
  * Sample tables live in slrhip_scene_desc::spectrum_data at [data_offset, +num_samples)
- * (IRREGULAR: num_samples wavelengths followed by num_samples values).                 */
+ * (IRREGULAR: num_samples wavelengths followed by num_samples values).
+ * UPSAMPLED: the grid-cell lookup of evaluate() (SpectrumTypes.h:241-312) depends only on
+ * (u, v), so the caller resolves it once: `reserved` = number of data points (0 = outside
+ * the grid, 3 or 4), and the payload at data_offset (a multiple of 4 floats) is 4
+ * interpolation weights followed by num_samples (= 95) records of 4 floats: the samples of
+ * the data-point spectra interleaved per wavelength bin, [bin][point] (unused points 0).
+ * slr_amd/spectra.py:resolve_upsampled builds it.                                       */
 enum {
     SLRHIP_SPECTRUM_RGB_ONLY = 0,
     SLRHIP_SPECTRUM_UPSAMPLED = 1,

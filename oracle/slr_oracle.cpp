@@ -674,10 +674,8 @@ template <> struct EvalSpectrum<16> {
                 uint32_t sBin = (uint32_t)sBinF;
                 uint32_t sBinNext = (sBin + 1 < NumWavelengthSamples) ? (sBin + 1) : (NumWavelengthSamples - 1);
                 float t = sBinF - sBin;
-                for (uint32_t j = 0; j < numPoints; ++j) {
-                    const float* spectrum = spectra + (size_t)j * NumWavelengthSamples;
-                    ret[i] += weights[j] * (spectrum[sBin] * (1 - t) + spectrum[sBinNext] * t);
-                }
+                for (uint32_t j = 0; j < numPoints; ++j)       // samples are stored [bin][point] (include/slrhip.h)
+                    ret[i] += weights[j] * (spectra[4 * sBin + j] * (1 - t) + spectra[4 * sBinNext + j] * t);
             }
             return ret * sp.scale;
         }

@@ -36,8 +36,17 @@ SLR_DEV RGB loadEmittance(const DevMaterial* m) {
 // lambda_i of WavelengthSamples::createWithEqualOffsets, SpectrumTypes.h:54-64
 SLR_DEV float wavelengthOf(int i, float offset) { return 360.0f + (830.0f - 360.0f) * ((float)i + offset) / 16.0f; }
 
+SLR_DEV DevSpectrum loadSpectrumRecord(const DevSpectrum* spectra, int32_t idx) {
+    const uint4* q = reinterpret_cast<const uint4*>(spectra + idx);
+    const uint4 a = q[0], b = q[1];
+    DevSpectrum sp;
+    sp.kind = a.x; sp.numPoints = a.y; sp.numSamples = a.z; sp.dataOffset = a.w;
+    sp.scale = __uint_as_float(b.x); sp.lambdaMin = __uint_as_float(b.y); sp.lambdaMax = __uint_as_float(b.z); sp.pad = 0.0f;
+    return sp;
+}
+
 SLR_DEV Spec16 evalSpectrum(const DevSpectrum* spectra, const float* __restrict__ pool, int32_t idx, float wlOffset) {
-    const DevSpectrum sp = spectra[idx];
+    const DevSpectrum sp = loadSpectrumRecord(spectra, idx);
     const float* data = pool + sp.dataOffset;
     switch (sp.kind) {
     case SLRHIP_SPECTRUM_REGULAR: {
@@ -76,18 +85,19 @@ SLR_DEV Spec16 evalSpectrum(const DevSpectrum* spectra, const float* __restrict_
         if (numPoints == 0) return Spec16();
         const uint32_t nw = sp.numSamples;                // 95
         const float w0 = data[0], w1 = data[1], w2 = data[2], w3 = data[3];
-        const float* t0 = data + 4;
+        const float4* rec = reinterpret_cast<const float4*>(data + 4);     // [bin][point], 16-byte aligned (checked at upload)
         Spec16 ret = Spec16::make([&](int i) {
             float p = (wavelengthOf(i, wlOffset) - 360.0f) / (830.0f - 360.0f);
             float sBinF = p * (float)(nw - 1);
             uint32_t sBin = (uint32_t)sBinF;
             uint32_t sBinNext = (sBin + 1 < nw) ? (sBin + 1) : (nw - 1);
             float t = sBinF - (float)sBin;
+            const float4 lo = rec[sBin], hi = rec[sBinNext];
             float r = 0.0f;
-            r += w0 * (t0[sBin] * (1 - t) + t0[sBinNext] * t);
-            r += w1 * (t0[nw + sBin] * (1 - t) + t0[nw + sBinNext] * t);
-            r += w2 * (t0[2 * nw + sBin] * (1 - t) + t0[2 * nw + sBinNext] * t);
-            if (numPoints == 4) r += w3 * (t0[3 * nw + sBin] * (1 - t) + t0[3 * nw + sBinNext] * t);
+            r += w0 * (lo.x * (1 - t) + hi.x * t);
+            r += w1 * (lo.y * (1 - t) + hi.y * t);
+            r += w2 * (lo.z * (1 - t) + hi.z * t);
+            if (numPoints == 4) r += w3 * (lo.w * (1 - t) + hi.w * t);
             return r;
         });
         return ret * sp.scale;
@@ -100,7 +110,11 @@ SLR_DEV Spec16 evalSpectrum(const DevSpectrum* spectra, const float* __restrict_
 // SurfaceMaterial::getBSDF in spectral mode (basic_SurfaceMaterials.cpp:15-43, MicrofacetSurfaceMaterial.cpp:14-28):
 // evaluate the constant spectra the lobe needs at this path's wavelengths.
 SLR_DEV Mat<Spec16> loadMatSpectral(const DevMaterialS* mats, uint32_t idx, const DevSpectrum* spectra, const float* pool, float wlOffset) {
-    const DevMaterialS m = mats[idx];
+    const uint4* mq = reinterpret_cast<const uint4*>(mats + idx);
+    const uint4 m0 = mq[0], m1 = mq[1];
+    DevMaterialS m;
+    m.type = m0.x; m.param = __uint_as_float(m0.y); m.onA = __uint_as_float(m0.z); m.onB = __uint_as_float(m0.w);
+    m.spec[0] = (int32_t)m1.x; m.spec[1] = (int32_t)m1.y; m.spec[2] = (int32_t)m1.z; m.spec[3] = (int32_t)m1.w;
     Mat<Spec16> r;
     r.type = m.type; r.param = m.param; r.onA = m.onA; r.onB = m.onB;
     if (m.spec[0] >= 0) r.a = 1.0f * evalSpectrum(spectra, pool, m.spec[0], wlOffset);     // scale * spectrum, scale = 1
@@ -282,8 +296,8 @@ SLR_DEV S bsdfSample(const Mat<S>& m, uint32_t type, V3 dirOut, V3 gNorm, uint32
         GGX D_ = {m.param};
         bool entering = dirOut.z >= 0.0f;
         float sign = entering ? 1.0f : -1.0f;
-        const S& eEnter = entering ? m.b : m.c;
-        const S& eExit = entering ? m.c : m.b;
+        const S eEnter = selectSpectrum(entering, m.b, m.c);     // by value: a reference select would pin m in scratch
+        const S eExit = selectSpectrum(entering, m.c, m.b);
         V3 mm; float mPDF;
         float D = D_.sample(sign * dirOut, u0, u1, &mm, &mPDF);
         float dotHV = dot(dirOut, mm);
@@ -464,8 +478,8 @@ SLR_DEV S bsdfEvaluate(const Mat<S>& m, uint32_t type, V3 dirOut, V3 gNorm, V3 d
             fs_sn = F * D * G / (4 * dotNVdotNL);
         }
         else if (dotNVdotNL < 0 && dtMatches(flags, DT_Transmission | DT_AllFreq)) {
-            const S& eEnter = entering ? m.b : m.c;
-            const S& eExit = entering ? m.c : m.b;
+            const S eEnter = selectSpectrum(entering, m.b, m.c);
+            const S eExit = selectSpectrum(entering, m.c, m.b);
             S ret = S::make([&](int i) { return mfTransmissionWl(D_, m, eEnter, eExit, dirOut, dir, (uint32_t)i); });
             ret = ret / fabsf(dotNVdotNL);
             fs_sn = ret * (eEnter * eEnter);

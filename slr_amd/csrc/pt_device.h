@@ -97,10 +97,18 @@ struct Spec16 {
         return r;
     }
     SLR_DEV float comp(uint32_t idx) const {
-        float v = c[0];
+        // A 4-level select tree on the bits of idx over register copies.  The empty asm makes each copy opaque: without
+        // it the optimiser folds a select of two loads (or a chain of idx == i selects) back into ONE load through a
+        // selected / indexed pointer, and that pins the whole spectrum — and the struct around it — in scratch memory.
+        float t[16];
 #pragma unroll
-        for (int i = 1; i < 16; ++i) v = (idx == (uint32_t)i) ? c[i] : v;
-        return v;
+        for (int i = 0; i < 16; ++i) { t[i] = c[i]; asm volatile("" : "+v"(t[i])); }
+        const bool b0 = idx & 1u, b1 = idx & 2u, b2 = idx & 4u, b3 = idx & 8u;
+        const float p0 = b0 ? t[1] : t[0], p1 = b0 ? t[3] : t[2], p2 = b0 ? t[5] : t[4], p3 = b0 ? t[7] : t[6];
+        const float p4 = b0 ? t[9] : t[8], p5 = b0 ? t[11] : t[10], p6 = b0 ? t[13] : t[12], p7 = b0 ? t[15] : t[14];
+        const float q0 = b1 ? p1 : p0, q1 = b1 ? p3 : p2, q2 = b1 ? p5 : p4, q3 = b1 ? p7 : p6;
+        const float r0 = b2 ? q1 : q0, r1 = b2 ? q3 : q2;
+        return b3 ? r1 : r0;
     }
     SLR_DEV bool isZero() const {
         bool z = true;
@@ -139,6 +147,11 @@ SLR_DEV float importance(const S& s, uint32_t selectedLambda) {
     const float primary = 0.9f;
     const float marginal = (1 - primary) / (S::N - 1);
     return sum * marginal + s.comp(selectedLambda) * (primary - marginal);
+}
+
+SLR_DEV RGB selectSpectrum(bool pick, const RGB& a, const RGB& b) { return RGB(pick ? a.r : b.r, pick ? a.g : b.g, pick ? a.b : b.b); }
+SLR_DEV Spec16 selectSpectrum(bool pick, const Spec16& a, const Spec16& b) {
+    return Spec16::make([&](int i) { return pick ? a.c[i] : b.c[i]; });
 }
 
 // BasicTypes/CompensatedSum.h:24-30

@@ -24,6 +24,7 @@ struct DevScene {
     uint32_t numLights;
     uint32_t lightPow2;           // prevPowerOf2(numLights)
     uint32_t hasMicrofacet;       // any SLRHIP_MATERIAL_MICROFACET_* in the scene
+    uint32_t numSpectra;
     // environment sphere (InfiniteSphereSurfaceObject, SurfaceObject.cpp:137-222); RGB mode
     uint32_t hasEnv;
     uint32_t envWidth, envHeight, envMapWidth, envMapHeight;

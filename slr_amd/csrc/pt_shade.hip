@@ -47,6 +47,7 @@ enum : uint32_t {
 static const int kShadeBlock = 256;
 static const int kLdsMaterials = 32;
 static const int kLdsLights = 16;
+static const int kLdsSpectra = 96;
 
 // Spectrum-valued path state in HBM.  RGB: one float4 per slot, the scalar that travels with it in .w.
 // Spectral: four float4 planes per array (plane p of slot i at [p * numSlots + i], so every plane is a coalesced
@@ -90,13 +91,18 @@ template <> struct MatIO<RGB> {
     }
 };
 template <> struct MatIO<Spec16> {
+    // spectral mode: the LDS table holds the DevMaterialS records (2 x float4 each) followed by the DevSpectrum records
     template <bool LDS>
-    static __device__ __forceinline__ Mat<Spec16> load(const DevScene& sc, const float4*, uint32_t idx, float wlOffset) {
-        return loadMatSpectral(sc.materialsS, idx, sc.spectra, sc.spectrumPool, wlOffset);
+    static __device__ __forceinline__ Mat<Spec16> load(const DevScene& sc, const float4* ldsMats, uint32_t idx, float wlOffset) {
+        const DevMaterialS* mats = LDS ? reinterpret_cast<const DevMaterialS*>(ldsMats) : sc.materialsS;
+        const DevSpectrum* spectra = LDS ? reinterpret_cast<const DevSpectrum*>(ldsMats + 2 * kLdsMaterials) : sc.spectra;
+        return loadMatSpectral(mats, idx, spectra, sc.spectrumPool, wlOffset);
     }
     template <bool LDS>
-    static __device__ __forceinline__ Spec16 emittance(const DevScene& sc, const float4*, uint32_t idx, float wlOffset) {
-        return evalSpectrum(sc.spectra, sc.spectrumPool, sc.materialsS[idx].spec[3], wlOffset);
+    static __device__ __forceinline__ Spec16 emittance(const DevScene& sc, const float4* ldsMats, uint32_t idx, float wlOffset) {
+        const DevMaterialS* mats = LDS ? reinterpret_cast<const DevMaterialS*>(ldsMats) : sc.materialsS;
+        const DevSpectrum* spectra = LDS ? reinterpret_cast<const DevSpectrum*>(ldsMats + 2 * kLdsMaterials) : sc.spectra;
+        return evalSpectrum(spectra, sc.spectrumPool, mats[idx].spec[3], wlOffset);
     }
 };
 
@@ -189,8 +195,53 @@ __device__ __forceinline__ float envAreaPDF(const DevScene& sc, float phi, float
     return (float)((double)uvPDF / (2 * kPi * kPi * (double)sinf(theta)));
 }
 
+// SampledSpectrumSum sp of Job::contribution (PathTracingRenderer.cpp:141): see the note at its use in k_logic.
+template <class S> struct SpAcc;
+template <> struct SpAcc<RGB> {
+    RGB r, c, nee;
+    float camWeight;
+    __device__ __forceinline__ void begin(const PathBuffers& pb, uint32_t slot, uint32_t n) {
+        float unused;
+        SpecIO<RGB>::load(pb.spR, nullptr, slot, n, r, camWeight);
+        SpecIO<RGB>::load(pb.spC, nullptr, slot, n, c, unused);
+        SpecIO<RGB>::load(pb.nee, nullptr, slot, n, nee, unused);
+    }
+    __device__ __forceinline__ void addPendingNee(const PathBuffers&, uint32_t, uint32_t) { kahanAdd(r, c, nee); }
+    __device__ __forceinline__ void add(const PathBuffers&, uint32_t, uint32_t, const RGB& v) { kahanAdd(r, c, v); }
+    __device__ __forceinline__ void end(const PathBuffers& pb, uint32_t slot, uint32_t n, bool pathContinues) {
+        SpecIO<RGB>::store(pb.spR, nullptr, slot, n, r, camWeight);
+        if (pathContinues) SpecIO<RGB>::store(pb.spC, nullptr, slot, n, c, 0.0f);       // a finished path only hands over the sum
+    }
+};
+template <> struct SpAcc<Spec16> {
+    __device__ __forceinline__ void begin(const PathBuffers&, uint32_t, uint32_t) {}
+    __device__ __forceinline__ void add(const PathBuffers& pb, uint32_t slot, uint32_t n, const Spec16& v) {
+        // plane by plane: 4 components of the Kahan pair in flight at a time
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            float4 r = pb.spR[(size_t)p * n + slot], c = pb.spC[(size_t)p * n + slot];
+            kahanAdd(r.x, c.x, v.c[4 * p]); kahanAdd(r.y, c.y, v.c[4 * p + 1]);
+            kahanAdd(r.z, c.z, v.c[4 * p + 2]); kahanAdd(r.w, c.w, v.c[4 * p + 3]);
+            pb.spR[(size_t)p * n + slot] = r;
+            pb.spC[(size_t)p * n + slot] = c;
+        }
+    }
+    __device__ __forceinline__ void addPendingNee(const PathBuffers& pb, uint32_t slot, uint32_t n) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const float4 v = pb.nee[(size_t)p * n + slot];
+            float4 r = pb.spR[(size_t)p * n + slot], c = pb.spC[(size_t)p * n + slot];
+            kahanAdd(r.x, c.x, v.x); kahanAdd(r.y, c.y, v.y); kahanAdd(r.z, c.z, v.z); kahanAdd(r.w, c.w, v.w);
+            pb.spR[(size_t)p * n + slot] = r;
+            pb.spC[(size_t)p * n + slot] = c;
+        }
+    }
+    __device__ __forceinline__ void end(const PathBuffers&, uint32_t, uint32_t, bool) {}
+};
+
 struct ShadeLds {
-    float4 mats[kLdsMaterials * 5];        // DevMaterial = 5 x float4
+    // RGB: DevMaterial = 5 x float4 each.  Spectral: DevMaterialS (2 x float4 each), then DevSpectrum (2 x float4 each)
+    float4 mats[(kLdsMaterials * 5 > kLdsMaterials * 2 + kLdsSpectra * 2) ? kLdsMaterials * 5 : kLdsMaterials * 2 + kLdsSpectra * 2];
     float4 lights[kLdsLights * 9];         // LightTri   = 9 x float4
     float lightPMF[kLdsLights];
     float lightCDF[kLdsLights + 1];
@@ -204,6 +255,12 @@ __global__ __launch_bounds__(kShadeBlock) void k_logic(DevScene sc, PathBuffers 
         if (S::N == 3) {
             const float4* gm = reinterpret_cast<const float4*>(sc.materials);
             for (uint32_t i = threadIdx.x; i < sc.numMaterials * 5; i += kShadeBlock) lds.mats[i] = gm[i];
+        }
+        else {
+            const float4* gm = reinterpret_cast<const float4*>(sc.materialsS);
+            const float4* gs = reinterpret_cast<const float4*>(sc.spectra);
+            for (uint32_t i = threadIdx.x; i < sc.numMaterials * 2; i += kShadeBlock) lds.mats[i] = gm[i];
+            for (uint32_t i = threadIdx.x; i < sc.numSpectra * 2; i += kShadeBlock) lds.mats[2 * kLdsMaterials + i] = gs[i];
         }
         const float4* gl = reinterpret_cast<const float4*>(sc.lightTris);
         for (uint32_t i = threadIdx.x; i < sc.numLights * 9; i += kShadeBlock) lds.lights[i] = gl[i];
@@ -222,12 +279,14 @@ __global__ __launch_bounds__(kShadeBlock) void k_logic(DevScene sc, PathBuffers 
         // ---- all state loads up front: one memory round trip instead of a dependent chain -----------
         uint32_t flags = pb.flags[slot];
         const uint4 r4 = pb.rng[slot];
-        S alpha, spR, spC, neeC;
-        float bsdfPDFprev, camWeight, unusedW;
+        // The path's radiance sum (Kahan pair) and the pending light sample: RGB keeps them in registers (3 x 16 B,
+        // requested with everything else); in spectral mode they are 3 x 64 B that most visits never touch, so they
+        // stay in HBM and SpAcc updates them in place when a contribution actually arrives.
+        S alpha;
+        SpAcc<S> sp;
+        float bsdfPDFprev;
         SpecIO<S>::load(pb.alpha, pb.pdfPrev, slot, rp.numSlots, alpha, bsdfPDFprev);
-        SpecIO<S>::load(pb.spR, pb.camWeight, slot, rp.numSlots, spR, camWeight);
-        SpecIO<S>::load(pb.spC, nullptr, slot, rp.numSlots, spC, unusedW);
-        SpecIO<S>::load(pb.nee, nullptr, slot, rp.numSlots, neeC, unusedW);
+        sp.begin(pb, slot, rp.numSlots);
         const float4 h = pb.hit[slot];
         const float4 o4 = pb.rayOrg[slot], d4 = pb.rayDir[slot];
         const uint32_t vis = pb.visible[slot];
@@ -256,7 +315,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_logic(DevScene sc, PathBuffers 
             }
 
             // ---- 1. resolve the pending next-event estimate (:180,202) ---------------------------------
-            if (F_SHADOW(flags) && vis) kahanAdd(spR, spC, neeC);
+            if (F_SHADOW(flags) && vis) sp.addPendingNee(pb, slot, rp.numSlots);
 
             // ---- 2. the hit that just came back ------------------------------------------------------------
             Mat<S> m;
@@ -271,7 +330,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_logic(DevScene sc, PathBuffers 
                     // emittance x IBLEDF::evaluate = 1 / pi (EDFs/IBLEDF.cpp:19-23)
                     S Le = envEmittanceS<S>(sc, texU, texV) * S((float)(1.0 / kPi));
                     if (state == ST_FIRST_HIT) {
-                        kahanAdd(spR, spC, alpha * Le);                        // :152-157, atInfinity -> return sp
+                        sp.add(pb, slot, rp.numSlots, alpha * Le);             // :152-157, atInfinity -> return sp
                     }
                     else {
                         // implicit light sampling :232-250; the path ends at infinity before Russian roulette
@@ -282,7 +341,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_logic(DevScene sc, PathBuffers 
                         float MISWeight = 1.0f;
                         if (!F_DELTA(flags))
                             MISWeight = (bsdfPDFprev * bsdfPDFprev) / (lightPDF * lightPDF + bsdfPDFprev * bsdfPDFprev);
-                        kahanAdd(spR, spC, alpha * Le * MISWeight);
+                        sp.add(pb, slot, rp.numSlots, alpha * Le * MISWeight);
                     }
                 }
             }
@@ -306,7 +365,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_logic(DevScene sc, PathBuffers 
                 if (surf.light >= 0) {
                     S Le = MatIO<S>::template emittance<LDS_TABLES>(sc, lds.mats, surf.material, wlOffset) * S(diffuseEDF(dirOut_sn));
                     if (state == ST_FIRST_HIT) {
-                        kahanAdd(spR, spC, alpha * Le);                        // :152-156
+                        sp.add(pb, slot, rp.numSlots, alpha * Le);             // :152-156
                     }
                     else {
                         // implicit light sampling with MIS :232-249
@@ -317,7 +376,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_logic(DevScene sc, PathBuffers 
                         float MISWeight = 1.0f;
                         if (!F_DELTA(flags))
                             MISWeight = (bsdfPDFprev * bsdfPDFprev) / (lightPDF * lightPDF + bsdfPDFprev * bsdfPDFprev);
-                        kahanAdd(spR, spC, alpha * Le * MISWeight);
+                        sp.add(pb, slot, rp.numSlots, alpha * Le * MISWeight);
                     }
                 }
                 if (state == ST_NEXT_HIT) {
@@ -466,9 +525,8 @@ __global__ __launch_bounds__(kShadeBlock) void k_logic(DevScene sc, PathBuffers 
 
             // ---- store path state ---------------------------------------------------------------------------
             pb.flags[slot] = flags;
-            SpecIO<S>::store(pb.spR, pb.camWeight, slot, rp.numSlots, spR, camWeight);
+            sp.end(pb, slot, rp.numSlots, !emitRegen);
             if (!emitRegen) {
-                SpecIO<S>::store(pb.spC, nullptr, slot, rp.numSlots, spC, 0.0f);
                 pb.rng[slot] = make_uint4(rng.s0, rng.s1, rng.s2, rng.s3);
                 SpecIO<S>::store(pb.alpha, pb.pdfPrev, slot, rp.numSlots, alpha, bsdfPDFprev);
             }
@@ -664,7 +722,8 @@ void launchRegen(const DevScene& sc, const PathBuffers& pb, const RenderParams& 
 }
 void launchLogic(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, hipStream_t stream) {
     const dim3 grid((rp.numSlots + kShadeBlock - 1) / kShadeBlock), block(kShadeBlock);
-    const bool ldsTables = sc.numMaterials <= (uint32_t)kLdsMaterials && sc.numLights <= (uint32_t)kLdsLights;
+    const bool ldsTables = sc.numMaterials <= (uint32_t)kLdsMaterials && sc.numLights <= (uint32_t)kLdsLights &&
+                           (!rp.spectral || sc.numSpectra <= (uint32_t)kLdsSpectra);
     // The microfacet (GGX) code costs ~45 VGPRs, so scenes without such lobes get kernels without it.
     if (rp.spectral) {
         if (ldsTables && !sc.hasMicrofacet) hipLaunchKernelGGL((k_logic<Spec16, true, false>), grid, block, 0, stream, sc, pb, rp, parity);

@@ -260,6 +260,8 @@ int slrhip_upload_scene(slrhip_ctx* ctx, const slrhip_scene_desc* d) {
         if (sp.kind != SLRHIP_SPECTRUM_RGB_ONLY) {
             if (sp.num_samples < 2 || (size_t)sp.data_offset + need > d->num_spectrum_data || !d->spectrum_data)
                 return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: spectrum data out of range");
+            if (sp.kind == SLRHIP_SPECTRUM_UPSAMPLED && sp.data_offset % 4 != 0)
+                return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: upsampled spectrum payload must start at a multiple of 4 floats");
             if (sp.kind == SLRHIP_SPECTRUM_UPSAMPLED && sp.reserved != 0 && sp.reserved != 3 && sp.reserved != 4)
                 return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: upsampled spectrum must resolve to 0, 3 or 4 points");
         }
@@ -401,6 +403,7 @@ int slrhip_upload_scene(slrhip_ctx* ctx, const slrhip_scene_desc* d) {
     sc.lightCDF = ctx->lightCDF.ptr;
     sc.numNodes = (uint32_t)bvh.nodes.size();
     sc.numMaterials = (uint32_t)mats.size();
+    sc.numSpectra = (uint32_t)devSpectra.size();
     sc.numLights = (uint32_t)lights.size();
     sc.hasMicrofacet = 0;
     for (const DevMaterial& dm : mats)
@@ -479,6 +482,8 @@ int slrhip_render_begin(slrhip_ctx* ctx, const slrhip_render_settings* st, slrhi
     HIP_TRY(ctx->totals.alloc((size_t)T_KINDS * kShards * kTotalStride));
     HIP_TRY(hipMemset(ctx->totals.ptr, 0, ctx->totals.count * sizeof(uint64_t)));
     HIP_TRY(hipMemset(ctx->queueCount.ptr, 0, 2 * kQueueSetWords * sizeof(uint32_t)));
+    // hipMemset on device memory is only ordered on the null stream; slrhip_render may be given a non-blocking stream
+    HIP_TRY(hipStreamSynchronize(nullptr));
 
     PathBuffers& pb = ctx->buffers;
     pb.rng = ctx->rng.ptr; pb.rayOrg = ctx->rayOrg.ptr; pb.rayDir = ctx->rayDir.ptr; pb.hit = ctx->hit.ptr;

@@ -144,9 +144,13 @@ class SpectrumSet:
         if rgb is None:
             rgb = (srgb_degamma(e0), srgb_degamma(e1), srgb_degamma(e2)) if space == SRGB_NONLINEAR else (e0, e1, e2)
         rec["rgb"] = rgb
+        # payload: 4 weights, then the 95 samples of the (up to) four data-point spectra INTERLEAVED per wavelength bin
+        # ([bin][point], 16-byte aligned) so that evaluating one wavelength reads two 16-byte records
         spec = tables()["point_spectrum"]
-        payload = list(w) + [x for k in range(4) for x in (spec[idx[k]] if k < n else np.zeros(NUM_WL, F))]
-        return self._append(rec, payload)
+        pts = np.stack([spec[idx[k]] if k < n else np.zeros(NUM_WL, F) for k in range(4)], axis=1)      # [95][4]
+        while len(self.data) % 4:
+            self.data.append(0.0)
+        return self._append(rec, list(w) + pts.reshape(-1).tolist())
 
     def regular(self, lambda_min, lambda_max, values, rgb=(0, 0, 0), scale=1.0):
         """RegularContinuousSpectrum; `scale` multiplies the samples like createScaled (SpectrumTypes.h:112-118),
