@@ -108,5 +108,11 @@ void launchLogic(const DevScene& sc, const PathBuffers& pb, const RenderParams& 
 void launchResolve(const PathBuffers& pb, const RenderParams& rp, float* dst, hipStream_t stream);
 void launchTraceBatch(const DevScene& sc, const float4* org, const float4* dir, float4* out, uint32_t n, hipStream_t stream);
 int traceBlocksPerCU();
+// wave-specialised variants (pt_trace_ws.hip): same results, producer wave + refilled consumer waves
+void launchTraceClosestWs(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, uint32_t blocks, bool count,
+                          hipStream_t stream);
+void launchTraceShadowWs(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, uint32_t blocks, bool count,
+                         hipStream_t stream);
+int traceWsBlocksPerCU();
 
 } // namespace slrhip

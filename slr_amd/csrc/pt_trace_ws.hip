@@ -1,0 +1,396 @@
+// pt_trace_ws.hip — wave-specialised BVH traversal kernels (gfx950, wave64).
+//
+// Same results as pt_trace.hip (Scene::intersect / testVisibility, Core/SurfaceObject.cpp:408-430; QBVH::intersect,
+// Accelerator/QBVH.h:295-339; Triangle::intersect, Surface/TriangleMesh.cpp:131-178), different schedule.
+//
+// Why: PMC on the batch kernels showed 19-21 % VALU lane utilisation (SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU)):
+// a wave of 64 rays runs until its LONGEST ray is done, and in this scene most rays need 3-4 nodes while a few need 20+.
+// Refilling idle lanes needs new rays without stalling the lanes that are still traversing, and loads return in order
+// per wave (vmcnt), so a wave cannot prefetch from HBM behind its own node fetches.  Hence two roles per workgroup:
+//
+//   wave 0      PRODUCER: streams the slot arrays in order (coalesced 1 KiB bursts, four 64-slot sub-chunks in flight),
+//               keeps the slots that have a ray, and appends them to a ring of rays in LDS.
+//   waves 1..3  CONSUMERS: one lane = one ray; whenever kRefill or more lanes are idle the wave reserves that many ring
+//               entries (one LDS compare-and-swap by lane 0) and the idle lanes start on them, while the other lanes
+//               carry on mid-traversal.  A traversal step is one node (four slab tests) or ONE triangle, so lanes in
+//               different phases interleave at fine grain.
+//
+// All hand-offs are LDS atomics at workgroup scope; no global atomics, no inter-workgroup communication.  Every spin is
+// bounded (kSpinLimit) so a logic error ends the kernel instead of hanging the GPU.
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+
+#include "pt_device.h"
+#include "pt_kernels.h"
+
+namespace slrhip {
+
+// NC = consumer waves per workgroup (3 -> 256 threads, 7 -> 512 threads); the ring holds 128 rays per wave of the group
+static const int kWsLdsStack = 8;
+static const int kWsSpill = 56;            // 8 + 56 = the reference's 64-entry stack (QBVH.h:299)
+static const int kSub = 2;                 // 64-slot sub-chunks the producer keeps in flight
+static uint32_t g_refill = 20;             // idle lanes that trigger a refill (SLRHIP_WS_REFILL)
+static int g_consumers = 3;                // SLRHIP_WS_NC
+static const uint32_t kSpinLimit = 1u << 22;
+static const uint32_t kIdle = 0xFFFFFFFFu;
+
+int traceWsBlocksPerCU() {
+    static const bool init = [] {
+        if (const char* e = getenv("SLRHIP_WS_REFILL")) g_refill = (uint32_t)atoi(e);
+        if (const char* e = getenv("SLRHIP_WS_NC")) g_consumers = atoi(e) == 7 ? 7 : 3;
+        if (g_refill < 1) g_refill = 1;
+        if (g_refill > 64) g_refill = 64;
+        return true;
+    }();
+    (void)init;
+    return g_consumers == 7 ? 4 : 8;       // 15.4 KiB / 32.5 KiB of LDS per workgroup, 32 waves per CU either way (<= 64 VGPR)
+}
+
+template <int NC>
+struct WsLds {
+    static constexpr uint32_t kRing = 64u * (NC + 1);      // ray ring entries (power of two)
+    float4 org[kRing];                     // xyz + tmin
+    float4 dir[kRing];                     // xyz + tmax
+    uint32_t slot[kRing];
+    uint32_t stack[NC][kWsLdsStack * 64];
+    uint32_t tail;                         // entries published by the producer
+    uint32_t reserved;                     // entries claimed by consumers
+    uint32_t released;                     // entries consumers have finished reading (ring space)
+    uint32_t done;                         // producer has published its last entry
+    uint32_t red[NC + 1];
+};
+
+// streamed once per launch: keep them out of the vector L1 so that it stays with the BVH nodes
+typedef float wsFloat4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ntLoad4(const float4* p) {
+    const wsFloat4 v = __builtin_nontemporal_load(reinterpret_cast<const wsFloat4*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void ntStore4(float4* p, float4 q) {
+    wsFloat4 v = {q.x, q.y, q.z, q.w};
+    __builtin_nontemporal_store(v, reinterpret_cast<wsFloat4*>(p));
+}
+
+#define WS_LOAD(p, order) __hip_atomic_load((p), order, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define WS_STORE(p, v, order) __hip_atomic_store((p), (v), order, __HIP_MEMORY_SCOPE_WORKGROUP)
+
+__device__ __forceinline__ void wsBlockAdd(uint64_t* totals, uint32_t kind, uint32_t v, uint32_t* scratch) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    __syncthreads();
+    if ((threadIdx.x & 63u) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (uint32_t w = 0; w < blockDim.x / 64; ++w) t += scratch[w];
+        if (t) atomicAdd((unsigned long long*)&totals[totalIndex(kind, blockIdx.x % kShards)], (unsigned long long)t);
+    }
+}
+
+// Append the rays of one 64-lane sub-chunk that are live; returns how many were appended (wave-uniform).
+template <int NC>
+__device__ __forceinline__ uint32_t wsAppend(WsLds<NC>& lds, uint32_t tailLocal, bool live, uint32_t slot, float4 o, float4 d) {
+    const uint64_t mask = __ballot(live);
+    if (live) {
+        const uint32_t lane = threadIdx.x & 63u;
+        const uint32_t pos = (tailLocal + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))) & (WsLds<NC>::kRing - 1);
+        lds.org[pos] = o;
+        lds.dir[pos] = d;
+        lds.slot[pos] = slot;
+    }
+    return (uint32_t)__popcll(mask);
+}
+
+// Wait until the ring can take `need` more entries.  Returns false if the bound was hit (never expected).
+template <int NC>
+__device__ __forceinline__ bool wsWaitSpace(WsLds<NC>& lds, uint32_t tailLocal, uint32_t need) {
+    for (uint32_t spin = 0; spin < kSpinLimit; ++spin) {
+        const uint32_t rel = WS_LOAD(&lds.released, __ATOMIC_ACQUIRE);
+        if (tailLocal + need - rel <= WsLds<NC>::kRing) return true;
+        __builtin_amdgcn_s_sleep(8);
+    }
+    return false;
+}
+
+// The consumer side: shared by the closest-hit and the any-hit kernels.
+template <bool ANY_HIT, bool COUNT, int NC, class Sink>
+__device__ __forceinline__ void wsConsume(const DevScene& sc, WsLds<NC>& lds, uint32_t refill, Sink sink, uint32_t& nodeCount, uint32_t& triCount) {
+    constexpr uint32_t kRing = WsLds<NC>::kRing;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t below = (1ull << lane) - 1ull;
+    uint32_t* stack = lds.stack[(threadIdx.x >> 6) - 1] + lane;          // [entry][lane]
+    const float4* __restrict__ nodes4 = sc.nodes;
+    const float4* __restrict__ tris4 = sc.leafTris;
+
+    uint32_t slot = kIdle;
+    float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, idx = 0, idy = 0, idz = 0, tmin = 0, tmax = 0;
+    uint32_t cur = 0;
+    int sp = 0;
+    uint32_t hitTri = 0xFFFFFFFFu;
+    float hitT = INFINITY, hitB0 = 0.0f, hitB1 = 0.0f;
+    uint32_t spill[kWsSpill];
+    uint32_t idleSpins = 0;
+
+    for (;;) {
+        const uint64_t idleMask = __ballot(slot == kIdle);
+        const uint32_t nIdle = (uint32_t)__popcll(idleMask);
+        if (nIdle >= refill) {
+            uint32_t start = 0, take = 0;
+            if (lane == 0) {
+                // reserved <= tail at all times and tail only grows: reading reserved FIRST makes tail - reserved >= 0
+                for (int attempt = 0; attempt < 64; ++attempt) {
+                    uint32_t r = WS_LOAD(&lds.reserved, __ATOMIC_RELAXED);
+                    const uint32_t t = WS_LOAD(&lds.tail, __ATOMIC_ACQUIRE);
+                    take = min(t - r, nIdle);
+                    if (take == 0) break;
+                    if (__hip_atomic_compare_exchange_strong(&lds.reserved, &r, r + take, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_WORKGROUP)) { start = r; break; }
+                    take = 0;
+                }
+            }
+            start = __builtin_amdgcn_readfirstlane(start);
+            take = __builtin_amdgcn_readfirstlane(take);
+            if (take) {
+                idleSpins = 0;
+                const uint32_t rank = (uint32_t)__popcll(idleMask & below);
+                if (slot == kIdle && rank < take) {
+                    const uint32_t pos = (start + rank) & (kRing - 1);
+                    const float4 o = lds.org[pos], d = lds.dir[pos];
+                    slot = lds.slot[pos];
+                    ox = o.x; oy = o.y; oz = o.z; tmin = o.w;
+                    dx = d.x; dy = d.y; dz = d.z; tmax = d.w;
+                    idx = 1.0f / dx; idy = 1.0f / dy; idz = 1.0f / dz;          // Vector3.h:60 reciprocal()
+                    cur = 0; sp = 0;
+                    hitTri = 0xFFFFFFFFu; hitT = INFINITY; hitB0 = 0.0f; hitB1 = 0.0f;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");           // the ring reads above are complete
+                if (lane == 0) __hip_atomic_fetch_add(&lds.released, take, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            else if (nIdle == 64) {
+                // nothing in flight and nothing to take: finished, or the producer is behind
+                if (WS_LOAD(&lds.done, __ATOMIC_ACQUIRE) && WS_LOAD(&lds.tail, __ATOMIC_ACQUIRE) == WS_LOAD(&lds.reserved, __ATOMIC_RELAXED)) break;
+                if (++idleSpins > kSpinLimit) break;
+                __builtin_amdgcn_s_sleep(4);
+                continue;
+            }
+        }
+
+        if (slot != kIdle) {
+            bool finished = false;
+            if (cur & kLeafFlag) {
+                // ONE triangle of the leaf packet per step; the reference tests them in order (QBVH.h:322-327)
+                const uint32_t first = cur & kLeafIndexMask;
+                const uint32_t count = (cur >> kLeafCountShift) & 0xF;
+                const float4* tp = tris4 + (size_t)first * 3;
+                const float4 a = tp[0], b = tp[1], c = tp[2];
+                const V3 v0(a.x, a.y, a.z), e1(b.x, b.y, b.z), e2(c.x, c.y, c.z);
+                const uint32_t triIdx = __float_as_uint(a.w);
+                const V3 org(ox, oy, oz), dir(dx, dy, dz);
+                if (COUNT) ++triCount;
+                // Moller-Trumbore exactly as TriangleMesh.cpp:139-160
+                const V3 p = cross(dir, e2);
+                const float det = dot(e1, p);
+                bool accept = det != 0.0f;
+                const float invDet = 1.0f / det;
+                const V3 dd = org - v0;
+                const float b1 = dot(dd, p) * invDet;
+                accept = accept && !(b1 < 0.0f || b1 > 1.0f);
+                const V3 q = cross(dd, e1);
+                const float b2 = dot(dir, q) * invDet;
+                accept = accept && !(b2 < 0.0f || b1 + b2 > 1.0f);
+                const float tt = dot(e2, q) * invDet;
+                accept = accept && !(tt < tmin || tt > tmax);
+                if (accept) {
+                    if (ANY_HIT) {
+                        hitTri = triIdx;
+                        finished = true;
+                    }
+                    else if (!(tt == tmax && hitTri != 0xFFFFFFFFu && triIdx < hitTri)) {
+                        // equal distance: the larger scene index wins (tree-independent tie rule)
+                        tmax = tt;                                  // ray.distMax = isect->dist (QBVH.h:335)
+                        hitTri = triIdx;
+                        hitT = tt;
+                        hitB0 = 1.0f - b1 - b2;                     // TriangleMesh.cpp:162,172-173
+                        hitB1 = b1;
+                    }
+                }
+                if (!finished) {
+                    if (count > 1) cur = kLeafFlag | ((count - 1) << kLeafCountShift) | (first + 1);
+                    else if (sp == 0) finished = true;
+                    else { --sp; cur = sp < kWsLdsStack ? stack[sp * 64] : spill[sp - kWsLdsStack]; }
+                }
+            }
+            else {
+                if (COUNT) ++nodeCount;
+                // float4 index inside a node: 0..2 = min xyz, 3..5 = max xyz, 6 = children (QBVH.h:66-71 folded into offsets)
+                const int nx = idx > 0.0f ? 0 : 3, fx = 3 - nx;
+                const int ny = idy > 0.0f ? 1 : 4, fy = 5 - ny;
+                const int nz = idz > 0.0f ? 2 : 5, fz = 7 - nz;
+                const float4* n = nodes4 + (size_t)cur * 8;
+                const float4 nX = n[nx], nY = n[ny], nZ = n[nz], fX = n[fx], fY = n[fy], fZ = n[fz], ch = n[6];
+                // slab test of QBVH::Node::intersect (QBVH.h:55-76): tNear <= tFar
+                const float tn0 = fmaxf(fmaxf((nX.x - ox) * idx, (nY.x - oy) * idy), fmaxf((nZ.x - oz) * idz, tmin));
+                const float tn1 = fmaxf(fmaxf((nX.y - ox) * idx, (nY.y - oy) * idy), fmaxf((nZ.y - oz) * idz, tmin));
+                const float tn2 = fmaxf(fmaxf((nX.z - ox) * idx, (nY.z - oy) * idy), fmaxf((nZ.z - oz) * idz, tmin));
+                const float tn3 = fmaxf(fmaxf((nX.w - ox) * idx, (nY.w - oy) * idy), fmaxf((nZ.w - oz) * idz, tmin));
+                const float tf0 = fminf(fminf((fX.x - ox) * idx, (fY.x - oy) * idy), fminf((fZ.x - oz) * idz, tmax));
+                const float tf1 = fminf(fminf((fX.y - ox) * idx, (fY.y - oy) * idy), fminf((fZ.y - oz) * idz, tmax));
+                const float tf2 = fminf(fminf((fX.z - ox) * idx, (fY.z - oy) * idy), fminf((fZ.z - oz) * idz, tmax));
+                const float tf3 = fminf(fminf((fX.w - ox) * idx, (fY.w - oy) * idy), fminf((fZ.w - oz) * idz, tmax));
+                const uint32_t c0 = __float_as_uint(ch.x), c1 = __float_as_uint(ch.y), c2 = __float_as_uint(ch.z), c3 = __float_as_uint(ch.w);
+                const bool h0 = tn0 <= tf0 && c0 != kInvalidChild;
+                const bool h1 = tn1 <= tf1 && c1 != kInvalidChild;
+                const bool h2 = tn2 <= tf2 && c2 != kInvalidChild;
+                const bool h3 = tn3 <= tf3 && c3 != kInvalidChild;
+                // nearest hit child is visited next; the rest go on the stack
+                float best = INFINITY;
+                uint32_t next = kInvalidChild;
+                if (h0) { best = tn0; next = c0; }
+                if (h1 && tn1 < best) { best = tn1; next = c1; }
+                if (h2 && tn2 < best) { best = tn2; next = c2; }
+                if (h3 && tn3 < best) { best = tn3; next = c3; }
+#define WS_PUSH(cond, ref)                                                              \
+                if ((cond) && (ref) != next) {                                          \
+                    if (sp < kWsLdsStack) stack[sp * 64] = (ref);                       \
+                    else if (sp < kWsLdsStack + kWsSpill) spill[sp - kWsLdsStack] = (ref); \
+                    ++sp;                                                               \
+                }
+                WS_PUSH(h0, c0)
+                WS_PUSH(h1, c1)
+                WS_PUSH(h2, c2)
+                WS_PUSH(h3, c3)
+#undef WS_PUSH
+                if (next != kInvalidChild) cur = next;
+                else if (sp == 0) finished = true;
+                else { --sp; cur = sp < kWsLdsStack ? stack[sp * 64] : spill[sp - kWsLdsStack]; }
+            }
+            if (finished) {
+                sink(slot, hitTri, hitT, hitB0, hitB1);
+                slot = kIdle;
+            }
+        }
+    }
+}
+
+// Extension rays: closest hit.  The producer walks ALL slots of its share (no queue): a slot has a ray in flight iff its
+// state is FIRST_HIT or NEXT_HIT (flag values 2 and 3, pt_shade.hip).
+template <bool COUNT, int NC>
+__global__ __launch_bounds__(64 * (NC + 1)) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_trace_closest_ws(DevScene sc, PathBuffers pb, uint32_t numSlots, uint32_t parity, uint32_t refill) {
+    __shared__ WsLds<NC> lds;
+    if (blockIdx.x == 0 && threadIdx.x < Q_KINDS * kShards) {
+        // clear the counter set the logic kernel of this iteration fills
+        pb.queueCount[queueCounterIndex(parity ^ 1, threadIdx.x / kShards, threadIdx.x % kShards)] = 0;
+    }
+    if (threadIdx.x == 0) { lds.tail = 0; lds.reserved = 0; lds.released = 0; lds.done = 0; }
+    __syncthreads();
+    uint32_t rays = 0, nodeCount = 0, triCount = 0;
+    if (threadIdx.x < 64) {
+        const uint32_t lane = threadIdx.x;
+        uint32_t tailLocal = 0;
+        const uint32_t chunk = kSub * 64;
+        const uint32_t numChunks = (numSlots + chunk - 1) / chunk;
+        for (uint32_t c = blockIdx.x; c < numChunks; c += gridDim.x) {
+            uint32_t fl[kSub];
+            float4 o[kSub], d[kSub];
+#pragma unroll
+            for (int j = 0; j < kSub; ++j) {
+                const uint32_t s = c * chunk + j * 64 + lane;
+                const bool valid = s < numSlots;
+                fl[j] = valid ? __builtin_nontemporal_load(&pb.flags[s]) : 0u;
+                o[j] = valid ? ntLoad4(&pb.rayOrg[s]) : make_float4(0, 0, 0, 0);
+                d[j] = valid ? ntLoad4(&pb.rayDir[s]) : make_float4(0, 0, 0, 0);
+            }
+            if (!wsWaitSpace(lds, tailLocal, chunk)) break;
+#pragma unroll
+            for (int j = 0; j < kSub; ++j) {
+                const uint32_t state = fl[j] & 7u;
+                tailLocal += wsAppend(lds, tailLocal, state == 2u || state == 3u, c * chunk + j * 64 + lane, o[j], d[j]);
+            }
+            WS_STORE(&lds.tail, tailLocal, __ATOMIC_RELEASE);
+        }
+        WS_STORE(&lds.done, 1u, __ATOMIC_RELEASE);
+        rays = lane == 0 ? tailLocal : 0u;
+    }
+    else {
+        float4* hitOut = pb.hit;
+        wsConsume<false, COUNT, NC>(sc, lds, refill, [hitOut](uint32_t slot, uint32_t tri, float t, float b0, float b1) {
+            hitOut[slot] = make_float4(__uint_as_float(tri), t, b0, b1);
+        }, nodeCount, triCount);
+    }
+    wsBlockAdd(pb.totals, T_EXT_RAYS, rays, lds.red);
+    if (COUNT) { wsBlockAdd(pb.totals, T_NODES_CLOSEST, nodeCount, lds.red); wsBlockAdd(pb.totals, T_TRIS_CLOSEST, triCount, lds.red); }
+}
+
+// Shadow rays: Scene::testVisibility (SurfaceObject.cpp:418-430) = "no hit in [eps, d(1-eps)]".
+// Workgroup b serves queue region b % kShards (gridDim is a multiple of kShards).
+template <bool COUNT, int NC>
+__global__ __launch_bounds__(64 * (NC + 1)) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_trace_shadow_ws(DevScene sc, PathBuffers pb, uint32_t shardCapacity, uint32_t parity, uint32_t refill) {
+    __shared__ WsLds<NC> lds;
+    if (threadIdx.x == 0) { lds.tail = 0; lds.reserved = 0; lds.released = 0; lds.done = 0; }
+    __syncthreads();
+    uint32_t rays = 0, nodeCount = 0, triCount = 0;
+    if (threadIdx.x < 64) {
+        const uint32_t lane = threadIdx.x;
+        const uint32_t shard = blockIdx.x % kShards;
+        const uint32_t n = pb.queueCount[queueCounterIndex(parity, Q_SHADOW, shard)];
+        const uint32_t* queue = pb.shadowQueue + (size_t)shard * shardCapacity;
+        uint32_t tailLocal = 0;
+        const uint32_t chunk = kSub * 64;
+        const uint32_t numChunks = (n + chunk - 1) / chunk;
+        for (uint32_t c = blockIdx.x / kShards; c < numChunks; c += gridDim.x / kShards) {
+            uint32_t sl[kSub];
+            float4 o[kSub], d[kSub];
+#pragma unroll
+            for (int j = 0; j < kSub; ++j) {
+                const uint32_t i = c * chunk + j * 64 + lane;
+                sl[j] = i < n ? __builtin_nontemporal_load(&queue[i]) : kIdle;
+            }
+#pragma unroll
+            for (int j = 0; j < kSub; ++j) {
+                const bool valid = sl[j] != kIdle;
+                o[j] = valid ? ntLoad4(&pb.rayOrg[sl[j]]) : make_float4(0, 0, 0, 0);
+                d[j] = valid ? ntLoad4(&pb.shadowDir[sl[j]]) : make_float4(0, 0, 0, 0);
+                o[j].w = kRayEpsilon;
+            }
+            if (!wsWaitSpace(lds, tailLocal, chunk)) break;
+#pragma unroll
+            for (int j = 0; j < kSub; ++j) tailLocal += wsAppend(lds, tailLocal, sl[j] != kIdle, sl[j], o[j], d[j]);
+            WS_STORE(&lds.tail, tailLocal, __ATOMIC_RELEASE);
+        }
+        WS_STORE(&lds.done, 1u, __ATOMIC_RELEASE);
+        rays = lane == 0 ? tailLocal : 0u;
+    }
+    else {
+        uint32_t* visible = pb.visible;
+        wsConsume<true, COUNT, NC>(sc, lds, refill, [visible](uint32_t slot, uint32_t tri, float, float, float) {
+            visible[slot] = tri == 0xFFFFFFFFu ? 1u : 0u;
+        }, nodeCount, triCount);
+    }
+    wsBlockAdd(pb.totals, T_SHADOW_RAYS, rays, lds.red);
+    if (COUNT) { wsBlockAdd(pb.totals, T_NODES_SHADOW, nodeCount, lds.red); wsBlockAdd(pb.totals, T_TRIS_SHADOW, triCount, lds.red); }
+}
+
+void launchTraceClosestWs(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, uint32_t blocks, bool count,
+                          hipStream_t stream) {
+    if (g_consumers == 7) {
+        if (count) hipLaunchKernelGGL((k_trace_closest_ws<true, 7>), dim3(blocks), dim3(512), 0, stream, sc, pb, rp.numSlots, parity, g_refill);
+        else hipLaunchKernelGGL((k_trace_closest_ws<false, 7>), dim3(blocks), dim3(512), 0, stream, sc, pb, rp.numSlots, parity, g_refill);
+    }
+    else {
+        if (count) hipLaunchKernelGGL((k_trace_closest_ws<true, 3>), dim3(blocks), dim3(256), 0, stream, sc, pb, rp.numSlots, parity, g_refill);
+        else hipLaunchKernelGGL((k_trace_closest_ws<false, 3>), dim3(blocks), dim3(256), 0, stream, sc, pb, rp.numSlots, parity, g_refill);
+    }
+}
+void launchTraceShadowWs(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, uint32_t blocks, bool count,
+                         hipStream_t stream) {
+    blocks = (blocks + kShards - 1) / kShards * kShards;
+    if (g_consumers == 7) {
+        if (count) hipLaunchKernelGGL((k_trace_shadow_ws<true, 7>), dim3(blocks), dim3(512), 0, stream, sc, pb, rp.shardCapacity, parity, g_refill);
+        else hipLaunchKernelGGL((k_trace_shadow_ws<false, 7>), dim3(blocks), dim3(512), 0, stream, sc, pb, rp.shardCapacity, parity, g_refill);
+    }
+    else {
+        if (count) hipLaunchKernelGGL((k_trace_shadow_ws<true, 3>), dim3(blocks), dim3(256), 0, stream, sc, pb, rp.shardCapacity, parity, g_refill);
+        else hipLaunchKernelGGL((k_trace_shadow_ws<false, 3>), dim3(blocks), dim3(256), 0, stream, sc, pb, rp.shardCapacity, parity, g_refill);
+    }
+}
+
+} // namespace slrhip

@@ -524,7 +524,10 @@ int slrhip_render(slrhip_ctx* ctx, uint32_t sppBegin, uint32_t sppCount, void* s
     launchResetSlots(ctx->buffers, rp, ctx->firstRenderCall, stream);
     ctx->firstRenderCall = false;
     // persistent traversal workgroups: a fixed number per CU, each staging the top of the tree in LDS once
-    const uint32_t traceBlocks = (uint32_t)ctx->numCUs * (uint32_t)traceBlocksPerCU();
+    // Traversal schedule: wave-specialised (pt_trace_ws.hip) unless SLRHIP_TRACE=batch asks for the 64-ray-batch kernels
+    // of pt_trace.hip (kept for A/B measurements; results are identical)
+    static const bool useWs = [] { const char* e = getenv("SLRHIP_TRACE"); return !(e && std::string(e) == "batch"); }();
+    const uint32_t traceBlocks = (uint32_t)ctx->numCUs * (uint32_t)(useWs ? traceWsBlocksPerCU() : traceBlocksPerCU());
 
     uint32_t parity = 0;
     uint32_t active = rp.numSlots;
@@ -545,9 +548,11 @@ int slrhip_render(slrhip_ctx* ctx, uint32_t sppBegin, uint32_t sppCount, void* s
             if (ev) HIP_TRY(hipEventRecord(ev[0], stream));
             launchRegen(ctx->scene, ctx->buffers, rp, parity, stream);
             if (ev) HIP_TRY(hipEventRecord(ev[1], stream));
-            launchTraceClosest(ctx->scene, ctx->buffers, rp, parity, traceBlocks, count, stream);
+            if (useWs) launchTraceClosestWs(ctx->scene, ctx->buffers, rp, parity, traceBlocks, count, stream);
+            else launchTraceClosest(ctx->scene, ctx->buffers, rp, parity, traceBlocks, count, stream);
             if (ev) HIP_TRY(hipEventRecord(ev[2], stream));
-            launchTraceShadow(ctx->scene, ctx->buffers, rp, parity, traceBlocks, count, stream);
+            if (useWs) launchTraceShadowWs(ctx->scene, ctx->buffers, rp, parity, traceBlocks, count, stream);
+            else launchTraceShadow(ctx->scene, ctx->buffers, rp, parity, traceBlocks, count, stream);
             if (ev) HIP_TRY(hipEventRecord(ev[3], stream));
             launchLogic(ctx->scene, ctx->buffers, rp, parity, stream);
             if (ev) HIP_TRY(hipEventRecord(ev[4], stream));
