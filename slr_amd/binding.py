@@ -36,9 +36,10 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise HipLibraryMissing("%s not built: run `make -C slr_amd/csrc` (or __graft_entry__.build())" % LIB_PATH)
-    lib = C.CDLL(LIB_PATH)
+    path = os.environ.get("SLRHIP_LIBRARY", LIB_PATH)      # development: an alternate build of the same ABI (tools/build_variant.sh)
+    if not os.path.exists(path):
+        raise HipLibraryMissing("%s not built: run `make -C slr_amd/csrc` (or __graft_entry__.build())" % path)
+    lib = C.CDLL(path)
     lib.slrhip_create.argtypes = [C.POINTER(abi.Config), C.POINTER(C.c_void_p)]
     lib.slrhip_destroy.argtypes = [C.c_void_p]
     lib.slrhip_upload_scene.argtypes = [C.c_void_p, C.POINTER(abi.SceneDesc)]

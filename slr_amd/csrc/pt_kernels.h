@@ -55,7 +55,10 @@ __host__ __device__ inline uint32_t queueCounterIndex(uint32_t parity, uint32_t 
 }
 // statistics, sharded the same way: [kind][shard] 64-bit words on separate lines
 enum { T_EXT_RAYS = 0, T_SHADOW_RAYS = 1, T_NODES_CLOSEST = 2, T_TRIS_CLOSEST = 3, T_NODES_SHADOW = 4, T_TRIS_SHADOW = 5,
-       T_SLOT_VISITS = 6, T_KINDS = 7 };
+       T_SLOT_VISITS = 6,
+       // schedule diagnostics of the wave-specialised closest-hit kernel (counting builds only; SLRHIP_DEBUG_WS prints them)
+       T_WS_STEPS = 7, T_WS_IDLE_SPINS = 8, T_WS_CYCLES = 9, T_WS_IDLE_CYCLES = 10, T_WS_REFILLS = 11, T_WS_PRODUCER_WAITS = 12,
+       T_KINDS = 13 };
 static const uint32_t kTotalStride = 16;                   // 64-bit words: one 128-byte line
 __host__ __device__ inline uint32_t totalIndex(uint32_t kind, uint32_t shard) { return (kind * kShards + shard) * kTotalStride; }
 

@@ -26,12 +26,16 @@
 namespace slrhip {
 
 // NC = consumer waves per workgroup (3 -> 256 threads, 7 -> 512 threads); the ring holds 128 rays per wave of the group
-static const int kWsLdsStack = 8;
-static const int kWsSpill = 56;            // 8 + 56 = the reference's 64-entry stack (QBVH.h:299)
+static const int kWsLdsStack = 11;          // + 1 trash row = 12 rows of 64 lanes = 3 KiB per consumer wave
+static const int kWsSpill = 53;            // 11 + 53 = the reference's 64-entry stack (QBVH.h:299)
 static const int kSub = 2;                 // 64-slot sub-chunks the producer keeps in flight
 static uint32_t g_refill = 20;             // idle lanes that trigger a refill (SLRHIP_WS_REFILL)
 static int g_consumers = 3;                // SLRHIP_WS_NC
 static const uint32_t kSpinLimit = 1u << 22;
+#ifndef SLR_WS_CHAIN
+#define SLR_WS_CHAIN 1
+#endif
+static const bool kChain = SLR_WS_CHAIN != 0;
 static const uint32_t kIdle = 0xFFFFFFFFu;
 
 int traceWsBlocksPerCU() {
@@ -43,7 +47,7 @@ int traceWsBlocksPerCU() {
         return true;
     }();
     (void)init;
-    return g_consumers == 7 ? 4 : 8;       // 15.4 KiB / 32.5 KiB of LDS per workgroup, 32 waves per CU either way (<= 64 VGPR)
+    return g_consumers == 7 ? 4 : 8;       // 18.5 KiB / 39.5 KiB of LDS per workgroup, 32 waves per CU either way (<= 64 VGPR)
 }
 
 template <int NC>
@@ -52,7 +56,7 @@ struct WsLds {
     float4 org[kRing];                     // xyz + tmin
     float4 dir[kRing];                     // xyz + tmax
     uint32_t slot[kRing];
-    uint32_t stack[NC][kWsLdsStack * 64];
+    uint32_t stack[NC][(kWsLdsStack + 1) * 64];
     uint32_t tail;                         // entries published by the producer
     uint32_t reserved;                     // entries claimed by consumers
     uint32_t released;                     // entries consumers have finished reading (ring space)
@@ -102,18 +106,26 @@ __device__ __forceinline__ uint32_t wsAppend(WsLds<NC>& lds, uint32_t tailLocal,
 
 // Wait until the ring can take `need` more entries.  Returns false if the bound was hit (never expected).
 template <int NC>
-__device__ __forceinline__ bool wsWaitSpace(WsLds<NC>& lds, uint32_t tailLocal, uint32_t need) {
+__device__ __forceinline__ bool wsWaitSpace(WsLds<NC>& lds, uint32_t tailLocal, uint32_t need, uint32_t* waits) {
     for (uint32_t spin = 0; spin < kSpinLimit; ++spin) {
         const uint32_t rel = WS_LOAD(&lds.released, __ATOMIC_ACQUIRE);
         if (tailLocal + need - rel <= WsLds<NC>::kRing) return true;
+        ++*waits;
         __builtin_amdgcn_s_sleep(8);
     }
     return false;
 }
 
 // The consumer side: shared by the closest-hit and the any-hit kernels.
+struct WsDebug {
+    uint32_t steps = 0, idleSpins = 0, refills = 0, producerWaits = 0;
+    uint64_t cycles = 0, idleCycles = 0;
+};
+
 template <bool ANY_HIT, bool COUNT, int NC, class Sink>
-__device__ __forceinline__ void wsConsume(const DevScene& sc, WsLds<NC>& lds, uint32_t refill, Sink sink, uint32_t& nodeCount, uint32_t& triCount) {
+__device__ __forceinline__ void wsConsume(const DevScene& sc, WsLds<NC>& lds, uint32_t refill, Sink sink, uint32_t& nodeCount, uint32_t& triCount,
+                                          WsDebug& dbg) {
+    const uint64_t tStart = COUNT ? __builtin_readcyclecounter() : 0;
     constexpr uint32_t kRing = WsLds<NC>::kRing;
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t below = (1ull << lane) - 1ull;
@@ -151,6 +163,7 @@ __device__ __forceinline__ void wsConsume(const DevScene& sc, WsLds<NC>& lds, ui
             take = __builtin_amdgcn_readfirstlane(take);
             if (take) {
                 idleSpins = 0;
+                if (COUNT) ++dbg.refills;
                 const uint32_t rank = (uint32_t)__popcll(idleMask & below);
                 if (slot == kIdle && rank < take) {
                     const uint32_t pos = (start + rank) & (kRing - 1);
@@ -169,14 +182,85 @@ __device__ __forceinline__ void wsConsume(const DevScene& sc, WsLds<NC>& lds, ui
                 // nothing in flight and nothing to take: finished, or the producer is behind
                 if (WS_LOAD(&lds.done, __ATOMIC_ACQUIRE) && WS_LOAD(&lds.tail, __ATOMIC_ACQUIRE) == WS_LOAD(&lds.reserved, __ATOMIC_RELAXED)) break;
                 if (++idleSpins > kSpinLimit) break;
-                __builtin_amdgcn_s_sleep(4);
+                if (COUNT) {
+                    const uint64_t t0 = __builtin_readcyclecounter();
+                    __builtin_amdgcn_s_sleep(4);
+                    dbg.idleCycles += __builtin_readcyclecounter() - t0;
+                    ++dbg.idleSpins;
+                }
+                else __builtin_amdgcn_s_sleep(4);
                 continue;
             }
         }
 
+        if (COUNT) ++dbg.steps;
         if (slot != kIdle) {
             bool finished = false;
-            if (cur & kLeafFlag) {
+            const bool leafAtTop = (cur & kLeafFlag) != 0;
+            if (!leafAtTop) {
+                if (COUNT) ++nodeCount;
+                // float4 index inside a node: 0..2 = min xyz, 3..5 = max xyz, 6 = children (QBVH.h:66-71 folded into offsets)
+                const int nx = idx > 0.0f ? 0 : 3, fx = 3 - nx;
+                const int ny = idy > 0.0f ? 1 : 4, fy = 5 - ny;
+                const int nz = idz > 0.0f ? 2 : 5, fz = 7 - nz;
+                const float4* n = nodes4 + (size_t)cur * 8;
+                const float4 nX = n[nx], nY = n[ny], nZ = n[nz], fX = n[fx], fY = n[fy], fZ = n[fz], ch = n[6];
+                // slab test of QBVH::Node::intersect (QBVH.h:55-76): tNear <= tFar
+                const float tn0 = fmaxf(fmaxf((nX.x - ox) * idx, (nY.x - oy) * idy), fmaxf((nZ.x - oz) * idz, tmin));
+                const float tn1 = fmaxf(fmaxf((nX.y - ox) * idx, (nY.y - oy) * idy), fmaxf((nZ.y - oz) * idz, tmin));
+                const float tn2 = fmaxf(fmaxf((nX.z - ox) * idx, (nY.z - oy) * idy), fmaxf((nZ.z - oz) * idz, tmin));
+                const float tn3 = fmaxf(fmaxf((nX.w - ox) * idx, (nY.w - oy) * idy), fmaxf((nZ.w - oz) * idz, tmin));
+                const float tf0 = fminf(fminf((fX.x - ox) * idx, (fY.x - oy) * idy), fminf((fZ.x - oz) * idz, tmax));
+                const float tf1 = fminf(fminf((fX.y - ox) * idx, (fY.y - oy) * idy), fminf((fZ.y - oz) * idz, tmax));
+                const float tf2 = fminf(fminf((fX.z - ox) * idx, (fY.z - oy) * idy), fminf((fZ.z - oz) * idz, tmax));
+                const float tf3 = fminf(fminf((fX.w - ox) * idx, (fY.w - oy) * idy), fminf((fZ.w - oz) * idz, tmax));
+                const uint32_t c0 = __float_as_uint(ch.x), c1 = __float_as_uint(ch.y), c2 = __float_as_uint(ch.z), c3 = __float_as_uint(ch.w);
+                const bool h0 = tn0 <= tf0 && c0 != kInvalidChild;
+                const bool h1 = tn1 <= tf1 && c1 != kInvalidChild;
+                const bool h2 = tn2 <= tf2 && c2 != kInvalidChild;
+                const bool h3 = tn3 <= tf3 && c3 != kInvalidChild;
+                // nearest hit child is visited next; the rest go on the stack
+                float best = INFINITY;
+                uint32_t next = kInvalidChild;
+                if (h0) { best = tn0; next = c0; }
+                if (h1 && tn1 < best) { best = tn1; next = c1; }
+                if (h2 && tn2 < best) { best = tn2; next = c2; }
+                if (h3 && tn3 < best) { best = tn3; next = c3; }
+                // the hit children other than `next` go on the stack in child order.  Fast path (all of them fit in the LDS
+                // part): branch-free, a child that is not pushed writes the trash row kWsLdsStack of this lane's column.
+                const bool v0 = h0 && c0 != next, v1 = h1 && c1 != next, v2 = h2 && c2 != next, v3 = h3 && c3 != next;
+                const int nPush = (int)v0 + (int)v1 + (int)v2 + (int)v3;
+                if (sp + nPush <= kWsLdsStack) {
+                    int p = sp;
+                    stack[(v0 ? p : kWsLdsStack) * 64] = c0; p += (int)v0;
+                    stack[(v1 ? p : kWsLdsStack) * 64] = c1; p += (int)v1;
+                    stack[(v2 ? p : kWsLdsStack) * 64] = c2; p += (int)v2;
+                    stack[(v3 ? p : kWsLdsStack) * 64] = c3; p += (int)v3;
+                    sp = p;
+                }
+                else {
+#define WS_PUSH(cond, ref)                                                              \
+                    if (cond) {                                                         \
+                        if (sp < kWsLdsStack) stack[sp * 64] = (ref);                   \
+                        else if (sp < kWsLdsStack + kWsSpill) spill[sp - kWsLdsStack] = (ref); \
+                        ++sp;                                                           \
+                    }
+                    WS_PUSH(v0, c0)
+                    WS_PUSH(v1, c1)
+                    WS_PUSH(v2, c2)
+                    WS_PUSH(v3, c3)
+#undef WS_PUSH
+                }
+                if (next != kInvalidChild) cur = next;
+                else if (sp == 0) finished = true;
+                else {
+                    --sp;
+                    if (sp < kWsLdsStack) cur = stack[sp * 64];
+                    else cur = spill[sp - kWsLdsStack];
+                }
+            }
+            // kChain: a lane whose node step ended on a leaf tests that leaf's first triangle in the same iteration
+            if (!finished && (kChain ? (cur & kLeafFlag) != 0 : leafAtTop)) {
                 // ONE triangle of the leaf packet per step; the reference tests them in order (QBVH.h:322-327)
                 const uint32_t first = cur & kLeafIndexMask;
                 const uint32_t count = (cur >> kLeafCountShift) & 0xF;
@@ -216,52 +300,12 @@ __device__ __forceinline__ void wsConsume(const DevScene& sc, WsLds<NC>& lds, ui
                 if (!finished) {
                     if (count > 1) cur = kLeafFlag | ((count - 1) << kLeafCountShift) | (first + 1);
                     else if (sp == 0) finished = true;
-                    else { --sp; cur = sp < kWsLdsStack ? stack[sp * 64] : spill[sp - kWsLdsStack]; }
+                    else {
+                        --sp;
+                        if (sp < kWsLdsStack) cur = stack[sp * 64];
+                        else cur = spill[sp - kWsLdsStack];
+                    }
                 }
-            }
-            else {
-                if (COUNT) ++nodeCount;
-                // float4 index inside a node: 0..2 = min xyz, 3..5 = max xyz, 6 = children (QBVH.h:66-71 folded into offsets)
-                const int nx = idx > 0.0f ? 0 : 3, fx = 3 - nx;
-                const int ny = idy > 0.0f ? 1 : 4, fy = 5 - ny;
-                const int nz = idz > 0.0f ? 2 : 5, fz = 7 - nz;
-                const float4* n = nodes4 + (size_t)cur * 8;
-                const float4 nX = n[nx], nY = n[ny], nZ = n[nz], fX = n[fx], fY = n[fy], fZ = n[fz], ch = n[6];
-                // slab test of QBVH::Node::intersect (QBVH.h:55-76): tNear <= tFar
-                const float tn0 = fmaxf(fmaxf((nX.x - ox) * idx, (nY.x - oy) * idy), fmaxf((nZ.x - oz) * idz, tmin));
-                const float tn1 = fmaxf(fmaxf((nX.y - ox) * idx, (nY.y - oy) * idy), fmaxf((nZ.y - oz) * idz, tmin));
-                const float tn2 = fmaxf(fmaxf((nX.z - ox) * idx, (nY.z - oy) * idy), fmaxf((nZ.z - oz) * idz, tmin));
-                const float tn3 = fmaxf(fmaxf((nX.w - ox) * idx, (nY.w - oy) * idy), fmaxf((nZ.w - oz) * idz, tmin));
-                const float tf0 = fminf(fminf((fX.x - ox) * idx, (fY.x - oy) * idy), fminf((fZ.x - oz) * idz, tmax));
-                const float tf1 = fminf(fminf((fX.y - ox) * idx, (fY.y - oy) * idy), fminf((fZ.y - oz) * idz, tmax));
-                const float tf2 = fminf(fminf((fX.z - ox) * idx, (fY.z - oy) * idy), fminf((fZ.z - oz) * idz, tmax));
-                const float tf3 = fminf(fminf((fX.w - ox) * idx, (fY.w - oy) * idy), fminf((fZ.w - oz) * idz, tmax));
-                const uint32_t c0 = __float_as_uint(ch.x), c1 = __float_as_uint(ch.y), c2 = __float_as_uint(ch.z), c3 = __float_as_uint(ch.w);
-                const bool h0 = tn0 <= tf0 && c0 != kInvalidChild;
-                const bool h1 = tn1 <= tf1 && c1 != kInvalidChild;
-                const bool h2 = tn2 <= tf2 && c2 != kInvalidChild;
-                const bool h3 = tn3 <= tf3 && c3 != kInvalidChild;
-                // nearest hit child is visited next; the rest go on the stack
-                float best = INFINITY;
-                uint32_t next = kInvalidChild;
-                if (h0) { best = tn0; next = c0; }
-                if (h1 && tn1 < best) { best = tn1; next = c1; }
-                if (h2 && tn2 < best) { best = tn2; next = c2; }
-                if (h3 && tn3 < best) { best = tn3; next = c3; }
-#define WS_PUSH(cond, ref)                                                              \
-                if ((cond) && (ref) != next) {                                          \
-                    if (sp < kWsLdsStack) stack[sp * 64] = (ref);                       \
-                    else if (sp < kWsLdsStack + kWsSpill) spill[sp - kWsLdsStack] = (ref); \
-                    ++sp;                                                               \
-                }
-                WS_PUSH(h0, c0)
-                WS_PUSH(h1, c1)
-                WS_PUSH(h2, c2)
-                WS_PUSH(h3, c3)
-#undef WS_PUSH
-                if (next != kInvalidChild) cur = next;
-                else if (sp == 0) finished = true;
-                else { --sp; cur = sp < kWsLdsStack ? stack[sp * 64] : spill[sp - kWsLdsStack]; }
             }
             if (finished) {
                 sink(slot, hitTri, hitT, hitB0, hitB1);
@@ -269,6 +313,7 @@ __device__ __forceinline__ void wsConsume(const DevScene& sc, WsLds<NC>& lds, ui
             }
         }
     }
+    if (COUNT) dbg.cycles = __builtin_readcyclecounter() - tStart;
 }
 
 // Extension rays: closest hit.  The producer walks ALL slots of its share (no queue): a slot has a ray in flight iff its
@@ -283,6 +328,7 @@ __global__ __launch_bounds__(64 * (NC + 1)) __attribute__((amdgpu_waves_per_eu(8
     if (threadIdx.x == 0) { lds.tail = 0; lds.reserved = 0; lds.released = 0; lds.done = 0; }
     __syncthreads();
     uint32_t rays = 0, nodeCount = 0, triCount = 0;
+    WsDebug dbg;
     if (threadIdx.x < 64) {
         const uint32_t lane = threadIdx.x;
         uint32_t tailLocal = 0;
@@ -299,7 +345,7 @@ __global__ __launch_bounds__(64 * (NC + 1)) __attribute__((amdgpu_waves_per_eu(8
                 o[j] = valid ? ntLoad4(&pb.rayOrg[s]) : make_float4(0, 0, 0, 0);
                 d[j] = valid ? ntLoad4(&pb.rayDir[s]) : make_float4(0, 0, 0, 0);
             }
-            if (!wsWaitSpace(lds, tailLocal, chunk)) break;
+            if (!wsWaitSpace(lds, tailLocal, chunk, &dbg.producerWaits)) break;
 #pragma unroll
             for (int j = 0; j < kSub; ++j) {
                 const uint32_t state = fl[j] & 7u;
@@ -314,10 +360,19 @@ __global__ __launch_bounds__(64 * (NC + 1)) __attribute__((amdgpu_waves_per_eu(8
         float4* hitOut = pb.hit;
         wsConsume<false, COUNT, NC>(sc, lds, refill, [hitOut](uint32_t slot, uint32_t tri, float t, float b0, float b1) {
             hitOut[slot] = make_float4(__uint_as_float(tri), t, b0, b1);
-        }, nodeCount, triCount);
+        }, nodeCount, triCount, dbg);
     }
     wsBlockAdd(pb.totals, T_EXT_RAYS, rays, lds.red);
-    if (COUNT) { wsBlockAdd(pb.totals, T_NODES_CLOSEST, nodeCount, lds.red); wsBlockAdd(pb.totals, T_TRIS_CLOSEST, triCount, lds.red); }
+    if (COUNT) {
+        wsBlockAdd(pb.totals, T_NODES_CLOSEST, nodeCount, lds.red); wsBlockAdd(pb.totals, T_TRIS_CLOSEST, triCount, lds.red);
+        const bool l0 = (threadIdx.x & 63u) == 0;      // wave-level figures: lane 0 of each wave speaks; cycles in units of 64
+        wsBlockAdd(pb.totals, T_WS_STEPS, l0 ? dbg.steps : 0u, lds.red);
+        wsBlockAdd(pb.totals, T_WS_IDLE_SPINS, l0 ? dbg.idleSpins : 0u, lds.red);
+        wsBlockAdd(pb.totals, T_WS_CYCLES, l0 ? (uint32_t)(dbg.cycles >> 6) : 0u, lds.red);
+        wsBlockAdd(pb.totals, T_WS_IDLE_CYCLES, l0 ? (uint32_t)(dbg.idleCycles >> 6) : 0u, lds.red);
+        wsBlockAdd(pb.totals, T_WS_REFILLS, l0 ? dbg.refills : 0u, lds.red);
+        wsBlockAdd(pb.totals, T_WS_PRODUCER_WAITS, l0 ? dbg.producerWaits : 0u, lds.red);
+    }
 }
 
 // Shadow rays: Scene::testVisibility (SurfaceObject.cpp:418-430) = "no hit in [eps, d(1-eps)]".
@@ -328,6 +383,7 @@ __global__ __launch_bounds__(64 * (NC + 1)) __attribute__((amdgpu_waves_per_eu(8
     if (threadIdx.x == 0) { lds.tail = 0; lds.reserved = 0; lds.released = 0; lds.done = 0; }
     __syncthreads();
     uint32_t rays = 0, nodeCount = 0, triCount = 0;
+    WsDebug dbg;
     if (threadIdx.x < 64) {
         const uint32_t lane = threadIdx.x;
         const uint32_t shard = blockIdx.x % kShards;
@@ -351,7 +407,7 @@ __global__ __launch_bounds__(64 * (NC + 1)) __attribute__((amdgpu_waves_per_eu(8
                 d[j] = valid ? ntLoad4(&pb.shadowDir[sl[j]]) : make_float4(0, 0, 0, 0);
                 o[j].w = kRayEpsilon;
             }
-            if (!wsWaitSpace(lds, tailLocal, chunk)) break;
+            if (!wsWaitSpace(lds, tailLocal, chunk, &dbg.producerWaits)) break;
 #pragma unroll
             for (int j = 0; j < kSub; ++j) tailLocal += wsAppend(lds, tailLocal, sl[j] != kIdle, sl[j], o[j], d[j]);
             WS_STORE(&lds.tail, tailLocal, __ATOMIC_RELEASE);
@@ -363,7 +419,7 @@ __global__ __launch_bounds__(64 * (NC + 1)) __attribute__((amdgpu_waves_per_eu(8
         uint32_t* visible = pb.visible;
         wsConsume<true, COUNT, NC>(sc, lds, refill, [visible](uint32_t slot, uint32_t tri, float, float, float) {
             visible[slot] = tri == 0xFFFFFFFFu ? 1u : 0u;
-        }, nodeCount, triCount);
+        }, nodeCount, triCount, dbg);
     }
     wsBlockAdd(pb.totals, T_SHADOW_RAYS, rays, lds.red);
     if (COUNT) { wsBlockAdd(pb.totals, T_NODES_SHADOW, nodeCount, lds.red); wsBlockAdd(pb.totals, T_TRIS_SHADOW, triCount, lds.red); }

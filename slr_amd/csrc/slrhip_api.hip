@@ -141,6 +141,12 @@ static int readTotals(slrhip_ctx* ctx, uint64_t* out) {
         out[k] = 0;
         for (uint32_t sh = 0; sh < kShards; ++sh) out[k] += raw[totalIndex(k, sh)];
     }
+    if (getenv("SLRHIP_DEBUG_WS") && out[T_WS_STEPS])
+        fprintf(stderr, "ws closest: rays %llu nodes %llu tris %llu | consumer wave-steps %llu refills %llu idle spins %llu | "
+                        "consumer wave cycles %llu x64, idle %llu x64 | producer waits %llu\n",
+                (unsigned long long)out[T_EXT_RAYS], (unsigned long long)out[T_NODES_CLOSEST], (unsigned long long)out[T_TRIS_CLOSEST],
+                (unsigned long long)out[T_WS_STEPS], (unsigned long long)out[T_WS_REFILLS], (unsigned long long)out[T_WS_IDLE_SPINS],
+                (unsigned long long)out[T_WS_CYCLES], (unsigned long long)out[T_WS_IDLE_CYCLES], (unsigned long long)out[T_WS_PRODUCER_WAITS]);
     return SLRHIP_OK;
 }
 

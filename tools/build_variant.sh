@@ -1,0 +1,15 @@
+#!/bin/bash
+# tools/build_variant.sh NAME FILE.hip "EXTRA FLAGS" — an alternate libslrhip with one translation unit rebuilt with extra
+# -D flags, for A/B timing on the GPU box: SLRHIP_LIBRARY=slr_amd/csrc/variants/libslrhip_NAME.so python bench.py ...
+set -e
+cd "$(dirname "$0")/../slr_amd/csrc"
+name=$1; src=$2; extra=$3
+mkdir -p variants
+make -s libslrhip.so
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-function $extra -c $src -o variants/${src%.hip}_$name.o
+objs=""
+for o in pt_trace.o pt_trace_ws.o pt_shade.o slrhip_api.o bvh.o host_util.o; do
+  if [ "$o" = "${src%.hip}.o" ]; then objs="$objs variants/${src%.hip}_$name.o"; else objs="$objs $o"; fi
+done
+hipcc --offload-arch=gfx950 -shared -o variants/libslrhip_$name.so $objs
+echo variants/libslrhip_$name.so
