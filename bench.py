@@ -182,6 +182,13 @@ def main():
                        "trace_shadow": nodes_s * NODE_BYTES + tris_s * TRI_BYTES + SHADOW_RAY_BYTES}
             shard_samples = float(counters.samples) * args.steps     # sample totals restart at every render_begin
             rays = {"trace_closest": shard_samples * ext_per_sample, "trace_shadow": shard_samples * shd_per_sample}
+            # the wave-specialised schedule traces both ray kinds in ONE launch, booked under trace_closest
+            merged = kernels["trace_shadow"]["launches"] == 0
+            if merged:
+                kernels["trace"] = kernels.pop("trace_closest")
+                kernels.pop("trace_shadow")
+                rays["trace"] = 1.0        # unit = one launch's worth of both kinds, bytes below
+                per_ray["trace"] = rays["trace_closest"] * per_ray["trace_closest"] + rays["trace_shadow"] * per_ray["trace_shadow"]
             dom = max(kernels, key=lambda n: kernels[n]["ms_total"])
             if dom == "shade":
                 # every live slot is visited once per iteration = once per extension ray (+ idle tail ignored)

@@ -111,11 +111,9 @@ void launchLogic(const DevScene& sc, const PathBuffers& pb, const RenderParams& 
 void launchResolve(const PathBuffers& pb, const RenderParams& rp, float* dst, hipStream_t stream);
 void launchTraceBatch(const DevScene& sc, const float4* org, const float4* dir, float4* out, uint32_t n, hipStream_t stream);
 int traceBlocksPerCU();
-// wave-specialised variants (pt_trace_ws.hip): same results, producer wave + refilled consumer waves
-void launchTraceClosestWs(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, uint32_t blocks, bool count,
-                          hipStream_t stream);
-void launchTraceShadowWs(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, uint32_t blocks, bool count,
-                         hipStream_t stream);
+// wave-specialised traversal (pt_trace_ws.hip): same results, ONE launch for the extension and the shadow rays of an iteration
+void launchTraceWs(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, uint32_t blocks, bool count,
+                   hipStream_t stream);
 int traceWsBlocksPerCU();
 
 } // namespace slrhip

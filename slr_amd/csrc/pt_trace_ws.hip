@@ -122,9 +122,14 @@ struct WsDebug {
     uint64_t cycles = 0, idleCycles = 0;
 };
 
-template <bool ANY_HIT, bool COUNT, int NC, class Sink>
-__device__ __forceinline__ void wsConsume(const DevScene& sc, WsLds<NC>& lds, uint32_t refill, Sink sink, uint32_t& nodeCount, uint32_t& triCount,
-                                          WsDebug& dbg) {
+static const uint32_t kShadowBit = 0x80000000u;   // ring slot word: bit 31 = shadow (any-hit) ray, bits 30..0 = slot
+
+struct WsCounts {
+    uint32_t nodes[2] = {0, 0}, tris[2] = {0, 0};   // [0] closest, [1] shadow
+};
+
+template <bool COUNT, int NC>
+__device__ __forceinline__ void wsConsume(const DevScene& sc, const PathBuffers& pb, WsLds<NC>& lds, uint32_t refill, WsCounts& cnt, WsDebug& dbg) {
     const uint64_t tStart = COUNT ? __builtin_readcyclecounter() : 0;
     constexpr uint32_t kRing = WsLds<NC>::kRing;
     const uint32_t lane = threadIdx.x & 63u;
@@ -175,8 +180,16 @@ __device__ __forceinline__ void wsConsume(const DevScene& sc, WsLds<NC>& lds, ui
                     cur = 0; sp = 0;
                     hitTri = 0xFFFFFFFFu; hitT = INFINITY; hitB0 = 0.0f; hitB1 = 0.0f;
                 }
+                // Ring space is handed back IN RESERVATION ORDER: `released` is a watermark, the producer overwrites
+                // everything below it, so this wave may only move it past its own entries once every earlier
+                // reservation (another wave, possibly still reading) has been released.  The wait is a few hundred
+                // cycles at most: the earlier wave is between its compare-and-swap and the end of its own ring reads.
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");           // the ring reads above are complete
-                if (lane == 0) __hip_atomic_fetch_add(&lds.released, take, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (lane == 0) {
+                    for (uint32_t spin = 0; spin < kSpinLimit && WS_LOAD(&lds.released, __ATOMIC_ACQUIRE) != start; ++spin)
+                        __builtin_amdgcn_s_sleep(1);
+                    WS_STORE(&lds.released, start + take, __ATOMIC_RELEASE);
+                }
             }
             else if (nIdle == 64) {
                 // nothing in flight and nothing to take: finished, or the producer is behind
@@ -198,7 +211,7 @@ __device__ __forceinline__ void wsConsume(const DevScene& sc, WsLds<NC>& lds, ui
             bool finished = false;
             const bool leafAtTop = (cur & kLeafFlag) != 0;
             if (!leafAtTop) {
-                if (COUNT) ++nodeCount;
+                if (COUNT) { const bool sh = (slot & kShadowBit) != 0; cnt.nodes[0] += sh ? 0u : 1u; cnt.nodes[1] += sh ? 1u : 0u; }
                 // float4 index inside a node: 0..2 = min xyz, 3..5 = max xyz, 6 = children (QBVH.h:66-71 folded into offsets)
                 const int nx = idx > 0.0f ? 0 : 3, fx = 3 - nx;
                 const int ny = idy > 0.0f ? 1 : 4, fy = 5 - ny;
@@ -269,7 +282,8 @@ __device__ __forceinline__ void wsConsume(const DevScene& sc, WsLds<NC>& lds, ui
                 const V3 v0(a.x, a.y, a.z), e1(b.x, b.y, b.z), e2(c.x, c.y, c.z);
                 const uint32_t triIdx = __float_as_uint(a.w);
                 const V3 org(ox, oy, oz), dir(dx, dy, dz);
-                if (COUNT) ++triCount;
+                const bool anyHit = (slot & kShadowBit) != 0;
+                if (COUNT) { cnt.tris[0] += anyHit ? 0u : 1u; cnt.tris[1] += anyHit ? 1u : 0u; }
                 // Moller-Trumbore exactly as TriangleMesh.cpp:139-160
                 const V3 p = cross(dir, e2);
                 const float det = dot(e1, p);
@@ -284,7 +298,7 @@ __device__ __forceinline__ void wsConsume(const DevScene& sc, WsLds<NC>& lds, ui
                 const float tt = dot(e2, q) * invDet;
                 accept = accept && !(tt < tmin || tt > tmax);
                 if (accept) {
-                    if (ANY_HIT) {
+                    if (anyHit) {
                         hitTri = triIdx;
                         finished = true;
                     }
@@ -308,7 +322,8 @@ __device__ __forceinline__ void wsConsume(const DevScene& sc, WsLds<NC>& lds, ui
                 }
             }
             if (finished) {
-                sink(slot, hitTri, hitT, hitB0, hitB1);
+                if (slot & kShadowBit) pb.visible[slot & ~kShadowBit] = hitTri == 0xFFFFFFFFu ? 1u : 0u;      // testVisibility
+                else pb.hit[slot] = make_float4(__uint_as_float(hitTri), hitT, hitB0, hitB1);
                 slot = kIdle;
             }
         }
@@ -316,10 +331,14 @@ __device__ __forceinline__ void wsConsume(const DevScene& sc, WsLds<NC>& lds, ui
     if (COUNT) dbg.cycles = __builtin_readcyclecounter() - tStart;
 }
 
-// Extension rays: closest hit.  The producer walks ALL slots of its share (no queue): a slot has a ray in flight iff its
-// state is FIRST_HIT or NEXT_HIT (flag values 2 and 3, pt_shade.hip).
+// ONE launch traces both ray kinds of an iteration, so the tail of the extension rays (the last long rays of a few
+// waves) is filled by shadow rays instead of idle CUs; measured: ~70 + ~50 us of fixed cost per launch pair before.
+//   phase 1, extension rays (closest hit): the producer walks ALL slots of its share (no queue); a slot has a ray in flight
+//            iff its state is FIRST_HIT or NEXT_HIT (flag values 2 and 3, pt_shade.hip).
+//   phase 2, shadow rays: Scene::testVisibility (SurfaceObject.cpp:418-430) = "no hit in [eps, d(1-eps)]"; workgroup b
+//            serves queue region b % kShards (gridDim is a multiple of kShards).
 template <bool COUNT, int NC>
-__global__ __launch_bounds__(64 * (NC + 1)) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_trace_closest_ws(DevScene sc, PathBuffers pb, uint32_t numSlots, uint32_t parity, uint32_t refill) {
+__global__ __launch_bounds__(64 * (NC + 1)) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_trace_ws(DevScene sc, PathBuffers pb, uint32_t numSlots, uint32_t shardCapacity, uint32_t parity, uint32_t refill) {
     __shared__ WsLds<NC> lds;
     if (blockIdx.x == 0 && threadIdx.x < Q_KINDS * kShards) {
         // clear the counter set the logic kernel of this iteration fills
@@ -327,44 +346,76 @@ __global__ __launch_bounds__(64 * (NC + 1)) __attribute__((amdgpu_waves_per_eu(8
     }
     if (threadIdx.x == 0) { lds.tail = 0; lds.reserved = 0; lds.released = 0; lds.done = 0; }
     __syncthreads();
-    uint32_t rays = 0, nodeCount = 0, triCount = 0;
+    uint32_t extRays = 0, shadowRays = 0;
+    WsCounts cnt;
     WsDebug dbg;
     if (threadIdx.x < 64) {
         const uint32_t lane = threadIdx.x;
         uint32_t tailLocal = 0;
         const uint32_t chunk = kSub * 64;
-        const uint32_t numChunks = (numSlots + chunk - 1) / chunk;
-        for (uint32_t c = blockIdx.x; c < numChunks; c += gridDim.x) {
-            uint32_t fl[kSub];
-            float4 o[kSub], d[kSub];
+        bool ok = true;
+        {
+            const uint32_t numChunks = (numSlots + chunk - 1) / chunk;
+            for (uint32_t c = blockIdx.x; ok && c < numChunks; c += gridDim.x) {
+                uint32_t fl[kSub];
+                float4 o[kSub], d[kSub];
 #pragma unroll
-            for (int j = 0; j < kSub; ++j) {
-                const uint32_t s = c * chunk + j * 64 + lane;
-                const bool valid = s < numSlots;
-                fl[j] = valid ? __builtin_nontemporal_load(&pb.flags[s]) : 0u;
-                o[j] = valid ? ntLoad4(&pb.rayOrg[s]) : make_float4(0, 0, 0, 0);
-                d[j] = valid ? ntLoad4(&pb.rayDir[s]) : make_float4(0, 0, 0, 0);
-            }
-            if (!wsWaitSpace(lds, tailLocal, chunk, &dbg.producerWaits)) break;
+                for (int j = 0; j < kSub; ++j) {
+                    const uint32_t s = c * chunk + j * 64 + lane;
+                    const bool valid = s < numSlots;
+                    fl[j] = valid ? __builtin_nontemporal_load(&pb.flags[s]) : 0u;
+                    o[j] = valid ? ntLoad4(&pb.rayOrg[s]) : make_float4(0, 0, 0, 0);
+                    d[j] = valid ? ntLoad4(&pb.rayDir[s]) : make_float4(0, 0, 0, 0);
+                }
+                ok = wsWaitSpace(lds, tailLocal, chunk, &dbg.producerWaits);
+                if (!ok) break;
 #pragma unroll
-            for (int j = 0; j < kSub; ++j) {
-                const uint32_t state = fl[j] & 7u;
-                tailLocal += wsAppend(lds, tailLocal, state == 2u || state == 3u, c * chunk + j * 64 + lane, o[j], d[j]);
+                for (int j = 0; j < kSub; ++j) {
+                    const uint32_t state = fl[j] & 7u;
+                    tailLocal += wsAppend(lds, tailLocal, state == 2u || state == 3u, c * chunk + j * 64 + lane, o[j], d[j]);
+                }
+                WS_STORE(&lds.tail, tailLocal, __ATOMIC_RELEASE);
             }
-            WS_STORE(&lds.tail, tailLocal, __ATOMIC_RELEASE);
+            extRays = tailLocal;
+        }
+        if (ok) {
+            const uint32_t shard = blockIdx.x % kShards;
+            const uint32_t n = pb.queueCount[queueCounterIndex(parity, Q_SHADOW, shard)];
+            const uint32_t* queue = pb.shadowQueue + (size_t)shard * shardCapacity;
+            const uint32_t numChunks = (n + chunk - 1) / chunk;
+            for (uint32_t c = blockIdx.x / kShards; c < numChunks; c += gridDim.x / kShards) {
+                uint32_t sl[kSub];
+                float4 o[kSub], d[kSub];
+#pragma unroll
+                for (int j = 0; j < kSub; ++j) {
+                    const uint32_t i = c * chunk + j * 64 + lane;
+                    sl[j] = i < n ? __builtin_nontemporal_load(&queue[i]) : kIdle;
+                }
+#pragma unroll
+                for (int j = 0; j < kSub; ++j) {
+                    const bool valid = sl[j] != kIdle;
+                    o[j] = valid ? ntLoad4(&pb.rayOrg[sl[j]]) : make_float4(0, 0, 0, 0);
+                    d[j] = valid ? ntLoad4(&pb.shadowDir[sl[j]]) : make_float4(0, 0, 0, 0);
+                    o[j].w = kRayEpsilon;
+                }
+                if (!wsWaitSpace(lds, tailLocal, chunk, &dbg.producerWaits)) break;
+#pragma unroll
+                for (int j = 0; j < kSub; ++j) tailLocal += wsAppend(lds, tailLocal, sl[j] != kIdle, sl[j] | kShadowBit, o[j], d[j]);
+                WS_STORE(&lds.tail, tailLocal, __ATOMIC_RELEASE);
+            }
+            shadowRays = tailLocal - extRays;
         }
         WS_STORE(&lds.done, 1u, __ATOMIC_RELEASE);
-        rays = lane == 0 ? tailLocal : 0u;
+        if (lane != 0) { extRays = 0; shadowRays = 0; }
     }
     else {
-        float4* hitOut = pb.hit;
-        wsConsume<false, COUNT, NC>(sc, lds, refill, [hitOut](uint32_t slot, uint32_t tri, float t, float b0, float b1) {
-            hitOut[slot] = make_float4(__uint_as_float(tri), t, b0, b1);
-        }, nodeCount, triCount, dbg);
+        wsConsume<COUNT, NC>(sc, pb, lds, refill, cnt, dbg);
     }
-    wsBlockAdd(pb.totals, T_EXT_RAYS, rays, lds.red);
+    wsBlockAdd(pb.totals, T_EXT_RAYS, extRays, lds.red);
+    wsBlockAdd(pb.totals, T_SHADOW_RAYS, shadowRays, lds.red);
     if (COUNT) {
-        wsBlockAdd(pb.totals, T_NODES_CLOSEST, nodeCount, lds.red); wsBlockAdd(pb.totals, T_TRIS_CLOSEST, triCount, lds.red);
+        wsBlockAdd(pb.totals, T_NODES_CLOSEST, cnt.nodes[0], lds.red); wsBlockAdd(pb.totals, T_TRIS_CLOSEST, cnt.tris[0], lds.red);
+        wsBlockAdd(pb.totals, T_NODES_SHADOW, cnt.nodes[1], lds.red); wsBlockAdd(pb.totals, T_TRIS_SHADOW, cnt.tris[1], lds.red);
         const bool l0 = (threadIdx.x & 63u) == 0;      // wave-level figures: lane 0 of each wave speaks; cycles in units of 64
         wsBlockAdd(pb.totals, T_WS_STEPS, l0 ? dbg.steps : 0u, lds.red);
         wsBlockAdd(pb.totals, T_WS_IDLE_SPINS, l0 ? dbg.idleSpins : 0u, lds.red);
@@ -375,77 +426,16 @@ __global__ __launch_bounds__(64 * (NC + 1)) __attribute__((amdgpu_waves_per_eu(8
     }
 }
 
-// Shadow rays: Scene::testVisibility (SurfaceObject.cpp:418-430) = "no hit in [eps, d(1-eps)]".
-// Workgroup b serves queue region b % kShards (gridDim is a multiple of kShards).
-template <bool COUNT, int NC>
-__global__ __launch_bounds__(64 * (NC + 1)) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_trace_shadow_ws(DevScene sc, PathBuffers pb, uint32_t shardCapacity, uint32_t parity, uint32_t refill) {
-    __shared__ WsLds<NC> lds;
-    if (threadIdx.x == 0) { lds.tail = 0; lds.reserved = 0; lds.released = 0; lds.done = 0; }
-    __syncthreads();
-    uint32_t rays = 0, nodeCount = 0, triCount = 0;
-    WsDebug dbg;
-    if (threadIdx.x < 64) {
-        const uint32_t lane = threadIdx.x;
-        const uint32_t shard = blockIdx.x % kShards;
-        const uint32_t n = pb.queueCount[queueCounterIndex(parity, Q_SHADOW, shard)];
-        const uint32_t* queue = pb.shadowQueue + (size_t)shard * shardCapacity;
-        uint32_t tailLocal = 0;
-        const uint32_t chunk = kSub * 64;
-        const uint32_t numChunks = (n + chunk - 1) / chunk;
-        for (uint32_t c = blockIdx.x / kShards; c < numChunks; c += gridDim.x / kShards) {
-            uint32_t sl[kSub];
-            float4 o[kSub], d[kSub];
-#pragma unroll
-            for (int j = 0; j < kSub; ++j) {
-                const uint32_t i = c * chunk + j * 64 + lane;
-                sl[j] = i < n ? __builtin_nontemporal_load(&queue[i]) : kIdle;
-            }
-#pragma unroll
-            for (int j = 0; j < kSub; ++j) {
-                const bool valid = sl[j] != kIdle;
-                o[j] = valid ? ntLoad4(&pb.rayOrg[sl[j]]) : make_float4(0, 0, 0, 0);
-                d[j] = valid ? ntLoad4(&pb.shadowDir[sl[j]]) : make_float4(0, 0, 0, 0);
-                o[j].w = kRayEpsilon;
-            }
-            if (!wsWaitSpace(lds, tailLocal, chunk, &dbg.producerWaits)) break;
-#pragma unroll
-            for (int j = 0; j < kSub; ++j) tailLocal += wsAppend(lds, tailLocal, sl[j] != kIdle, sl[j], o[j], d[j]);
-            WS_STORE(&lds.tail, tailLocal, __ATOMIC_RELEASE);
-        }
-        WS_STORE(&lds.done, 1u, __ATOMIC_RELEASE);
-        rays = lane == 0 ? tailLocal : 0u;
-    }
-    else {
-        uint32_t* visible = pb.visible;
-        wsConsume<true, COUNT, NC>(sc, lds, refill, [visible](uint32_t slot, uint32_t tri, float, float, float) {
-            visible[slot] = tri == 0xFFFFFFFFu ? 1u : 0u;
-        }, nodeCount, triCount, dbg);
-    }
-    wsBlockAdd(pb.totals, T_SHADOW_RAYS, rays, lds.red);
-    if (COUNT) { wsBlockAdd(pb.totals, T_NODES_SHADOW, nodeCount, lds.red); wsBlockAdd(pb.totals, T_TRIS_SHADOW, triCount, lds.red); }
-}
-
-void launchTraceClosestWs(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, uint32_t blocks, bool count,
-                          hipStream_t stream) {
-    if (g_consumers == 7) {
-        if (count) hipLaunchKernelGGL((k_trace_closest_ws<true, 7>), dim3(blocks), dim3(512), 0, stream, sc, pb, rp.numSlots, parity, g_refill);
-        else hipLaunchKernelGGL((k_trace_closest_ws<false, 7>), dim3(blocks), dim3(512), 0, stream, sc, pb, rp.numSlots, parity, g_refill);
-    }
-    else {
-        if (count) hipLaunchKernelGGL((k_trace_closest_ws<true, 3>), dim3(blocks), dim3(256), 0, stream, sc, pb, rp.numSlots, parity, g_refill);
-        else hipLaunchKernelGGL((k_trace_closest_ws<false, 3>), dim3(blocks), dim3(256), 0, stream, sc, pb, rp.numSlots, parity, g_refill);
-    }
-}
-void launchTraceShadowWs(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, uint32_t blocks, bool count,
-                         hipStream_t stream) {
+void launchTraceWs(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, uint32_t blocks, bool count,
+                   hipStream_t stream) {
     blocks = (blocks + kShards - 1) / kShards * kShards;
     if (g_consumers == 7) {
-        if (count) hipLaunchKernelGGL((k_trace_shadow_ws<true, 7>), dim3(blocks), dim3(512), 0, stream, sc, pb, rp.shardCapacity, parity, g_refill);
-        else hipLaunchKernelGGL((k_trace_shadow_ws<false, 7>), dim3(blocks), dim3(512), 0, stream, sc, pb, rp.shardCapacity, parity, g_refill);
+        if (count) hipLaunchKernelGGL((k_trace_ws<true, 7>), dim3(blocks), dim3(512), 0, stream, sc, pb, rp.numSlots, rp.shardCapacity, parity, g_refill);
+        else hipLaunchKernelGGL((k_trace_ws<false, 7>), dim3(blocks), dim3(512), 0, stream, sc, pb, rp.numSlots, rp.shardCapacity, parity, g_refill);
     }
     else {
-        if (count) hipLaunchKernelGGL((k_trace_shadow_ws<true, 3>), dim3(blocks), dim3(256), 0, stream, sc, pb, rp.shardCapacity, parity, g_refill);
-        else hipLaunchKernelGGL((k_trace_shadow_ws<false, 3>), dim3(blocks), dim3(256), 0, stream, sc, pb, rp.shardCapacity, parity, g_refill);
+        if (count) hipLaunchKernelGGL((k_trace_ws<true, 3>), dim3(blocks), dim3(256), 0, stream, sc, pb, rp.numSlots, rp.shardCapacity, parity, g_refill);
+        else hipLaunchKernelGGL((k_trace_ws<false, 3>), dim3(blocks), dim3(256), 0, stream, sc, pb, rp.numSlots, rp.shardCapacity, parity, g_refill);
     }
 }
 

@@ -531,8 +531,9 @@ int slrhip_render(slrhip_ctx* ctx, uint32_t sppBegin, uint32_t sppCount, void* s
     ctx->firstRenderCall = false;
     // persistent traversal workgroups: a fixed number per CU, each staging the top of the tree in LDS once
     // Traversal schedule: wave-specialised (pt_trace_ws.hip) unless SLRHIP_TRACE=batch asks for the 64-ray-batch kernels
-    // of pt_trace.hip (kept for A/B measurements; results are identical)
-    static const bool useWs = [] { const char* e = getenv("SLRHIP_TRACE"); return !(e && std::string(e) == "batch"); }();
+    // of pt_trace.hip, and so does SLRHIP_FLAG_TRACE_BATCH per context (kept for A/B checks; results are identical)
+    static const bool envBatch = [] { const char* e = getenv("SLRHIP_TRACE"); return e && std::string(e) == "batch"; }();
+    const bool useWs = !envBatch && !(ctx->config.flags & SLRHIP_FLAG_TRACE_BATCH);
     const uint32_t traceBlocks = (uint32_t)ctx->numCUs * (uint32_t)(useWs ? traceWsBlocksPerCU() : traceBlocksPerCU());
 
     uint32_t parity = 0;
@@ -554,12 +555,17 @@ int slrhip_render(slrhip_ctx* ctx, uint32_t sppBegin, uint32_t sppCount, void* s
             if (ev) HIP_TRY(hipEventRecord(ev[0], stream));
             launchRegen(ctx->scene, ctx->buffers, rp, parity, stream);
             if (ev) HIP_TRY(hipEventRecord(ev[1], stream));
-            if (useWs) launchTraceClosestWs(ctx->scene, ctx->buffers, rp, parity, traceBlocks, count, stream);
-            else launchTraceClosest(ctx->scene, ctx->buffers, rp, parity, traceBlocks, count, stream);
-            if (ev) HIP_TRY(hipEventRecord(ev[2], stream));
-            if (useWs) launchTraceShadowWs(ctx->scene, ctx->buffers, rp, parity, traceBlocks, count, stream);
-            else launchTraceShadow(ctx->scene, ctx->buffers, rp, parity, traceBlocks, count, stream);
-            if (ev) HIP_TRY(hipEventRecord(ev[3], stream));
+            if (useWs) {
+                // both ray kinds in one launch: its time is booked under TRACE_CLOSEST, TRACE_SHADOW counts no launches
+                launchTraceWs(ctx->scene, ctx->buffers, rp, parity, traceBlocks, count, stream);
+                if (ev) { HIP_TRY(hipEventRecord(ev[2], stream)); HIP_TRY(hipEventRecord(ev[3], stream)); }
+            }
+            else {
+                launchTraceClosest(ctx->scene, ctx->buffers, rp, parity, traceBlocks, count, stream);
+                if (ev) HIP_TRY(hipEventRecord(ev[2], stream));
+                launchTraceShadow(ctx->scene, ctx->buffers, rp, parity, traceBlocks, count, stream);
+                if (ev) HIP_TRY(hipEventRecord(ev[3], stream));
+            }
             launchLogic(ctx->scene, ctx->buffers, rp, parity, stream);
             if (ev) HIP_TRY(hipEventRecord(ev[4], stream));
             parity ^= 1;
@@ -572,6 +578,7 @@ int slrhip_render(slrhip_ctx* ctx, uint32_t sppBegin, uint32_t sppCount, void* s
             for (int k = 0; k < kCheckEvery; ++k) {
                 hipEvent_t* ev = &ctx->events[(size_t)k * kEv];
                 for (int j = 0; j < 4; ++j) {
+                    if (useWs && cls[j] == SLRHIP_KERNEL_TRACE_SHADOW) continue;
                     float ms = 0.0f;
                     HIP_TRY(hipEventElapsedTime(&ms, ev[j], ev[j + 1]));
                     ctx->profMs[cls[j]] += ms;

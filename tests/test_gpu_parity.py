@@ -111,6 +111,24 @@ def test_shards_sum_to_full_image(ctx, oracle_rgb):
     assert s["exact_fraction"] >= 0.999, s
 
 
+def test_trace_schedules_agree_bit_for_bit(oracle_rgb):
+    """The wave-specialised traversal (producer wave, LDS ray ring, refilled consumer lanes) and the 64-ray-batch kernels
+    must give the same frame and the same ray counts, run after run: enough rays (4.7 M slots, ring wrapping thousands of
+    times per workgroup) that a hand-off race in the ring shows up as a differing hash."""
+    sc = scenes.cornell_box_spheres(1.0, 48, 24, "glass")
+    st = ob.settings(768, 768, seed=5)
+    frames, counts = [], []
+    for flags in (abi.FLAG_TRACE_BATCH, 0, 0):
+        c = Context(stripes=8, flags=flags)
+        frames.append(c.render_image(sc, st, 32))
+        k = c.counters()
+        counts.append((int(k.extension_rays), int(k.shadow_rays), int(k.samples)))
+        c.close()
+    assert counts[0] == counts[1] == counts[2], counts
+    assert_bit_equal(frames[1], frames[0], "wave-specialised vs batch")
+    assert_bit_equal(frames[2], frames[1], "wave-specialised, second run")
+
+
 def test_errors_are_loud(ctx):
     import ctypes as C
     from slr_amd.binding import SlrHipError

@@ -13,7 +13,7 @@ import json
 import os
 import sys
 
-CLASSES = {"k_trace_closest": "trace_closest", "k_trace_shadow": "trace_shadow", "k_logic": "shade", "k_regen": "regen"}
+CLASSES = {"k_trace_closest": "trace_closest", "k_trace_shadow": "trace_shadow", "k_trace_ws": "trace", "k_logic": "shade", "k_regen": "regen"}
 
 
 def collect(d, counter):
@@ -24,7 +24,7 @@ def collect(d, counter):
                 if row["Counter_Name"] != counter:
                     continue
                 name = row["Kernel_Name"]
-                if "k_trace" in name and "<true>" in name:
+                if "k_trace" in name and ("<true>" in name or "<true," in name):
                     continue          # the traversal-counting variant runs only in bench.py's untimed statistics pass
                 cls = next((v for k, v in CLASSES.items() if k in name), None)
                 if cls is None:
