@@ -36,6 +36,11 @@ static const uint32_t kSpinLimit = 1u << 22;
 #define SLR_WS_CHAIN 1
 #endif
 static const bool kChain = SLR_WS_CHAIN != 0;
+#ifdef SLR_WS_NOSPILL
+static const bool kNoSpill = true;
+#else
+static const bool kNoSpill = false;
+#endif
 static const uint32_t kIdle = 0xFFFFFFFFu;
 
 int traceWsBlocksPerCU() {
@@ -47,6 +52,7 @@ int traceWsBlocksPerCU() {
         return true;
     }();
     (void)init;
+    if (const char* e = getenv("SLRHIP_WS_BLOCKS_PER_CU")) { const int b = atoi(e); if (b >= 1 && b <= 8) return b; }   // experiments
     return g_consumers == 7 ? 4 : 8;       // 18.5 KiB / 39.5 KiB of LDS per workgroup, 32 waves per CU either way (<= 64 VGPR)
 }
 
@@ -144,7 +150,11 @@ __device__ __forceinline__ void wsConsume(const DevScene& sc, const PathBuffers&
     int sp = 0;
     uint32_t hitTri = 0xFFFFFFFFu;
     float hitT = INFINITY, hitB0 = 0.0f, hitB1 = 0.0f;
+#ifdef SLR_WS_NOSPILL
+    uint32_t* spill = nullptr;      // timing experiment only: no scratch, pushes beyond the LDS part are dropped
+#else
     uint32_t spill[kWsSpill];
+#endif
     uint32_t idleSpins = 0;
 
     for (;;) {
@@ -254,9 +264,8 @@ __device__ __forceinline__ void wsConsume(const DevScene& sc, const PathBuffers&
                 else {
 #define WS_PUSH(cond, ref)                                                              \
                     if (cond) {                                                         \
-                        if (sp < kWsLdsStack) stack[sp * 64] = (ref);                   \
-                        else if (sp < kWsLdsStack + kWsSpill) spill[sp - kWsLdsStack] = (ref); \
-                        ++sp;                                                           \
+                        if (sp < kWsLdsStack) { stack[sp * 64] = (ref); ++sp; }         \
+                        else if (!kNoSpill && sp < kWsLdsStack + kWsSpill) { spill[sp - kWsLdsStack] = (ref); ++sp; } \
                     }
                     WS_PUSH(v0, c0)
                     WS_PUSH(v1, c1)
@@ -268,7 +277,7 @@ __device__ __forceinline__ void wsConsume(const DevScene& sc, const PathBuffers&
                 else if (sp == 0) finished = true;
                 else {
                     --sp;
-                    if (sp < kWsLdsStack) cur = stack[sp * 64];
+                    if (kNoSpill || sp < kWsLdsStack) cur = stack[sp * 64];
                     else cur = spill[sp - kWsLdsStack];
                 }
             }
@@ -316,7 +325,7 @@ __device__ __forceinline__ void wsConsume(const DevScene& sc, const PathBuffers&
                     else if (sp == 0) finished = true;
                     else {
                         --sp;
-                        if (sp < kWsLdsStack) cur = stack[sp * 64];
+                        if (kNoSpill || sp < kWsLdsStack) cur = stack[sp * 64];
                         else cur = spill[sp - kWsLdsStack];
                     }
                 }
