@@ -58,7 +58,8 @@ enum { T_EXT_RAYS = 0, T_SHADOW_RAYS = 1, T_NODES_CLOSEST = 2, T_TRIS_CLOSEST = 
        T_SLOT_VISITS = 6,
        // schedule diagnostics of the wave-specialised closest-hit kernel (counting builds only; SLRHIP_DEBUG_WS prints them)
        T_WS_STEPS = 7, T_WS_IDLE_SPINS = 8, T_WS_CYCLES = 9, T_WS_IDLE_CYCLES = 10, T_WS_REFILLS = 11, T_WS_PRODUCER_WAITS = 12,
-       T_KINDS = 13 };
+       T_WS_NODE_BLOCKS = 13, T_WS_TRI_BLOCKS = 14, T_WS_ACTIVE_LANES = 15,
+       T_KINDS = 16 };
 static const uint32_t kTotalStride = 16;                   // 64-bit words: one 128-byte line
 __host__ __device__ inline uint32_t totalIndex(uint32_t kind, uint32_t shard) { return (kind * kShards + shard) * kTotalStride; }
 

@@ -124,7 +124,7 @@ __device__ __forceinline__ bool wsWaitSpace(WsLds<NC>& lds, uint32_t tailLocal, 
 
 // The consumer side: shared by the closest-hit and the any-hit kernels.
 struct WsDebug {
-    uint32_t steps = 0, idleSpins = 0, refills = 0, producerWaits = 0;
+    uint32_t steps = 0, idleSpins = 0, refills = 0, producerWaits = 0, nodeBlocks = 0, triBlocks = 0, activeLanes = 0;
     uint64_t cycles = 0, idleCycles = 0;
 };
 
@@ -216,7 +216,12 @@ __device__ __forceinline__ void wsConsume(const DevScene& sc, const PathBuffers&
             }
         }
 
-        if (COUNT) ++dbg.steps;
+        if (COUNT) {
+            ++dbg.steps;
+            const uint64_t act = __ballot(slot != kIdle);
+            dbg.activeLanes += (uint32_t)__popcll(act);
+            if (__ballot(slot != kIdle && !(cur & kLeafFlag))) ++dbg.nodeBlocks;
+        }
         if (slot != kIdle) {
             bool finished = false;
             const bool leafAtTop = (cur & kLeafFlag) != 0;
@@ -226,9 +231,20 @@ __device__ __forceinline__ void wsConsume(const DevScene& sc, const PathBuffers&
                 const int nx = idx > 0.0f ? 0 : 3, fx = 3 - nx;
                 const int ny = idy > 0.0f ? 1 : 4, fy = 5 - ny;
                 const int nz = idz > 0.0f ? 2 : 5, fz = 7 - nz;
-                const float4* n = nodes4 + (size_t)cur * 8;
-                const float4 nX = n[nx], nY = n[ny], nZ = n[nz], fX = n[fx], fY = n[fy], fZ = n[fz], ch = n[6];
-                // slab test of QBVH::Node::intersect (QBVH.h:55-76): tNear <= tFar
+                // 32-bit byte offsets from the (uniform) array base: SGPR-base + VGPR-offset addressing, one VALU op per load
+                // instead of a 64-bit address computation (node array < 4 GiB: checked at upload)
+                const char* nb = reinterpret_cast<const char*>(nodes4);
+                const uint32_t nOff = cur * 128u;
+                const float4 nX = *reinterpret_cast<const float4*>(nb + (nOff + (uint32_t)nx * 16u));
+                const float4 nY = *reinterpret_cast<const float4*>(nb + (nOff + (uint32_t)ny * 16u));
+                const float4 nZ = *reinterpret_cast<const float4*>(nb + (nOff + (uint32_t)nz * 16u));
+                const float4 fX = *reinterpret_cast<const float4*>(nb + (nOff + (uint32_t)fx * 16u));
+                const float4 fY = *reinterpret_cast<const float4*>(nb + (nOff + (uint32_t)fy * 16u));
+                const float4 fZ = *reinterpret_cast<const float4*>(nb + (nOff + (uint32_t)fz * 16u));
+                const float4 ch = *reinterpret_cast<const float4*>(nb + (nOff + 96u));
+                // slab test of QBVH::Node::intersect (QBVH.h:55-76): tNear <= tFar.  (Tried: fma(plane, id, -(o * id)) on
+                // padded boxes, half the arithmetic — but for rays that start ON a surface the cancellation noise near t = 0
+                // admits the boxes around the origin: 3x the triangle tests for shadow rays, 4x slower on the 10 M grid.)
                 const float tn0 = fmaxf(fmaxf((nX.x - ox) * idx, (nY.x - oy) * idy), fmaxf((nZ.x - oz) * idz, tmin));
                 const float tn1 = fmaxf(fmaxf((nX.y - ox) * idx, (nY.y - oy) * idy), fmaxf((nZ.y - oz) * idz, tmin));
                 const float tn2 = fmaxf(fmaxf((nX.z - ox) * idx, (nY.z - oy) * idy), fmaxf((nZ.z - oz) * idz, tmin));
@@ -282,12 +298,17 @@ __device__ __forceinline__ void wsConsume(const DevScene& sc, const PathBuffers&
                 }
             }
             // kChain: a lane whose node step ended on a leaf tests that leaf's first triangle in the same iteration
+            if (COUNT && __ballot(!finished && (kChain ? (cur & kLeafFlag) != 0 : leafAtTop)) && (threadIdx.x & 63u) == (uint32_t)__ffsll((long long)__ballot(true)) - 1u)
+                ++dbg.triBlocks;      // counted by the first active lane; summed over lanes at the end
             if (!finished && (kChain ? (cur & kLeafFlag) != 0 : leafAtTop)) {
                 // ONE triangle of the leaf packet per step; the reference tests them in order (QBVH.h:322-327)
                 const uint32_t first = cur & kLeafIndexMask;
                 const uint32_t count = (cur >> kLeafCountShift) & 0xF;
-                const float4* tp = tris4 + (size_t)first * 3;
-                const float4 a = tp[0], b = tp[1], c = tp[2];
+                const char* tb = reinterpret_cast<const char*>(tris4);
+                const uint32_t tOff = first * 48u;
+                const float4 a = *reinterpret_cast<const float4*>(tb + tOff);
+                const float4 b = *reinterpret_cast<const float4*>(tb + (tOff + 16u));
+                const float4 c = *reinterpret_cast<const float4*>(tb + (tOff + 32u));
                 const V3 v0(a.x, a.y, a.z), e1(b.x, b.y, b.z), e2(c.x, c.y, c.z);
                 const uint32_t triIdx = __float_as_uint(a.w);
                 const V3 org(ox, oy, oz), dir(dx, dy, dz);
@@ -432,6 +453,9 @@ __global__ __launch_bounds__(64 * (NC + 1)) __attribute__((amdgpu_waves_per_eu(8
         wsBlockAdd(pb.totals, T_WS_IDLE_CYCLES, l0 ? (uint32_t)(dbg.idleCycles >> 6) : 0u, lds.red);
         wsBlockAdd(pb.totals, T_WS_REFILLS, l0 ? dbg.refills : 0u, lds.red);
         wsBlockAdd(pb.totals, T_WS_PRODUCER_WAITS, l0 ? dbg.producerWaits : 0u, lds.red);
+        wsBlockAdd(pb.totals, T_WS_NODE_BLOCKS, l0 ? dbg.nodeBlocks : 0u, lds.red);
+        wsBlockAdd(pb.totals, T_WS_TRI_BLOCKS, dbg.triBlocks, lds.red);
+        wsBlockAdd(pb.totals, T_WS_ACTIVE_LANES, l0 ? dbg.activeLanes : 0u, lds.red);
     }
 }
 

@@ -143,10 +143,12 @@ static int readTotals(slrhip_ctx* ctx, uint64_t* out) {
     }
     if (getenv("SLRHIP_DEBUG_WS") && out[T_WS_STEPS])
         fprintf(stderr, "ws closest: rays %llu nodes %llu tris %llu | consumer wave-steps %llu refills %llu idle spins %llu | "
-                        "consumer wave cycles %llu x64, idle %llu x64 | producer waits %llu\n",
+                        "consumer wave cycles %llu x64, idle %llu x64 | producer waits %llu | node blocks %llu tri blocks %llu active lanes %llu | shadow rays %llu nodes %llu tris %llu\n",
                 (unsigned long long)out[T_EXT_RAYS], (unsigned long long)out[T_NODES_CLOSEST], (unsigned long long)out[T_TRIS_CLOSEST],
                 (unsigned long long)out[T_WS_STEPS], (unsigned long long)out[T_WS_REFILLS], (unsigned long long)out[T_WS_IDLE_SPINS],
-                (unsigned long long)out[T_WS_CYCLES], (unsigned long long)out[T_WS_IDLE_CYCLES], (unsigned long long)out[T_WS_PRODUCER_WAITS]);
+                (unsigned long long)out[T_WS_CYCLES], (unsigned long long)out[T_WS_IDLE_CYCLES], (unsigned long long)out[T_WS_PRODUCER_WAITS],
+                (unsigned long long)out[T_WS_NODE_BLOCKS], (unsigned long long)out[T_WS_TRI_BLOCKS], (unsigned long long)out[T_WS_ACTIVE_LANES],
+                (unsigned long long)out[T_SHADOW_RAYS], (unsigned long long)out[T_NODES_SHADOW], (unsigned long long)out[T_TRIS_SHADOW]);
     return SLRHIP_OK;
 }
 
@@ -280,6 +282,8 @@ int slrhip_upload_scene(slrhip_ctx* ctx, const slrhip_scene_desc* d) {
         return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: BVH build failed");
     if (3 * bvh.depth + 1 > 64)
         return fail(SLRHIP_ERR_UNSUPPORTED, "slrhip_upload_scene: tree deeper than the 64-entry traversal stack (QBVH.h:299)");
+    if ((uint64_t)bvh.nodes.size() * sizeof(QNode) >= (1ull << 32) || (uint64_t)bvh.leafTris.size() * sizeof(LeafTri) >= (1ull << 32))
+        return fail(SLRHIP_ERR_UNSUPPORTED, "slrhip_upload_scene: node or leaf array beyond the 4 GiB the traversal kernels address with 32-bit offsets");
 
     // --- per-triangle shading records and the light list (SurfaceObject.cpp:232-249) ---------------------
     std::vector<ShadeTri> shade(d->num_triangles);
