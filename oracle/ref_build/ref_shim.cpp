@@ -485,6 +485,23 @@ long slr_ref_dump_table(int what, const char* name, void* dst, long capacity) {
         }
         return n;
     }
+    if (what == 5) {
+        // DiscretizedSpectrum's colour-matching tables after DiscretizedSpectrum::init() (SpectrumTypes.h:745-797):
+        // xbar[16], ybar[16], zbar[16], integralCMF.  Only the spectral build has them.
+#ifdef Use_Spectral_Representation
+        static bool inited = false;
+        if (!inited) { initSpectrum(); inited = true; }
+        const long n = 3 * 16 + 1;
+        if (dst && capacity >= n) {
+            float* f = (float*)dst;
+            for (int i = 0; i < 16; ++i) { f[i] = DiscretizedSpectrum::xbar[i]; f[16 + i] = DiscretizedSpectrum::ybar[i]; f[32 + i] = DiscretizedSpectrum::zbar[i]; }
+            f[48] = DiscretizedSpectrum::integralCMF;
+        }
+        return n;
+#else
+        return -1;
+#endif
+    }
     if (what == 3) {
         const long n = StandardIlluminant::NumSamples;
         if (dst && capacity >= n) std::memcpy(dst, StandardIlluminant::D65, n * sizeof(float));

@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "../../include/slrhip.h"
+#include "cmf16_table.h"
 
 namespace {
 
@@ -36,14 +37,32 @@ int32_t slrhip_sample_seed(int32_t rngSeed, uint32_t px, uint32_t py, uint32_t p
 int slrhip_tonemap_bgr8(const float* fb, int32_t width, int32_t height, int32_t components, float scale, uint8_t* dst,
                         size_t dstBytes) {
     if (!fb || !dst || width <= 0 || height <= 0) return SLRHIP_ERR_INVALID_ARGUMENT;
-    if (components != 3) return SLRHIP_ERR_UNSUPPORTED;
+    if (components != 3 && components != 16) return SLRHIP_ERR_UNSUPPORTED;
     const uint32_t byteWidth = 3u * (uint32_t)width + (uint32_t)width % 4u;      // ImageSensor.cpp:149 (sic)
     if (dstBytes < (size_t)byteWidth * (size_t)height) return SLRHIP_ERR_INVALID_ARGUMENT;
     std::memset(dst, 0, (size_t)byteWidth * (size_t)height);
     for (int32_t i = 0; i < height; ++i) {
         for (int32_t j = 0; j < width; ++j) {
-            const float* p = fb + ((size_t)i * width + j) * 3;
-            float RGB[3] = {p[0] * scale, p[1] * scale, p[2] * scale};       // pixel(j, i) * scale
+            const float* p = fb + ((size_t)i * width + j) * components;
+            float RGB[3];
+            if (components == 3) {
+                RGB[0] = p[0] * scale; RGB[1] = p[1] * scale; RGB[2] = p[2] * scale;       // pixel(j, i) * scale
+            }
+            else {
+                // DiscretizedSpectrum::getRGB, BasicTypes/SpectrumTypes.h:702-721: 16 storage bins -> XYZ -> sRGB
+                float XYZ[3] = {0, 0, 0};
+                for (int b = 0; b < 16; ++b) {
+                    const float v = p[b] * scale;                                          // pixel(j, i) * scale
+                    XYZ[0] += kCmfX16[b] * v;
+                    XYZ[1] += kCmfY16[b] * v;
+                    XYZ[2] += kCmfZ16[b] * v;
+                }
+                XYZ[0] /= kIntegralCmf16; XYZ[1] /= kIntegralCmf16; XYZ[2] /= kIntegralCmf16;
+                // XYZ_to_sRGB, BasicTypes/Spectrum.h:60-64 (double literals, float operands and results)
+                RGB[0] = (float)(3.2404542 * XYZ[0] - 1.5371385 * XYZ[1] - 0.4985314 * XYZ[2]);
+                RGB[1] = (float)(-0.9692660 * XYZ[0] + 1.8760108 * XYZ[1] + 0.0415560 * XYZ[2]);
+                RGB[2] = (float)(0.0556434 * XYZ[0] - 0.2040259 * XYZ[1] + 1.0572252 * XYZ[2]);
+            }
             for (int k = 0; k < 3; ++k) RGB[k] = RGB[k] < 0.0f ? 0.0f : RGB[k];
             float Y = (float)(0.222485 * RGB[0] + 0.716905 * RGB[1] + 0.060610 * RGB[2]);
             float scaleY = Y != 0 ? (1.0f - std::exp(-Y)) / Y : 0.0f;

@@ -102,6 +102,20 @@ def main():
     make("rgb_ggx_metal", scenes.cornell_lobes("ggx_metal"), lib, 40, 40, 8, 2)
     make("rgb_ggx_glass", scenes.cornell_lobes("ggx_glass"), lib, 40, 40, 8, 2)
     spec = ob.load("ref_spectral")
+    if spec is not None:
+        # the spectral build's saveImage (16 storage bins -> getRGB -> tone map -> BMP) on a known framebuffer
+        rng = np.random.default_rng(11)
+        w, h = 29, 17
+        fb16 = (rng.random((h, w, 16)) ** 3 * 0.02).astype(np.float32)
+        fb16[0, 0] = 0.0
+        fb16[1, 1, :] = 0.0; fb16[1, 1, 2] = 0.5          # a saturated blue bin: negative sRGB components are clamped
+        fb16[2, 2] = 5.0
+        with tempfile.TemporaryDirectory() as d:
+            path = os.path.join(d, "t.bmp")
+            ob.ref_save_image(spec, fb16, 509.29581, 0.41, path)
+            bmp16 = np.frombuffer(open(path, "rb").read(), dtype=np.uint8)
+        np.savez_compressed(os.path.join(HERE, "tonemap_bmp_spectral.npz"), framebuffer=fb16, sensitivity=np.float32(509.29581),
+                            scale=np.float32(0.41), bmp=bmp16)
     make("spectral_cornell_glass", scenes.cornell_box_spheres(1.0, 12, 6, "glass"), spec, 32, 32, 8, 2)
     make("spectral_cornell_matte", scenes.cornell_box_spheres(1.0, 12, 6, "matte"), spec, 32, 32, 8, 2)
     make("spectral_oren_nayar", scenes.cornell_lobes("oren_nayar", segments=10, rings=5), spec, 32, 32, 8, 2)

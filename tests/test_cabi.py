@@ -61,16 +61,18 @@ def test_sample_seed_matches_python_restatement(lib):
         assert lib.slrhip_sample_seed(seed, x, y, s) == abi.sample_seed(seed, x, y, s)
 
 
-def test_tonemap_and_bmp_match_reference_saveimage(lib):
+@pytest.mark.parametrize("name", ["tonemap_bmp", "tonemap_bmp_spectral"])
+def test_tonemap_and_bmp_match_reference_saveimage(lib, name):
     """slrhip_tonemap_bgr8 + slrhip_save_bmp == ImageSensor::saveImage + saveBMP, byte for byte
-    (golden BMP written by the compiled reference; pad bytes excluded: the reference leaves them uninitialised)."""
-    g = load_golden("tonemap_bmp")
+    (golden BMP written by the compiled reference — RGB build, and spectral build: 16 storage bins through
+    DiscretizedSpectrum::getRGB; pad bytes excluded: the reference leaves them uninitialised)."""
+    g = load_golden(name)
     fb = np.ascontiguousarray(g["framebuffer"])
-    h, w, _ = fb.shape
+    h, w, comps = fb.shape
     byte_width = 3 * w + w % 4
     out = np.zeros(byte_width * h, np.uint8)
     scale = float(g["scale"]) * float(g["sensitivity"])          # saveImage: scale *= sensitivity (ImageSensor.cpp:147)
-    rc = lib.slrhip_tonemap_bgr8(fb.ctypes.data, w, h, 3, C.c_float(scale), out.ctypes.data, out.size)
+    rc = lib.slrhip_tonemap_bgr8(fb.ctypes.data, w, h, comps, C.c_float(scale), out.ctypes.data, out.size)
     assert rc == 0
     with tempfile.TemporaryDirectory() as d:
         path = os.path.join(d, "o.bmp")
