@@ -241,6 +241,8 @@ typedef struct slrhip_profile {
 /* config.flags */
 #define SLRHIP_FLAG_TIME_KERNELS   1u   /* bracket every launch with HIP events (a few us per launch)        */
 #define SLRHIP_FLAG_COUNT_TRAVERSAL 2u  /* count nodes / triangles per ray (instrumented kernels, slower)    */
+#define SLRHIP_FLAG_SPECTRAL_QUAD  8u   /* spectral shade kernel with the 16 samples spread over four lanes per path (a quarter of
+                                         * the registers, the scalar path work replicated); identical results, kept for A/B timing */
 #define SLRHIP_FLAG_TRACE_BATCH    4u   /* trace with the 64-ray-batch kernels (two launches per iteration) instead of
                                          * the wave-specialised one; identical results, kept for A/B checks and timing   */
 

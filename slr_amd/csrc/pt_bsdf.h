@@ -45,14 +45,18 @@ SLR_DEV DevSpectrum loadSpectrumRecord(const DevSpectrum* spectra, int32_t idx) 
     return sp;
 }
 
-SLR_DEV Spec16 evalSpectrum(const DevSpectrum* spectra, const float* __restrict__ pool, int32_t idx, float wlOffset) {
+template <class S>
+SLR_DEV S evalSpectrum(const DevSpectrum* spectra, const float* __restrict__ pool, int32_t idx, float wlOffset) {
+#ifdef SLR_EXP_CONST_SPECTRA
+    return S(0.5f + 0.001f * (float)idx);     // timing experiment only: what the table look-ups cost
+#endif
     const DevSpectrum sp = loadSpectrumRecord(spectra, idx);
     const float* data = pool + sp.dataOffset;
     switch (sp.kind) {
     case SLRHIP_SPECTRUM_REGULAR: {
         // RegularContinuousSpectrumTemplate::evaluate, SpectrumTypes.h:90-109
         const uint32_t numSamples = sp.numSamples;
-        return Spec16::make([&](int i) {
+        return S::make([&](int i) {
             float binF = (wavelengthOf(i, wlOffset) - sp.lambdaMin) / (sp.lambdaMax - sp.lambdaMin) * (float)(numSamples - 1);
             if (binF <= 0.0f) return data[0];
             if (binF >= (float)(numSamples - 1)) return data[numSamples - 1];
@@ -67,10 +71,21 @@ SLR_DEV Spec16 evalSpectrum(const DevSpectrum* spectra, const float* __restrict_
         const int32_t n = (int32_t)sp.numSamples;
         const float* lambdas = data;
         const float* values = data + n;
-        return Spec16::make([&](int i) {
+        // lower_bound = first index with lambdas[idx] >= wl.  It never decreases from one component to the next (wl ascends),
+        // so only the first component of a lane does the binary search; the others walk on from the previous position
+        // (29 nm per component against the tables' 5-25 nm steps: a few probes).
+        int32_t lo = 0;
+        bool first = true;
+        return S::make([&](int i) {
             const float wl = wavelengthOf(i, wlOffset);
-            int32_t lo = 0, hi = n;                       // first index with lambdas[idx] >= wl
-            while (lo < hi) { int32_t mid = (lo + hi) >> 1; if (lambdas[mid] < wl) lo = mid + 1; else hi = mid; }
+            if (first) {
+                int32_t hi = n;
+                while (lo < hi) { int32_t mid = (lo + hi) >> 1; if (lambdas[mid] < wl) lo = mid + 1; else hi = mid; }
+                first = false;
+            }
+            else {
+                while (lo < n && lambdas[lo] < wl) ++lo;
+            }
             int32_t lowIdx = max(lo - 1, 0);
             if (lowIdx >= n - 1) return values[n - 1];
             float t = (wl - lambdas[lowIdx]) / (lambdas[lowIdx + 1] - lambdas[lowIdx]);
@@ -82,11 +97,11 @@ SLR_DEV Spec16 evalSpectrum(const DevSpectrum* spectra, const float* __restrict_
         // UpsampledContinuousSpectrumTemplate::evaluate, SpectrumTypes.h:314-338: the wavelength loop; the cell lookup and
         // the weights (:241-312) are constants of the spectrum, resolved on the host (slr_amd/spectra.py).
         const uint32_t numPoints = sp.numPoints;
-        if (numPoints == 0) return Spec16();
+        if (numPoints == 0) return S();
         const uint32_t nw = sp.numSamples;                // 95
         const float w0 = data[0], w1 = data[1], w2 = data[2], w3 = data[3];
         const float4* rec = reinterpret_cast<const float4*>(data + 4);     // [bin][point], 16-byte aligned (checked at upload)
-        Spec16 ret = Spec16::make([&](int i) {
+        S ret = S::make([&](int i) {
             float p = (wavelengthOf(i, wlOffset) - 360.0f) / (830.0f - 360.0f);
             float sBinF = p * (float)(nw - 1);
             uint32_t sBin = (uint32_t)sBinF;
@@ -103,23 +118,24 @@ SLR_DEV Spec16 evalSpectrum(const DevSpectrum* spectra, const float* __restrict_
         return ret * sp.scale;
     }
     default:
-        return Spec16();
+        return S();
     }
 }
 
 // SurfaceMaterial::getBSDF in spectral mode (basic_SurfaceMaterials.cpp:15-43, MicrofacetSurfaceMaterial.cpp:14-28):
 // evaluate the constant spectra the lobe needs at this path's wavelengths.
-SLR_DEV Mat<Spec16> loadMatSpectral(const DevMaterialS* mats, uint32_t idx, const DevSpectrum* spectra, const float* pool, float wlOffset) {
+template <class S>
+SLR_DEV Mat<S> loadMatSpectral(const DevMaterialS* mats, uint32_t idx, const DevSpectrum* spectra, const float* pool, float wlOffset) {
     const uint4* mq = reinterpret_cast<const uint4*>(mats + idx);
     const uint4 m0 = mq[0], m1 = mq[1];
     DevMaterialS m;
     m.type = m0.x; m.param = __uint_as_float(m0.y); m.onA = __uint_as_float(m0.z); m.onB = __uint_as_float(m0.w);
     m.spec[0] = (int32_t)m1.x; m.spec[1] = (int32_t)m1.y; m.spec[2] = (int32_t)m1.z; m.spec[3] = (int32_t)m1.w;
-    Mat<Spec16> r;
+    Mat<S> r;
     r.type = m.type; r.param = m.param; r.onA = m.onA; r.onB = m.onB;
-    if (m.spec[0] >= 0) r.a = 1.0f * evalSpectrum(spectra, pool, m.spec[0], wlOffset);     // scale * spectrum, scale = 1
-    if (m.spec[1] >= 0) r.b = evalSpectrum(spectra, pool, m.spec[1], wlOffset);
-    if (m.spec[2] >= 0) r.c = evalSpectrum(spectra, pool, m.spec[2], wlOffset);
+    if (m.spec[0] >= 0) r.a = 1.0f * evalSpectrum<S>(spectra, pool, m.spec[0], wlOffset);     // scale * spectrum, scale = 1
+    if (m.spec[1] >= 0) r.b = evalSpectrum<S>(spectra, pool, m.spec[1], wlOffset);
+    if (m.spec[2] >= 0) r.c = evalSpectrum<S>(spectra, pool, m.spec[2], wlOffset);
     return r;
 }
 
@@ -214,15 +230,16 @@ template <class S>
 SLR_DEV float fresnelDielectricWl(const S& etaExt, const S& etaInt, float cosEnter, uint32_t wl) {
     cosEnter = fminf(1.0f, fmaxf(-1.0f, cosEnter));
     bool entering = cosEnter > 0.0f;
-    const float eEnter = entering ? etaExt.comp(wl) : etaInt.comp(wl);
-    const float eExit = entering ? etaInt.comp(wl) : etaExt.comp(wl);
+    // wl is the index a make() callback was given (this lane's own component when the spectrum is spread over a quad)
+    const float eEnter = entering ? etaExt.own((int)wl) : etaInt.own((int)wl);
+    const float eExit = entering ? etaInt.own((int)wl) : etaExt.own((int)wl);
     return fresnelDielectric1(eEnter, eExit, sqrtf(fmaxf(0.0f, 1.0f - cosEnter * cosEnter)), fabsf(cosEnter));
 }
 
 // One wavelength of the Walter-07 transmission term (MicrofacetBSDF.cpp:170-181, :225-236)
 template <class S>
 SLR_DEV float mfTransmissionWl(const GGX& D_, const Mat<S>& m, const S& eEnter, const S& eExit, V3 dirOut, V3 dir, uint32_t wl) {
-    const float ee = eEnter.comp(wl), ex = eExit.comp(wl);
+    const float ee = eEnter.own((int)wl), ex = eExit.own((int)wl);
     V3 m_wl = normalize(-(ee * dirOut + ex * dir));
     float dotHV_wl = dot(dirOut, m_wl);
     float dotHL_wl = dot(dir, m_wl);

@@ -25,6 +25,7 @@ struct DevScene {
     uint32_t lightPow2;           // prevPowerOf2(numLights)
     uint32_t hasMicrofacet;       // any SLRHIP_MATERIAL_MICROFACET_* in the scene
     uint32_t numSpectra;
+    uint32_t numSpectrumData;     // floats in spectrumPool (padded to a multiple of 4 on upload)
     // environment sphere (InfiniteSphereSurfaceObject, SurfaceObject.cpp:137-222); RGB mode
     uint32_t hasEnv;
     uint32_t envWidth, envHeight, envMapWidth, envMapHeight;
@@ -100,6 +101,7 @@ struct RenderParams {
     uint32_t countSlots;          // SLRHIP_FLAG_COUNT_TRAVERSAL: also count live slots per logic launch
     uint32_t shardCapacity;       // entries per queue region = ceil(numBlocks / kShards) * 256
     uint32_t spectral;            // 0 = RGB (3 components), 1 = 16 wavelength samples
+    uint32_t spectralQuad;        // spectral shade kernel with four lanes per slot (SLRHIP_FLAG_SPECTRAL_QUAD)
 };
 
 void launchResetSlots(const PathBuffers& pb, const RenderParams& rp, bool clearAccumulators, hipStream_t stream);

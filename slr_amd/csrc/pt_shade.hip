@@ -19,6 +19,9 @@
 // loads of k_logic are issued together at the top (the kernel is latency-bound: PMC shows > 80 % of
 // wave cycles waiting on memory), and the material / light tables live in LDS.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
+
+#include <string>
 
 #include "pt_bsdf.h"
 #include "pt_kernels.h"
@@ -48,6 +51,7 @@ static const int kShadeBlock = 256;
 static const int kLdsMaterials = 32;
 static const int kLdsLights = 16;
 static const int kLdsSpectra = 96;
+static const int kLdsPoolFloats = 6144;     // 24 KiB: the spectrum sample tables of a scene (spectral mode), staged per workgroup
 
 // Spectrum-valued path state in HBM.  RGB: one float4 per slot, the scalar that travels with it in .w.
 // Spectral: four float4 planes per array (plane p of slot i at [p * numSlots + i], so every plane is a coalesced
@@ -78,6 +82,19 @@ template <> struct SpecIO<Spec16> {
     }
 };
 
+template <> struct SpecIO<SpecQ> {
+    // lane q of the quad moves plane q (components 4q .. 4q+3); the scalar is read by all four lanes and written by lane 0
+    static __device__ __forceinline__ void load(const float4* a, const float* scalars, uint32_t slot, uint32_t n, SpecQ& v, float& w) {
+        const float4 t = a[(size_t)SpecQ::q() * n + slot];
+        v.c[0] = t.x; v.c[1] = t.y; v.c[2] = t.z; v.c[3] = t.w;
+        w = scalars ? scalars[slot] : 0.0f;
+    }
+    static __device__ __forceinline__ void store(float4* a, float* scalars, uint32_t slot, uint32_t n, const SpecQ& v, float w) {
+        a[(size_t)SpecQ::q() * n + slot] = make_float4(v.c[0], v.c[1], v.c[2], v.c[3]);
+        if (scalars && SpecQ::q() == 0) scalars[slot] = w;
+    }
+};
+
 // Material access per mode
 template <class S> struct MatIO;
 template <> struct MatIO<RGB> {
@@ -90,21 +107,27 @@ template <> struct MatIO<RGB> {
         return loadEmittance(LDS ? reinterpret_cast<const DevMaterial*>(ldsMats) + idx : sc.materials + idx);
     }
 };
-template <> struct MatIO<Spec16> {
+// spectral mode, LDS tables: [DevMaterialS x kLdsMaterials][DevSpectrum x kLdsSpectra][sample pool, kLdsPoolFloats floats]
+__device__ __forceinline__ const float* ldsPoolOf(const float4* ldsMats) {
+    return reinterpret_cast<const float*>(ldsMats + 2 * kLdsMaterials + 2 * kLdsSpectra);
+}
+template <class S> struct MatIOSpectral {
     // spectral mode: the LDS table holds the DevMaterialS records (2 x float4 each) followed by the DevSpectrum records
     template <bool LDS>
-    static __device__ __forceinline__ Mat<Spec16> load(const DevScene& sc, const float4* ldsMats, uint32_t idx, float wlOffset) {
+    static __device__ __forceinline__ Mat<S> load(const DevScene& sc, const float4* ldsMats, uint32_t idx, float wlOffset) {
         const DevMaterialS* mats = LDS ? reinterpret_cast<const DevMaterialS*>(ldsMats) : sc.materialsS;
         const DevSpectrum* spectra = LDS ? reinterpret_cast<const DevSpectrum*>(ldsMats + 2 * kLdsMaterials) : sc.spectra;
-        return loadMatSpectral(mats, idx, spectra, sc.spectrumPool, wlOffset);
+        return loadMatSpectral<S>(mats, idx, spectra, LDS ? ldsPoolOf(ldsMats) : sc.spectrumPool, wlOffset);
     }
     template <bool LDS>
-    static __device__ __forceinline__ Spec16 emittance(const DevScene& sc, const float4* ldsMats, uint32_t idx, float wlOffset) {
+    static __device__ __forceinline__ S emittance(const DevScene& sc, const float4* ldsMats, uint32_t idx, float wlOffset) {
         const DevMaterialS* mats = LDS ? reinterpret_cast<const DevMaterialS*>(ldsMats) : sc.materialsS;
         const DevSpectrum* spectra = LDS ? reinterpret_cast<const DevSpectrum*>(ldsMats + 2 * kLdsMaterials) : sc.spectra;
-        return evalSpectrum(spectra, sc.spectrumPool, mats[idx].spec[3], wlOffset);
+        return evalSpectrum<S>(spectra, LDS ? ldsPoolOf(ldsMats) : sc.spectrumPool, mats[idx].spec[3], wlOffset);
     }
 };
+template <> struct MatIO<Spec16> : MatIOSpectral<Spec16> {};
+template <> struct MatIO<SpecQ> : MatIOSpectral<SpecQ> {};
 
 // Append `slot` to the workgroup's region of up to two queues: wave ballots + popcount prefixes, the four
 // wave counts meet in LDS, ONE atomic per queue per workgroup (on the region's own counter line).
@@ -184,6 +207,7 @@ __device__ __forceinline__ RGB envEmittance(const DevScene& sc, float tcU, float
 template <class S> __device__ __forceinline__ S envEmittanceS(const DevScene& sc, float u, float v);
 template <> __device__ __forceinline__ RGB envEmittanceS<RGB>(const DevScene& sc, float u, float v) { return envEmittance(sc, u, v); }
 template <> __device__ __forceinline__ Spec16 envEmittanceS<Spec16>(const DevScene&, float, float) { return Spec16(); }   // rejected at upload
+template <> __device__ __forceinline__ SpecQ envEmittanceS<SpecQ>(const DevScene&, float, float) { return SpecQ(); }
 // InfiniteSphereSurfaceObject::evaluateAreaPDF, SurfaceObject.cpp:217-222 (RegularConstantContinuous2D::evaluatePDF :218-224)
 __device__ __forceinline__ float envAreaPDF(const DevScene& sc, float phi, float theta) {
     float d0 = (float)((double)phi / (2 * kPi)), d1 = (float)((double)theta / kPi);
@@ -239,9 +263,32 @@ template <> struct SpAcc<Spec16> {
     __device__ __forceinline__ void end(const PathBuffers&, uint32_t, uint32_t, bool) {}
 };
 
+template <> struct SpAcc<SpecQ> {
+    __device__ __forceinline__ void begin(const PathBuffers&, uint32_t, uint32_t) {}
+    __device__ __forceinline__ void add(const PathBuffers& pb, uint32_t slot, uint32_t n, const SpecQ& v) {
+        const size_t i = (size_t)SpecQ::q() * n + slot;
+        float4 r = pb.spR[i], c = pb.spC[i];
+        kahanAdd(r.x, c.x, v.c[0]); kahanAdd(r.y, c.y, v.c[1]); kahanAdd(r.z, c.z, v.c[2]); kahanAdd(r.w, c.w, v.c[3]);
+        pb.spR[i] = r;
+        pb.spC[i] = c;
+    }
+    __device__ __forceinline__ void addPendingNee(const PathBuffers& pb, uint32_t slot, uint32_t n) {
+        const size_t i = (size_t)SpecQ::q() * n + slot;
+        const float4 v = pb.nee[i];
+        float4 r = pb.spR[i], c = pb.spC[i];
+        kahanAdd(r.x, c.x, v.x); kahanAdd(r.y, c.y, v.y); kahanAdd(r.z, c.z, v.z); kahanAdd(r.w, c.w, v.w);
+        pb.spR[i] = r;
+        pb.spC[i] = c;
+    }
+    __device__ __forceinline__ void end(const PathBuffers&, uint32_t, uint32_t, bool) {}
+};
+
+template <bool SPECTRAL>
 struct ShadeLds {
-    // RGB: DevMaterial = 5 x float4 each.  Spectral: DevMaterialS (2 x float4 each), then DevSpectrum (2 x float4 each)
-    float4 mats[(kLdsMaterials * 5 > kLdsMaterials * 2 + kLdsSpectra * 2) ? kLdsMaterials * 5 : kLdsMaterials * 2 + kLdsSpectra * 2];
+    // RGB: DevMaterial = 5 x float4 each.  Spectral: DevMaterialS (2 x float4 each), DevSpectrum (2 x float4 each), then the
+    // spectrum sample pool: evaluating a spectrum is 16 x 2 scattered 16-byte reads per slot, which the vector L1 serves at
+    // one cache line per clock (measured: the look-ups were 1.0-1.6 ms of a 1.4-2.0 ms launch); LDS serves them in banks
+    float4 mats[SPECTRAL ? kLdsMaterials * 2 + kLdsSpectra * 2 + kLdsPoolFloats / 4 : kLdsMaterials * 5];
     float4 lights[kLdsLights * 9];         // LightTri   = 9 x float4
     float lightPMF[kLdsLights];
     float lightCDF[kLdsLights + 1];
@@ -249,7 +296,7 @@ struct ShadeLds {
 
 template <class S, bool LDS_TABLES, bool MF>
 __global__ __launch_bounds__(kShadeBlock) void k_logic(DevScene sc, PathBuffers pb, RenderParams rp, uint32_t parity) {
-    __shared__ ShadeLds lds;
+    __shared__ ShadeLds<S::N != 3> lds;
     __shared__ PushLds pushLds;
     if (LDS_TABLES) {
         if (S::N == 3) {
@@ -261,6 +308,8 @@ __global__ __launch_bounds__(kShadeBlock) void k_logic(DevScene sc, PathBuffers 
             const float4* gs = reinterpret_cast<const float4*>(sc.spectra);
             for (uint32_t i = threadIdx.x; i < sc.numMaterials * 2; i += kShadeBlock) lds.mats[i] = gm[i];
             for (uint32_t i = threadIdx.x; i < sc.numSpectra * 2; i += kShadeBlock) lds.mats[2 * kLdsMaterials + i] = gs[i];
+            const float4* gp = reinterpret_cast<const float4*>(sc.spectrumPool);
+            for (uint32_t i = threadIdx.x; i < (sc.numSpectrumData + 3) / 4; i += kShadeBlock) lds.mats[2 * kLdsMaterials + 2 * kLdsSpectra + i] = gp[i];
         }
         const float4* gl = reinterpret_cast<const float4*>(sc.lightTris);
         for (uint32_t i = threadIdx.x; i < sc.numLights * 9; i += kShadeBlock) lds.lights[i] = gl[i];
@@ -271,7 +320,11 @@ __global__ __launch_bounds__(kShadeBlock) void k_logic(DevScene sc, PathBuffers 
     const float* lightPMF = LDS_TABLES ? lds.lightPMF : sc.lightPMF;
     const float* lightCDF = LDS_TABLES ? lds.lightCDF : sc.lightCDF;
 
-    const uint32_t slot = blockIdx.x * kShadeBlock + threadIdx.x;
+    // S::LANES adjacent lanes share one slot (SpecQ: 4, each holding a quarter of the spectrum; the per-path scalar work is
+    // replicated, identically, in all of them); the first of them ("leader") writes the scalar state and the queue entries
+    constexpr uint32_t L = S::LANES;
+    const uint32_t slot = (blockIdx.x * kShadeBlock + threadIdx.x) / L;
+    const bool leader = L == 1 || (threadIdx.x & (L - 1)) == 0;
     bool emitExt = false, emitShadow = false, emitRegen = false;
     uint32_t* qw = pb.queueCount + (parity ^ 1) * kQueueSetWords;
 
@@ -461,7 +514,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_logic(DevScene sc, PathBuffers 
                             sdir = (lp - surf.p) / dist;
                             shadowTmax = dist * (1 - kRayEpsilon);
                         }
-                        pb.shadowDir[slot] = make_float4(sdir.x, sdir.y, sdir.z, shadowTmax);
+                        if (leader) pb.shadowDir[slot] = make_float4(sdir.x, sdir.y, sdir.z, shadowTmax);
                         emitShadow = true;
                         // contribution if visible :181-202
                         float dist2;
@@ -509,7 +562,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_logic(DevScene sc, PathBuffers 
                         emitExt = true;
                     }
                     // the shadow ray starts at the shading point, which is also the next ray's origin
-                    if (emitShadow && !emitExt) pb.rayOrg[slot] = make_float4(surf.p.x, surf.p.y, surf.p.z, kRayEpsilon);
+                    if (emitShadow && !emitExt && leader) pb.rayOrg[slot] = make_float4(surf.p.x, surf.p.y, surf.p.z, kRayEpsilon);
                 }
             }
 
@@ -524,13 +577,13 @@ __global__ __launch_bounds__(kShadeBlock) void k_logic(DevScene sc, PathBuffers 
             }
 
             // ---- store path state ---------------------------------------------------------------------------
-            pb.flags[slot] = flags;
+            if (leader) pb.flags[slot] = flags;
             sp.end(pb, slot, rp.numSlots, !emitRegen);
             if (!emitRegen) {
-                pb.rng[slot] = make_uint4(rng.s0, rng.s1, rng.s2, rng.s3);
+                if (leader) pb.rng[slot] = make_uint4(rng.s0, rng.s1, rng.s2, rng.s3);
                 SpecIO<S>::store(pb.alpha, pb.pdfPrev, slot, rp.numSlots, alpha, bsdfPDFprev);
             }
-            if (emitExt) {
+            if (emitExt && leader) {
                 pb.rayOrg[slot] = make_float4(rayOrg.x, rayOrg.y, rayOrg.z, rayTmin);
                 pb.rayDir[slot] = make_float4(rayDir.x, rayDir.y, rayDir.z, INFINITY);
             }
@@ -539,9 +592,9 @@ __global__ __launch_bounds__(kShadeBlock) void k_logic(DevScene sc, PathBuffers 
 
     // ---- stream compaction of the shadow rays and of the finished slots -----------------------------------------
     (void)emitExt;     // extension rays need no queue: the traversal kernel reads the state flag
-    blockPush(pushLds, emitShadow, emitRegen, slot, pb.shadowQueue, pb.regenQueue, qw, rp.shardCapacity);
+    blockPush(pushLds, emitShadow && leader, emitRegen && leader, slot, pb.shadowQueue, pb.regenQueue, qw, rp.shardCapacity);
     if (rp.countSlots) {
-        const uint64_t ma = __ballot(emitExt || emitShadow || emitRegen);
+        const uint64_t ma = __ballot((emitExt || emitShadow || emitRegen) && leader);
         if ((threadIdx.x & 63u) == 0 && ma)
             atomicAdd((unsigned long long*)&pb.totals[totalIndex(T_SLOT_VISITS, blockIdx.x % kShards)], (unsigned long long)__popcll(ma));
     }
@@ -723,13 +776,25 @@ void launchRegen(const DevScene& sc, const PathBuffers& pb, const RenderParams& 
 void launchLogic(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, hipStream_t stream) {
     const dim3 grid((rp.numSlots + kShadeBlock - 1) / kShadeBlock), block(kShadeBlock);
     const bool ldsTables = sc.numMaterials <= (uint32_t)kLdsMaterials && sc.numLights <= (uint32_t)kLdsLights &&
-                           (!rp.spectral || sc.numSpectra <= (uint32_t)kLdsSpectra);
+                           (!rp.spectral || (sc.numSpectra <= (uint32_t)kLdsSpectra && sc.numSpectrumData <= (uint32_t)kLdsPoolFloats));
     // The microfacet (GGX) code costs ~45 VGPRs, so scenes without such lobes get kernels without it.
     if (rp.spectral) {
-        if (ldsTables && !sc.hasMicrofacet) hipLaunchKernelGGL((k_logic<Spec16, true, false>), grid, block, 0, stream, sc, pb, rp, parity);
-        else if (ldsTables) hipLaunchKernelGGL((k_logic<Spec16, true, true>), grid, block, 0, stream, sc, pb, rp, parity);
-        else if (!sc.hasMicrofacet) hipLaunchKernelGGL((k_logic<Spec16, false, false>), grid, block, 0, stream, sc, pb, rp, parity);
-        else hipLaunchKernelGGL((k_logic<Spec16, false, true>), grid, block, 0, stream, sc, pb, rp, parity);
+        // One lane per slot (Spec16) unless the context asks for four (SpecQ: SLRHIP_FLAG_SPECTRAL_QUAD or SLRHIP_SPECTRAL_LANES=4).
+        // Measured on configs[2] after the LDS sample pool: 1 445 vs 1 487 us per launch — the quarter-size register footprint
+        // (125 vs 187 VGPR) does not pay for replicating the scalar path work four times.
+        static const bool envQuad = [] { const char* e = getenv("SLRHIP_SPECTRAL_LANES"); return e && std::string(e) == "4"; }();
+        if (!envQuad && !rp.spectralQuad) {
+            if (ldsTables && !sc.hasMicrofacet) hipLaunchKernelGGL((k_logic<Spec16, true, false>), grid, block, 0, stream, sc, pb, rp, parity);
+            else if (ldsTables) hipLaunchKernelGGL((k_logic<Spec16, true, true>), grid, block, 0, stream, sc, pb, rp, parity);
+            else if (!sc.hasMicrofacet) hipLaunchKernelGGL((k_logic<Spec16, false, false>), grid, block, 0, stream, sc, pb, rp, parity);
+            else hipLaunchKernelGGL((k_logic<Spec16, false, true>), grid, block, 0, stream, sc, pb, rp, parity);
+            return;
+        }
+        const dim3 gridQ((rp.numSlots * 4u + kShadeBlock - 1) / kShadeBlock);
+        if (ldsTables && !sc.hasMicrofacet) hipLaunchKernelGGL((k_logic<SpecQ, true, false>), gridQ, block, 0, stream, sc, pb, rp, parity);
+        else if (ldsTables) hipLaunchKernelGGL((k_logic<SpecQ, true, true>), gridQ, block, 0, stream, sc, pb, rp, parity);
+        else if (!sc.hasMicrofacet) hipLaunchKernelGGL((k_logic<SpecQ, false, false>), gridQ, block, 0, stream, sc, pb, rp, parity);
+        else hipLaunchKernelGGL((k_logic<SpecQ, false, true>), gridQ, block, 0, stream, sc, pb, rp, parity);
         return;
     }
     if (ldsTables && !sc.hasMicrofacet) hipLaunchKernelGGL((k_logic<RGB, true, false>), grid, block, 0, stream, sc, pb, rp, parity);

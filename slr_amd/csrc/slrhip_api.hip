@@ -393,6 +393,8 @@ int slrhip_upload_scene(slrhip_ctx* ctx, const slrhip_scene_desc* d) {
     {
         std::vector<float> pool;
         if (spectral && d->spectrum_data) pool.assign(d->spectrum_data, d->spectrum_data + d->num_spectrum_data);
+        while (pool.size() % 4) pool.push_back(0.0f);          // the shade kernel stages the pool into LDS 16 bytes at a time
+        ctx->scene.numSpectrumData = (uint32_t)pool.size();
         HIP_TRY(ctx->spectrumPool.upload(pool));
     }
     HIP_TRY(ctx->lightPMF.upload(pmf));
@@ -512,6 +514,7 @@ int slrhip_render_begin(slrhip_ctx* ctx, const slrhip_render_settings* st, slrhi
     rp.countSlots = (ctx->config.flags & SLRHIP_FLAG_COUNT_TRAVERSAL) ? 1u : 0u;
     rp.shardCapacity = shardCapacity;
     rp.spectral = spectral ? 1u : 0u;
+    rp.spectralQuad = (ctx->config.flags & SLRHIP_FLAG_SPECTRAL_QUAD) ? 1u : 0u;
     ctx->samplesDone = 0;
     ctx->settings = *st;
     ctx->shard = shard;

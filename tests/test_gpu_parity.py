@@ -244,6 +244,20 @@ def test_spectral_ggx_within_tolerance(sctx, name):
     assert np.isfinite(fb).all()
 
 
+@pytest.mark.parametrize("name", ["spectral_cornell_glass", "spectral_ggx_metal"])
+def test_spectral_quad_kernel_matches_the_one_lane_kernel(name):
+    """SLRHIP_FLAG_SPECTRAL_QUAD: the 16 samples of a path spread over four lanes (DPP broadcasts, in-order cross-lane running
+    sum).  Same arithmetic in the same order, so the frame must equal the one-lane kernel's bit for bit."""
+    g = load_golden(name)
+    st = ob.settings(int(g["width"]), int(g["height"]), int(g["seed"]))
+    frames = []
+    for flags in (0, abi.FLAG_SPECTRAL_QUAD):
+        c = Context(mode=abi.MODE_SPECTRAL, stripes=1, flags=flags)
+        frames.append(c.render_image(scene_from_golden(g), st, int(g["spp"])))
+        c.close()
+    assert_bit_equal(frames[1], frames[0], name + ": quad vs one lane")
+
+
 def test_spectral_mode_rejects_rgb_only_spectra(sctx):
     from slr_amd.binding import SlrHipError
     b = scenes.SceneBuilder()
