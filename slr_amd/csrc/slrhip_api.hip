@@ -532,10 +532,13 @@ int slrhip_render(slrhip_ctx* ctx, uint32_t sppBegin, uint32_t sppCount, void* s
     RenderParams& rp = ctx->params;
     rp.sppBegin = sppBegin;
     rp.sppCount = sppCount;
-    if (rp.numSlots == 0 || sppCount == 0) { ctx->firstRenderCall = false; return SLRHIP_OK; }
+    if (rp.numSlots == 0) { ctx->firstRenderCall = false; return SLRHIP_OK; }
 
+    // the first call after render_begin also clears the pixel accumulators (the buffers are reused across render_begin calls),
+    // even when it is asked for zero passes
     launchResetSlots(ctx->buffers, rp, ctx->firstRenderCall, stream);
     ctx->firstRenderCall = false;
+    if (sppCount == 0) return SLRHIP_OK;
     // persistent traversal workgroups: a fixed number per CU, each staging the top of the tree in LDS once
     // Traversal schedule: wave-specialised (pt_trace_ws.hip) unless SLRHIP_TRACE=batch asks for the 64-ray-batch kernels
     // of pt_trace.hip, and so does SLRHIP_FLAG_TRACE_BATCH per context (kept for A/B checks; results are identical)

@@ -111,6 +111,56 @@ def test_shards_sum_to_full_image(ctx, oracle_rgb):
     assert s["exact_fraction"] >= 0.999, s
 
 
+@pytest.mark.parametrize("size,spp,stripes", [((1, 1), 7, 1), ((3, 5), 5, 3), ((9, 8), 4, 64), ((37, 21), 3, 0)])
+def test_ragged_sizes_against_oracle(oracle_rgb, size, spp, stripes):
+    """Images smaller than a tile, not a multiple of 8, fewer samples than stripes, stripes that do not divide spp, and the
+    automatic stripe choice: every pixel still gets exactly its passes (stripes only reorder the per-pixel float sum)."""
+    sc = scenes.tiny_box(size[0] / size[1])
+    st = ob.settings(size[0], size[1], seed=21)
+    want, ctr = oracle_rgb.scene(sc).render(st, spp)
+    c = Context(stripes=stripes)
+    fb = c.render_image(sc, st, spp)
+    k = c.counters()
+    c.close()
+    assert k.samples == size[0] * size[1] * spp == ctr.samples
+    assert int(k.extension_rays) == int(ctr.extension_rays) and int(k.shadow_rays) == int(ctr.shadow_rays)
+    if stripes == 1:
+        assert_bit_equal(fb, want, "stripes=1")
+    else:
+        assert np.allclose(fb, want, rtol=2e-6, atol=1e-9)
+
+
+def test_empty_shards_and_empty_renders(ctx):
+    """More shards than tiles: the surplus shards own no pixel and must render (nothing) without error; zero passes is a no-op."""
+    sc = scenes.tiny_box(1.0)
+    st = ob.settings(8, 8, seed=2)
+    ctx.upload_scene(sc)
+    ctx.render_begin(st, shard=(0, 5))
+    ctx.render(0, 2)
+    full = ctx.read_framebuffer()
+    assert (full != 0).any()
+    for i in range(1, 5):
+        ctx.render_begin(st, shard=(i, 5))
+        ctx.render(0, 2)
+        assert not ctx.read_framebuffer().any()
+        assert ctx.counters().samples == 0
+    ctx.render_begin(st)
+    ctx.render(0, 0)
+    assert not ctx.read_framebuffer().any()
+
+
+def test_spectral_continued_render_matches_single_render(sctx):
+    g = load_golden("spectral_cornell_matte")
+    st = ob.settings(int(g["width"]), int(g["height"]), int(g["seed"]))
+    sctx.upload_scene(scene_from_golden(g))
+    sctx.render_begin(st)
+    half = int(g["spp"]) // 2
+    sctx.render(0, half)
+    assert_bit_equal(sctx.read_framebuffer(), g["framebuffer_half"], "first half")
+    sctx.render(half, half)
+    assert_bit_equal(sctx.read_framebuffer(), g["framebuffer"], "both halves")
+
+
 def test_trace_schedules_agree_bit_for_bit(oracle_rgb):
     """The wave-specialised traversal (producer wave, LDS ray ring, refilled consumer lanes) and the 64-ray-batch kernels
     must give the same frame and the same ray counts, run after run: enough rays (4.7 M slots, ring wrapping thousands of
