@@ -205,6 +205,63 @@ struct Builder {
 
 } // namespace
 
+namespace {
+// what the device computes for a plane: fma(q, scale, origin), correctly rounded (double holds the exact sum)
+inline float dequant(uint32_t q, float scale, float origin) { return (float)((double)q * (double)scale + (double)origin); }
+}
+
+void quantizeNodes(QBVH* out) {
+    const size_t n = out->nodes.size();
+    out->quantized.resize(n);
+    auto work = [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; ++i) {
+            const QNode& s = out->nodes[i];
+            QNodeQ d;
+            std::memset(&d, 0, sizeof(d));
+            const float* mins[3] = {s.minx, s.miny, s.minz};
+            const float* maxs[3] = {s.maxx, s.maxy, s.maxz};
+            float org[3], scl[3];
+            uint32_t qlo[3] = {0, 0, 0}, qhi[3] = {0, 0, 0};
+            for (int a = 0; a < 3; ++a) {
+                float bmin = INFINITY, bmax = -INFINITY;
+                for (int c = 0; c < 4; ++c)
+                    if (s.child[c] != kInvalidChild) { bmin = std::fmin(bmin, mins[a][c]); bmax = std::fmax(bmax, maxs[a][c]); }
+                if (!(bmin <= bmax)) { bmin = 0.0f; bmax = 0.0f; }
+                org[a] = bmin;
+                float sc = (bmax - bmin) / 255.0f;
+                // origin + 255 * scale must reach the top of the box under the device's rounding
+                while (sc > 0.0f && dequant(255, sc, bmin) < bmax) sc = std::nextafter(sc, INFINITY);
+                scl[a] = sc;
+                for (int c = 0; c < 4; ++c) {
+                    uint32_t l = 255, h = 0;                       // empty slot: inverted, never entered
+                    if (s.child[c] != kInvalidChild) {
+                        if (sc > 0.0f) {
+                            l = (uint32_t)std::fmin(255.0f, std::fmax(0.0f, std::floor((mins[a][c] - bmin) / sc)));
+                            h = (uint32_t)std::fmin(255.0f, std::fmax(0.0f, std::ceil((maxs[a][c] - bmin) / sc)));
+                            while (l > 0 && dequant(l, sc, bmin) > mins[a][c]) --l;
+                            while (h < 255 && dequant(h, sc, bmin) < maxs[a][c]) ++h;
+                        }
+                        else { l = 0; h = 0; }                    // flat box on this axis: origin is the plane, exactly
+                    }
+                    qlo[a] |= l << (8 * c);
+                    qhi[a] |= h << (8 * c);
+                }
+            }
+            d.ox = org[0]; d.oy = org[1]; d.oz = org[2];
+            d.sx = scl[0]; d.sy = scl[1]; d.sz = scl[2];
+            d.qlox = qlo[0]; d.qloy = qlo[1]; d.qloz = qlo[2];
+            d.qhix = qhi[0]; d.qhiy = qhi[1]; d.qhiz = qhi[2];
+            for (int c = 0; c < 4; ++c) d.child[c] = s.child[c];
+            out->quantized[i] = d;
+        }
+    };
+    unsigned nt = n < 65536 ? 1u : hostThreads();
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < nt; ++t) pool.emplace_back(work, n * t / nt, n * (t + 1) / nt);
+    work(0, n / nt);
+    for (std::thread& th : pool) th.join();
+}
+
 int buildQBVH(const slrhip_vertex* verts, const slrhip_triangle* tris, uint32_t numTris, QBVH* out) {
     if (!verts || !tris || numTris == 0 || numTris > kLeafIndexMask) return 1;
     std::vector<Box> primBox(numTris);

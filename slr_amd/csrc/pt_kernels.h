@@ -20,6 +20,7 @@ struct DevScene {
     const float* lightPMF;        // RegularConstantDiscrete1D of the aggregate's light list
     const float* lightCDF;        // numLights + 1 entries
     uint32_t numNodes;
+    const float4* nodesQ;         // QNodeQ array (4 x float4 per node) or nullptr: large scenes traverse this one
     uint32_t numMaterials;
     uint32_t numLights;
     uint32_t lightPow2;           // prevPowerOf2(numLights)

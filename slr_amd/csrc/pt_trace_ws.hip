@@ -134,7 +134,7 @@ struct WsCounts {
     uint32_t nodes[2] = {0, 0}, tris[2] = {0, 0};   // [0] closest, [1] shadow
 };
 
-template <bool COUNT, int NC>
+template <bool COUNT, int NC, bool QUANT>
 __device__ __forceinline__ void wsConsume(const DevScene& sc, const PathBuffers& pb, WsLds<NC>& lds, uint32_t refill, WsCounts& cnt, WsDebug& dbg) {
     const uint64_t tStart = COUNT ? __builtin_readcyclecounter() : 0;
     constexpr uint32_t kRing = WsLds<NC>::kRing;
@@ -227,21 +227,46 @@ __device__ __forceinline__ void wsConsume(const DevScene& sc, const PathBuffers&
             const bool leafAtTop = (cur & kLeafFlag) != 0;
             if (!leafAtTop) {
                 if (COUNT) { const bool sh = (slot & kShadowBit) != 0; cnt.nodes[0] += sh ? 0u : 1u; cnt.nodes[1] += sh ? 1u : 0u; }
-                // float4 index inside a node: 0..2 = min xyz, 3..5 = max xyz, 6 = children (QBVH.h:66-71 folded into offsets)
-                const int nx = idx > 0.0f ? 0 : 3, fx = 3 - nx;
-                const int ny = idy > 0.0f ? 1 : 4, fy = 5 - ny;
-                const int nz = idz > 0.0f ? 2 : 5, fz = 7 - nz;
-                // 32-bit byte offsets from the (uniform) array base: SGPR-base + VGPR-offset addressing, one VALU op per load
-                // instead of a 64-bit address computation (node array < 4 GiB: checked at upload)
-                const char* nb = reinterpret_cast<const char*>(nodes4);
-                const uint32_t nOff = cur * 128u;
-                const float4 nX = *reinterpret_cast<const float4*>(nb + (nOff + (uint32_t)nx * 16u));
-                const float4 nY = *reinterpret_cast<const float4*>(nb + (nOff + (uint32_t)ny * 16u));
-                const float4 nZ = *reinterpret_cast<const float4*>(nb + (nOff + (uint32_t)nz * 16u));
-                const float4 fX = *reinterpret_cast<const float4*>(nb + (nOff + (uint32_t)fx * 16u));
-                const float4 fY = *reinterpret_cast<const float4*>(nb + (nOff + (uint32_t)fy * 16u));
-                const float4 fZ = *reinterpret_cast<const float4*>(nb + (nOff + (uint32_t)fz * 16u));
-                const float4 ch = *reinterpret_cast<const float4*>(nb + (nOff + 96u));
+                // float4 index inside a 128-byte node: 0..2 = min xyz, 3..5 = max xyz, 6 = children (QBVH.h:66-71 folded into offsets)
+                float4 nX, nY, nZ, fX, fY, fZ, ch;
+                if (QUANT) {
+                    // 64-byte node, 8-bit child boxes (device_types.h QNodeQ): plane = fma(byte, scale, origin), rounded outwards by
+                    // the host, so the boxes are supersets of the float boxes and the set of hits is unchanged
+                    const char* nb = reinterpret_cast<const char*>(sc.nodesQ);
+                    const uint32_t nOff = cur * 64u;
+                    const float4 v0 = *reinterpret_cast<const float4*>(nb + nOff);
+                    const float4 v1 = *reinterpret_cast<const float4*>(nb + (nOff + 16u));
+                    const float4 v2 = *reinterpret_cast<const float4*>(nb + (nOff + 32u));
+                    ch = *reinterpret_cast<const float4*>(nb + (nOff + 48u));
+                    const uint32_t qlox = __float_as_uint(v1.z), qloy = __float_as_uint(v1.w), qloz = __float_as_uint(v2.x);
+                    const uint32_t qhix = __float_as_uint(v2.y), qhiy = __float_as_uint(v2.z), qhiz = __float_as_uint(v2.w);
+                    const uint32_t nqx = idx > 0.0f ? qlox : qhix, fqx = idx > 0.0f ? qhix : qlox;      // QBVH.h:66-71
+                    const uint32_t nqy = idy > 0.0f ? qloy : qhiy, fqy = idy > 0.0f ? qhiy : qloy;
+                    const uint32_t nqz = idz > 0.0f ? qloz : qhiz, fqz = idz > 0.0f ? qhiz : qloz;
+#define WS_DEQ(q, sh, scale, org) __builtin_fmaf((float)(((q) >> (sh)) & 0xFFu), scale, org)
+#define WS_DEQ4(q, scale, org) make_float4(WS_DEQ(q, 0, scale, org), WS_DEQ(q, 8, scale, org), WS_DEQ(q, 16, scale, org), WS_DEQ(q, 24, scale, org))
+                    nX = WS_DEQ4(nqx, v0.w, v0.x); fX = WS_DEQ4(fqx, v0.w, v0.x);
+                    nY = WS_DEQ4(nqy, v1.x, v0.y); fY = WS_DEQ4(fqy, v1.x, v0.y);
+                    nZ = WS_DEQ4(nqz, v1.y, v0.z); fZ = WS_DEQ4(fqz, v1.y, v0.z);
+#undef WS_DEQ4
+#undef WS_DEQ
+                }
+                else {
+                    // 32-bit byte offsets from the (uniform) array base: SGPR-base + VGPR-offset addressing, one VALU op per load
+                    // instead of a 64-bit address computation (node array < 4 GiB: checked at upload)
+                    const int nx = idx > 0.0f ? 0 : 3, fx = 3 - nx;
+                    const int ny = idy > 0.0f ? 1 : 4, fy = 5 - ny;
+                    const int nz = idz > 0.0f ? 2 : 5, fz = 7 - nz;
+                    const char* nb = reinterpret_cast<const char*>(nodes4);
+                    const uint32_t nOff = cur * 128u;
+                    nX = *reinterpret_cast<const float4*>(nb + (nOff + (uint32_t)nx * 16u));
+                    nY = *reinterpret_cast<const float4*>(nb + (nOff + (uint32_t)ny * 16u));
+                    nZ = *reinterpret_cast<const float4*>(nb + (nOff + (uint32_t)nz * 16u));
+                    fX = *reinterpret_cast<const float4*>(nb + (nOff + (uint32_t)fx * 16u));
+                    fY = *reinterpret_cast<const float4*>(nb + (nOff + (uint32_t)fy * 16u));
+                    fZ = *reinterpret_cast<const float4*>(nb + (nOff + (uint32_t)fz * 16u));
+                    ch = *reinterpret_cast<const float4*>(nb + (nOff + 96u));
+                }
                 // slab test of QBVH::Node::intersect (QBVH.h:55-76): tNear <= tFar.  (Tried: fma(plane, id, -(o * id)) on
                 // padded boxes, half the arithmetic — but for rays that start ON a surface the cancellation noise near t = 0
                 // admits the boxes around the origin: 3x the triangle tests for shadow rays, 4x slower on the 10 M grid.)
@@ -367,7 +392,7 @@ __device__ __forceinline__ void wsConsume(const DevScene& sc, const PathBuffers&
 //            iff its state is FIRST_HIT or NEXT_HIT (flag values 2 and 3, pt_shade.hip).
 //   phase 2, shadow rays: Scene::testVisibility (SurfaceObject.cpp:418-430) = "no hit in [eps, d(1-eps)]"; workgroup b
 //            serves queue region b % kShards (gridDim is a multiple of kShards).
-template <bool COUNT, int NC>
+template <bool COUNT, int NC, bool QUANT>
 __global__ __launch_bounds__(64 * (NC + 1)) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_trace_ws(DevScene sc, PathBuffers pb, uint32_t numSlots, uint32_t shardCapacity, uint32_t parity, uint32_t refill) {
     __shared__ WsLds<NC> lds;
     if (blockIdx.x == 0 && threadIdx.x < Q_KINDS * kShards) {
@@ -439,7 +464,7 @@ __global__ __launch_bounds__(64 * (NC + 1)) __attribute__((amdgpu_waves_per_eu(8
         if (lane != 0) { extRays = 0; shadowRays = 0; }
     }
     else {
-        wsConsume<COUNT, NC>(sc, pb, lds, refill, cnt, dbg);
+        wsConsume<COUNT, NC, QUANT>(sc, pb, lds, refill, cnt, dbg);
     }
     wsBlockAdd(pb.totals, T_EXT_RAYS, extRays, lds.red);
     wsBlockAdd(pb.totals, T_SHADOW_RAYS, shadowRays, lds.red);
@@ -459,16 +484,22 @@ __global__ __launch_bounds__(64 * (NC + 1)) __attribute__((amdgpu_waves_per_eu(8
     }
 }
 
+template <bool COUNT, int NC>
+static void launchTraceWsT(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, uint32_t blocks, hipStream_t stream) {
+    const dim3 grid(blocks), block(64 * (NC + 1));
+    if (sc.nodesQ) hipLaunchKernelGGL((k_trace_ws<COUNT, NC, true>), grid, block, 0, stream, sc, pb, rp.numSlots, rp.shardCapacity, parity, g_refill);
+    else hipLaunchKernelGGL((k_trace_ws<COUNT, NC, false>), grid, block, 0, stream, sc, pb, rp.numSlots, rp.shardCapacity, parity, g_refill);
+}
 void launchTraceWs(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, uint32_t blocks, bool count,
                    hipStream_t stream) {
     blocks = (blocks + kShards - 1) / kShards * kShards;
     if (g_consumers == 7) {
-        if (count) hipLaunchKernelGGL((k_trace_ws<true, 7>), dim3(blocks), dim3(512), 0, stream, sc, pb, rp.numSlots, rp.shardCapacity, parity, g_refill);
-        else hipLaunchKernelGGL((k_trace_ws<false, 7>), dim3(blocks), dim3(512), 0, stream, sc, pb, rp.numSlots, rp.shardCapacity, parity, g_refill);
+        if (count) launchTraceWsT<true, 7>(sc, pb, rp, parity, blocks, stream);
+        else launchTraceWsT<false, 7>(sc, pb, rp, parity, blocks, stream);
     }
     else {
-        if (count) hipLaunchKernelGGL((k_trace_ws<true, 3>), dim3(blocks), dim3(256), 0, stream, sc, pb, rp.numSlots, rp.shardCapacity, parity, g_refill);
-        else hipLaunchKernelGGL((k_trace_ws<false, 3>), dim3(blocks), dim3(256), 0, stream, sc, pb, rp.numSlots, rp.shardCapacity, parity, g_refill);
+        if (count) launchTraceWsT<true, 3>(sc, pb, rp, parity, blocks, stream);
+        else launchTraceWsT<false, 3>(sc, pb, rp, parity, blocks, stream);
     }
 }
 

@@ -95,6 +95,7 @@ struct slrhip_ctx {
 
     // scene
     DevArray<QNode> nodes;
+    DevArray<QNodeQ> nodesQ;
     DevArray<LeafTri> leafTris;
     DevArray<ShadeTri> shadeTris;
     DevArray<LightTri> lightTris;
@@ -384,6 +385,10 @@ int slrhip_upload_scene(slrhip_ctx* ctx, const slrhip_scene_desc* d) {
 
     // --- upload ----------------------------------------------------------------------------------------------
     HIP_TRY(ctx->nodes.upload(bvh.nodes));
+    // trees beyond the L2 (>= 64 Ki nodes = 8 MiB) are also stored with 8-bit child boxes: half the bytes per node visit
+    static const bool noQuant = [] { const char* e = getenv("SLRHIP_QUANT"); return e && std::string(e) == "0"; }();
+    const bool quant = bvh.nodes.size() >= 65536 && !noQuant;
+    if (quant) { quantizeNodes(&bvh); HIP_TRY(ctx->nodesQ.upload(bvh.quantized)); }
     HIP_TRY(ctx->leafTris.upload(bvh.leafTris));
     HIP_TRY(ctx->shadeTris.upload(shade));
     HIP_TRY(ctx->lightTris.upload(lights));
@@ -414,6 +419,7 @@ int slrhip_upload_scene(slrhip_ctx* ctx, const slrhip_scene_desc* d) {
     sc.lightPMF = ctx->lightPMF.ptr;
     sc.lightCDF = ctx->lightCDF.ptr;
     sc.numNodes = (uint32_t)bvh.nodes.size();
+    sc.nodesQ = quant ? reinterpret_cast<const float4*>(ctx->nodesQ.ptr) : nullptr;
     sc.numMaterials = (uint32_t)mats.size();
     sc.numSpectra = (uint32_t)devSpectra.size();
     sc.numLights = (uint32_t)lights.size();

@@ -179,6 +179,23 @@ def test_trace_schedules_agree_bit_for_bit(oracle_rgb):
     assert_bit_equal(frames[2], frames[1], "wave-specialised, second run")
 
 
+def test_quantized_nodes_give_the_same_hits():
+    """Trees of >= 64 Ki nodes are traversed through 64-byte nodes with 8-bit child boxes (rounded outwards on the host):
+    a superset of the float boxes, so frame and ray counts must equal those of the batch kernels on the float nodes."""
+    sc = scenes.displaced_grid(400, 16.0 / 9.0)
+    st = ob.settings(320, 180, seed=9)
+    frames, counts = [], []
+    for flags in (abi.FLAG_TRACE_BATCH, 0):
+        c = Context(stripes=4, flags=flags)
+        frames.append(c.render_image(sc, st, 16))
+        k = c.counters()
+        assert k.bvh_nodes >= 65536
+        counts.append((int(k.extension_rays), int(k.shadow_rays), int(k.samples)))
+        c.close()
+    assert counts[0] == counts[1], counts
+    assert_bit_equal(frames[1], frames[0], "quantized wave-specialised vs float batch")
+
+
 def test_errors_are_loud(ctx):
     import ctypes as C
     from slr_amd.binding import SlrHipError
