@@ -31,6 +31,22 @@ uint32_t Scene::addSpectrumRGB(float r, float g, float b) {
     m_spectra.push_back(s);
     return (uint32_t)m_spectra.size() - 1;
 }
+uint32_t Scene::addSpectrum(slrhip_spectrum descriptor, const float* payload, uint32_t numPayloadFloats) {
+    while (m_spectrumData.size() % 4) m_spectrumData.push_back(0.0f);
+    descriptor.data_offset = (uint32_t)m_spectrumData.size();
+    if (payload) m_spectrumData.insert(m_spectrumData.end(), payload, payload + numPayloadFloats);
+    m_spectra.push_back(descriptor);
+    return (uint32_t)m_spectra.size() - 1;
+}
+void Scene::setEnvironment(const float* texels, uint32_t width, uint32_t height, float scale, const float* importance, uint32_t mapWidth,
+                           uint32_t mapHeight) {
+    m_envTexels.assign(texels, texels + (size_t)width * height * 3);
+    m_envImportance.assign(importance, importance + (size_t)mapWidth * mapHeight);
+    std::memset(&m_env, 0, sizeof(m_env));
+    m_env.width = width; m_env.height = height; m_env.scale = scale;
+    m_env.map_width = mapWidth; m_env.map_height = mapHeight;
+    m_hasEnv = true;
+}
 uint32_t Scene::addMaterial(uint32_t type, int32_t s0, int32_t s1, int32_t s2, float param, int32_t emittance) {
     slrhip_material m = {type, {s0, s1, s2}, param, emittance};
     m_materials.push_back(m);
@@ -46,6 +62,12 @@ slrhip_scene_desc Scene::desc() const {
     d.spectrum_data = m_spectrumData.data(); d.num_spectrum_data = (uint32_t)m_spectrumData.size();
     d.camera = m_camera;
     d.env = nullptr;
+    if (m_hasEnv) {
+        // the descriptor points into this object: valid as long as the Scene is
+        const_cast<Scene*>(this)->m_env.texels = m_envTexels.data();
+        const_cast<Scene*>(this)->m_env.importance = m_envImportance.data();
+        d.env = &m_env;
+    }
     return d;
 }
 
@@ -55,7 +77,7 @@ static void die(const char* what, int rc) {
 }
 
 void PathTracingRenderer::render(const Scene& scene, const RenderSettings& settings) const {
-    slrhip_config cfg = {m_device, SLRHIP_MODE_RGB, 0, 0};
+    slrhip_config cfg = {m_device, m_mode, 0, 0};
     slrhip_ctx* ctx = nullptr;
     int rc = slrhip_create(&cfg, &ctx);
     if (rc) die("slrhip_create", rc);
@@ -77,7 +99,8 @@ void PathTracingRenderer::render(const Scene& scene, const RenderSettings& setti
     float sensitivity = cam.sensitivity > 0 ? cam.sensitivity : (float)(1.0f / (M_PI * (double)cam.lens_radius * (double)cam.lens_radius));
     if (std::isinf(sensitivity)) sensitivity = 1.0f;
 
-    const size_t numFloats = (size_t)st.image_width * st.image_height * 3;
+    const int components = slrhip_components(ctx);          // 3, or the 16 storage bins of the spectral build
+    const size_t numFloats = (size_t)st.image_width * st.image_height * components;
     std::vector<float> fb(numFloats);
     const uint32_t byteWidth = 3u * (uint32_t)st.image_width + (uint32_t)st.image_width % 4u;
     std::vector<uint8_t> bmp((size_t)byteWidth * st.image_height);
@@ -97,7 +120,7 @@ void PathTracingRenderer::render(const Scene& scene, const RenderSettings& setti
             std::snprintf(filename, sizeof(filename), "%03u.bmp", imgIdx);
             double elapsed = (double)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::system_clock::now() - start).count();
             const float scale = st.brightness / (float)done * sensitivity;
-            if ((rc = slrhip_tonemap_bgr8(fb.data(), st.image_width, st.image_height, 3, scale, bmp.data(), bmp.size()))) die("slrhip_tonemap_bgr8", rc);
+            if ((rc = slrhip_tonemap_bgr8(fb.data(), st.image_width, st.image_height, components, scale, bmp.data(), bmp.size()))) die("slrhip_tonemap_bgr8", rc);
             const std::string path = m_outputDir + "/" + filename;
             if ((rc = slrhip_save_bmp(path.c_str(), bmp.data(), st.image_width, st.image_height))) die("slrhip_save_bmp", rc);
             std::printf("%u samples: %s, %g[s]\n", exportPass, filename, elapsed * 0.001f);

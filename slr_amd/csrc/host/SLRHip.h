@@ -41,11 +41,21 @@ class Scene {
     std::vector<slrhip_spectrum> m_spectra;
     std::vector<float> m_spectrumData;
     slrhip_camera m_camera;
+    std::vector<float> m_envTexels, m_envImportance;
+    slrhip_envmap m_env;
+    bool m_hasEnv = false;
 public:
     Scene();
     uint32_t addVertex(const float position[3], const float normal[3], const float tangent[3], const float texcoord[2]);
     uint32_t addTriangle(uint32_t v0, uint32_t v1, uint32_t v2, uint32_t material);
     uint32_t addSpectrumRGB(float r, float g, float b);
+    // A spectrum with its spectral-mode descriptor (UPSAMPLED / REGULAR / IRREGULAR, include/slrhip.h) and sample payload;
+    // data_offset is assigned here (16-byte aligned).  RGB mode reads only descriptor.rgb.
+    uint32_t addSpectrum(slrhip_spectrum descriptor, const float* payload, uint32_t numPayloadFloats);
+    // Image-based environment light (InfiniteSphereSurfaceObject + IBLEmission): lat-long texels [height][width][3], the
+    // `scale` of IBLEmission, and the quarter-resolution luminance map ImageSpectrumTexture::createIBLImportanceMap would build.
+    void setEnvironment(const float* texels, uint32_t width, uint32_t height, float scale, const float* importance, uint32_t mapWidth,
+                        uint32_t mapHeight);
     uint32_t addMaterial(uint32_t type, int32_t s0, int32_t s1, int32_t s2, float param, int32_t emittance);
     void setCamera(const slrhip_camera& camera) { m_camera = camera; }
     const slrhip_camera& camera() const { return m_camera; }
@@ -62,9 +72,11 @@ class PathTracingRenderer : public Renderer {
     uint32_t m_samplesPerPixel;
     int m_device;
     std::string m_outputDir;
+    int m_mode;
 public:
-    explicit PathTracingRenderer(uint32_t spp, int device = 0, const std::string& outputDir = ".")
-        : m_samplesPerPixel(spp), m_device(device), m_outputDir(outputDir) {}
+    // mode: SLRHIP_MODE_RGB or SLRHIP_MODE_SPECTRAL — the reference's compile-time Use_Spectral_Representation switch
+    explicit PathTracingRenderer(uint32_t spp, int device = 0, const std::string& outputDir = ".", int mode = SLRHIP_MODE_RGB)
+        : m_samplesPerPixel(spp), m_device(device), m_outputDir(outputDir), m_mode(mode) {}
     void render(const Scene& scene, const RenderSettings& settings) const override;
 };
 
