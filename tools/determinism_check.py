@@ -5,11 +5,10 @@ CODE = r'''
 import sys, hashlib
 sys.path.insert(0, ".")
 import numpy as np
-from slr_amd import Context, scenes
-from oracle import binding as ob
+from slr_amd import Context, abi, scenes
 W, H, SPP = 1280, 720, int(sys.argv[1])
 c = Context()
-fb = c.render_image(scenes.cornell_box_spheres(W / H, 48, 24, "matte"), ob.settings(W, H), SPP)
+fb = c.render_image(scenes.cornell_box_spheres(W / H, 48, 24, "matte"), abi.RenderSettings(W, H, 0.0, 0.0, 1.0, abi.DEFAULT_SEED), SPP)
 k = c.counters()
 print(hashlib.sha1(fb.tobytes()).hexdigest()[:16], k.extension_rays, k.shadow_rays, k.samples)
 '''

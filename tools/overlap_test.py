@@ -3,11 +3,10 @@ import sys, time, threading
 sys.path.insert(0, ".")
 import torch
 from slr_amd import Context, abi, scenes
-from oracle import binding as ob
 
 W, H, SPP = 1280, 720, 256
 sc = scenes.cornell_box_spheres(W / H, 48, 24, "matte")
-st = ob.settings(W, H)
+st = abi.RenderSettings(W, H, 0.0, 0.0, 1.0, abi.DEFAULT_SEED)
 
 
 def one(stripes, spp, stream=None, begin=0):

@@ -2,10 +2,9 @@ import sys, time
 sys.path.insert(0, ".")
 import numpy as np
 from slr_amd import Context, abi, scenes
-from oracle import binding as ob
 for mode, name in ((abi.MODE_SPECTRAL, "spectral"), (abi.MODE_RGB, "rgb")):
     for scn, sc in (("boxes_ggx", scenes.cornell_box_boxes(1280/720)), ("spheres_matte", scenes.cornell_box_spheres(1280/720, 48, 24, "matte"))):
-        st = ob.settings(1280, 720)
+        st = abi.RenderSettings(1280, 720, 0.0, 0.0, 1.0, abi.DEFAULT_SEED)
         c = Context(mode=mode, flags=abi.FLAG_TIME_KERNELS)
         c.upload_scene(sc)
         c.render_begin(st); c.render(0, 16); c.synchronize()
