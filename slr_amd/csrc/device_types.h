@@ -102,7 +102,8 @@ struct alignas(16) DevSpectrum {
     uint32_t numPoints;     // UPSAMPLED: 3 or 4 data points (0 = outside the grid)
     uint32_t numSamples;
     uint32_t dataOffset;    // into the float pool
-    float scale, lambdaMin, lambdaMax, pad;
+    float scale, lambdaMin, lambdaMax;
+    uint32_t cellOffset;    // IRREGULAR: pool offset of the 472-byte search table built at upload, 0xFFFFFFFF = none
 };
 static_assert(sizeof(DevSpectrum) == 32, "DevSpectrum layout");
 

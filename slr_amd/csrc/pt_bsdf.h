@@ -41,7 +41,7 @@ SLR_DEV DevSpectrum loadSpectrumRecord(const DevSpectrum* spectra, int32_t idx) 
     const uint4 a = q[0], b = q[1];
     DevSpectrum sp;
     sp.kind = a.x; sp.numPoints = a.y; sp.numSamples = a.z; sp.dataOffset = a.w;
-    sp.scale = __uint_as_float(b.x); sp.lambdaMin = __uint_as_float(b.y); sp.lambdaMax = __uint_as_float(b.z); sp.pad = 0.0f;
+    sp.scale = __uint_as_float(b.x); sp.lambdaMin = __uint_as_float(b.y); sp.lambdaMax = __uint_as_float(b.z); sp.cellOffset = b.w;
     return sp;
 }
 
@@ -71,14 +71,21 @@ SLR_DEV S evalSpectrum(const DevSpectrum* spectra, const float* __restrict__ poo
         const int32_t n = (int32_t)sp.numSamples;
         const float* lambdas = data;
         const float* values = data + n;
-        // lower_bound = first index with lambdas[idx] >= wl.  It never decreases from one component to the next (wl ascends),
-        // so only the first component of a lane does the binary search; the others walk on from the previous position
-        // (29 nm per component against the tables' 5-25 nm steps: a few probes).
+        // lower_bound = first index with lambdas[idx] >= wl.  With the host's cell table (slrhip_api.hip: lower_bound of every
+        // 1-nm cell start, one byte each) the search starts at the cell's entry and walks at most a step or two: two
+        // dependent loads instead of a binary search per component.  Without one: binary search for a lane's first component,
+        // then onwards from the previous position (the index never decreases as wl ascends).
+        const uint32_t* cellWords = sp.cellOffset != 0xFFFFFFFFu ? reinterpret_cast<const uint32_t*>(pool + sp.cellOffset) : nullptr;
         int32_t lo = 0;
         bool first = true;
         return S::make([&](int i) {
             const float wl = wavelengthOf(i, wlOffset);
-            if (first) {
+            if (cellWords) {
+                const uint32_t cell = min((uint32_t)fmaxf(wl - 360.0f, 0.0f), 471u);
+                lo = (int32_t)((cellWords[cell >> 2] >> (8u * (cell & 3u))) & 0xFFu);
+                while (lo < n && lambdas[lo] < wl) ++lo;
+            }
+            else if (first) {
                 int32_t hi = n;
                 while (lo < hi) { int32_t mid = (lo + hi) >> 1; if (lambdas[mid] < wl) lo = mid + 1; else hi = mid; }
                 first = false;

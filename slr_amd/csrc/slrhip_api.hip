@@ -8,6 +8,7 @@
 // There is no CPU fallback: without a HIP device every entry point fails loudly.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -262,6 +263,7 @@ int slrhip_upload_scene(slrhip_ctx* ctx, const slrhip_scene_desc* d) {
         std::memset(&ds, 0, sizeof(ds));
         ds.kind = sp.kind; ds.numPoints = sp.reserved; ds.numSamples = sp.num_samples; ds.dataOffset = sp.data_offset;
         ds.scale = sp.scale; ds.lambdaMin = sp.lambda_min; ds.lambdaMax = sp.lambda_max;
+        ds.cellOffset = 0xFFFFFFFFu;
         size_t need = 0;
         if (sp.kind == SLRHIP_SPECTRUM_REGULAR) need = sp.num_samples;
         else if (sp.kind == SLRHIP_SPECTRUM_IRREGULAR) need = 2 * (size_t)sp.num_samples;
@@ -394,14 +396,32 @@ int slrhip_upload_scene(slrhip_ctx* ctx, const slrhip_scene_desc* d) {
     HIP_TRY(ctx->lightTris.upload(lights));
     HIP_TRY(ctx->materials.upload(mats));
     HIP_TRY(ctx->materialsS.upload(matsS));
-    HIP_TRY(ctx->spectra.upload(devSpectra));
     {
         std::vector<float> pool;
         if (spectral && d->spectrum_data) pool.assign(d->spectrum_data, d->spectrum_data + d->num_spectrum_data);
+        // Irregular spectra are evaluated with std::lower_bound per wavelength (SpectrumTypes.h:143-146): on the GPU that is a
+        // chain of dependent loads per component.  A path's wavelengths lie in [360, 830], so for every 1-nm cell the host
+        // stores lower_bound(cell start) as one byte: the device starts there and walks at most a step or two — the same index.
+        for (uint32_t i = 0; i < d->num_spectra && spectral; ++i) {
+            const slrhip_spectrum& sp = d->spectra[i];
+            if (sp.kind != SLRHIP_SPECTRUM_IRREGULAR || sp.num_samples > 255) continue;
+            while (pool.size() % 4) pool.push_back(0.0f);
+            const float* lambdas = d->spectrum_data + sp.data_offset;
+            const uint32_t cells = 472;                                   // 360 + j, j = 0 .. 471
+            std::vector<uint32_t> words(cells / 4, 0u);
+            for (uint32_t j = 0; j < cells; ++j) {
+                const float start = 360.0f + (float)j;
+                const uint32_t lb = (uint32_t)(std::lower_bound(lambdas, lambdas + sp.num_samples, start) - lambdas);
+                words[j / 4] |= lb << (8 * (j % 4));
+            }
+            devSpectra[i].cellOffset = (uint32_t)pool.size();
+            for (uint32_t w : words) { float f; std::memcpy(&f, &w, 4); pool.push_back(f); }
+        }
         while (pool.size() % 4) pool.push_back(0.0f);          // the shade kernel stages the pool into LDS 16 bytes at a time
         ctx->scene.numSpectrumData = (uint32_t)pool.size();
         HIP_TRY(ctx->spectrumPool.upload(pool));
     }
+    HIP_TRY(ctx->spectra.upload(devSpectra));
     HIP_TRY(ctx->lightPMF.upload(pmf));
     HIP_TRY(ctx->lightCDF.upload(cdf));
     HIP_TRY(ctx->envTexels.upload(envTexels));
