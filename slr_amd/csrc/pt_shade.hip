@@ -608,13 +608,33 @@ __global__ __launch_bounds__(kShadeBlock) void k_logic(DevScene sc, PathBuffers 
 __device__ __forceinline__ RGB storageAddend(const RGB& val, float) { return val; }
 __device__ __forceinline__ Spec16 storageAddend(const Spec16& val, float wlOffset) {
     const float recBinWidth = 16 / (830.0f - 360.0f);
-    Spec16 addend;
+    uint32_t sBin[16];
+    float v[16];
+    bool near = true;           // every component lands in its own bin or a neighbour (it always does up to rounding: lambda_i = 360 + 470 (i + u) / 16)
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        const uint32_t sBin = min((uint32_t)((wavelengthOf(i, wlOffset) - 360.0f) / (830.0f - 360.0f) * 16), 15u);
-        const float v = val.c[i] * recBinWidth;
+        sBin[i] = min((uint32_t)((wavelengthOf(i, wlOffset) - 360.0f) / (830.0f - 360.0f) * 16), 15u);
+        v[i] = val.c[i] * recBinWidth;
+        near = near && (sBin[i] + 1u >= (uint32_t)i) && (sBin[i] <= (uint32_t)i + 1u);
+    }
+    Spec16 addend;
+    if (near) {
+        // bin b can only receive components b-1, b, b+1: three guarded adds in component order instead of sixteen
 #pragma unroll
-        for (int b = 0; b < 16; ++b) addend.c[b] = (sBin == (uint32_t)b) ? addend.c[b] + v : addend.c[b];
+        for (int b = 0; b < 16; ++b) {
+            float a = 0.0f;
+            if (b > 0) a = (sBin[b - 1] == (uint32_t)b) ? a + v[b - 1] : a;
+            a = (sBin[b] == (uint32_t)b) ? a + v[b] : a;
+            if (b < 15) a = (sBin[b + 1] == (uint32_t)b) ? a + v[b + 1] : a;
+            addend.c[b] = a;
+        }
+    }
+    else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+#pragma unroll
+            for (int b = 0; b < 16; ++b) addend.c[b] = (sBin[i] == (uint32_t)b) ? addend.c[b] + v[i] : addend.c[b];
+        }
     }
     return addend;
 }
