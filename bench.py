@@ -274,6 +274,20 @@ def main():
                 d = (got.astype(np.float64) - want) / n * sens
                 out["parity"] = {"spp": n, "rmse_vs_cpu_matched_seeds": float(np.sqrt(np.mean(d * d))),
                                  "bit_exact_fraction": float(exact.mean()), "mean_radiance": float(want.mean() / n * sens)}
+                if comps == 16:
+                    # spectral RMSE on the 16 bins (above) and after DiscretizedSpectrum::getRGB (SpectrumTypes.h:702-721)
+                    from slr_amd import spectra
+                    t = spectra.tables()["cmf16"].astype(np.float64)
+                    m = np.array([[3.2404542, -1.5371385, -0.4985314], [-0.9692660, 1.8760108, 0.0415560], [0.0556434, -0.2040259, 1.0572252]])
+                    to_rgb = lambda fb: ((fb.astype(np.float64) / n * sens) @ t[:48].reshape(3, 16).T / t[48]) @ m.T
+                    drgb = to_rgb(got) - to_rgb(want)
+                    out["parity"]["rmse_after_getRGB"] = float(np.sqrt(np.mean(drgb * drgb)))
+            # the restatement on ONE host core, a small sample: 320x180 x 4 spp of the same scene
+            t1 = time.perf_counter()
+            orc.render(abi.RenderSettings(W // 4, H // 4, 0.0, 0.0, 1.0, abi.DEFAULT_SEED), 4, threads=1)
+            sec1 = time.perf_counter() - t1
+            out["cpu_baseline_port_1thread"] = {"value": round((W // 4) * (H // 4) * 4 / sec1 / 1e6, 4), "unit": "Msamples/s", "cores": 1, "kind": "port",
+                                                "sample": "oracle restatement, %dx%d x 4 spp of the same scene, 1 thread" % (W // 4, H // 4)}
             out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
             guard.__exit__()
         print(json.dumps(out))

@@ -149,8 +149,12 @@ typedef struct slrhip_camera {
 /* ---- environment light ------------------------------------------------------------ */
 /* InfiniteSphereSurfaceObject + IBLEmission over an image texture (SurfaceObject.cpp:137-222,
  * SurfaceMaterials/IBLEmission.cpp:15-25, Textures/image_textures.cpp:13-79): a lat-long radiance map looked up
- * at the nearest texel (row 0 = theta 0 = +Y; u = phi / 2 pi), times `scale`, times pi.  RGB mode only.
- *   texels     : width * height * 3 floats, row-major (the reference stores RGBA16F: use half-representable values)
+ * at the nearest texel (row 0 = theta 0 = +Y; u = phi / 2 pi), times `scale`, times pi.
+ *   texels     : width * height * 3 floats, row-major.  RGB mode: (r, g, b) — the reference stores RGBA16F, use
+ *                half-representable values.  Spectral mode: (u, v, s) as the reference's spectral build stores an
+ *                RGB image (Upsampling::sRGB_to_uvs per texel, BasicTypes/Spectrum.h:148-171, kept as halves:
+ *                Core/Image.h:39-40); every look-up evaluates UpsampledContinuousSpectrum(u, v, s / EqualEnergyReflectance)
+ *                at the path's wavelengths (image_textures.cpp:23-32), which needs `upsampling` in the scene description.
  *   importance : map_width * map_height floats = the area-averaged luminance of each map cell, i.e. what
  *                ImageSpectrumTexture::createIBLImportanceMap's pickFunc computes BEFORE the sin(theta) factor
  *                (image_textures.cpp:81-132; map = quarter resolution).  It is an input because it is image
@@ -163,6 +167,18 @@ typedef struct slrhip_envmap {
     uint32_t map_width, map_height;
     const float* importance;
 } slrhip_envmap;
+
+/* The Meng-15 RGB-upsampling tables (BasicTypes/Spectrum.h:197-575) for spectra whose (u, v) is only known at run time,
+ * i.e. environment-map texels in spectral mode: grid_width x grid_height cells of 8 bytes {inside, num_points, idx[6]}
+ * (row-major), num_points data points with their (u, v) and their 95-sample spectra (360-830 nm).  Constant spectra do
+ * not need it: their cell look-up is resolved by the caller (slrhip_spectrum, kind UPSAMPLED).                       */
+typedef struct slrhip_upsampling_tables {
+    uint32_t grid_width, grid_height;      /* 12 x 14 */
+    const uint8_t* cells;                  /* grid_width * grid_height * 8 bytes */
+    uint32_t num_points;
+    const float* point_uv;                 /* num_points * 2 */
+    const float* point_spectrum;           /* num_points * 95 */
+} slrhip_upsampling_tables;
 
 /* ---- scene ----------------------------------------------------------------------- */
 typedef struct slrhip_scene_desc {
@@ -178,6 +194,7 @@ typedef struct slrhip_scene_desc {
     uint32_t num_spectrum_data;
     slrhip_camera camera;
     const slrhip_envmap* env;     /* NULL = no environment sphere (Scene::build envSphere = nullptr) */
+    const slrhip_upsampling_tables* upsampling;   /* needed only with an environment map in spectral mode, else may be NULL */
 } slrhip_scene_desc;
 
 /* ---- render settings -------------------------------------------------------------- */

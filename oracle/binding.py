@@ -74,7 +74,7 @@ class OracleScene:
     def __init__(self, lib, scene):
         self.lib = lib
         self.scene = scene  # keep the numpy arrays alive
-        desc = scene.desc()
+        desc = scene.desc(lib.mode)
         self.handle = lib._f("create")(C.byref(desc), lib.mode)
         if not self.handle:
             raise RuntimeError("oracle: scene rejected (%s)" % lib.prefix)

@@ -84,7 +84,8 @@ public:
 #ifndef Use_Spectral_Representation
         ret.r = t[0]; ret.g = t[1]; ret.b = t[2];
 #else
-        (void)t;
+        // the reference's own class does the look-up and the interpolation (image_textures.cpp:23-32): texel = (u, v, s)
+        ret = UpsampledContinuousSpectrum(t[0], t[1], t[2] / Upsampling::EqualEnergyReflectance).evaluate(wls);
 #endif
         return ret;
     }
@@ -242,7 +243,7 @@ slr_oracle_scene* slr_ref_create(const slrhip_scene_desc* d, int mode) {
     s->cameraTF = new StaticTransform(Matrix4x4(m), Matrix4x4(mi));
     s->camera->setTransform(s->cameraTF);
     if (d->env) {
-        if (kComponents != 3 || !d->env->texels || !d->env->importance) { slr_ref_destroy(s); return nullptr; }
+        if (!d->env->texels || !d->env->importance) { slr_ref_destroy(s); return nullptr; }
         s->envTexture = new ArrayEnvTexture(*d->env);
         s->envEmission = new IBLEmission(&s->scene, s->envTexture, d->env->scale);      // setEnvironment, API.cpp
         s->envSphere = new InfiniteSphereSurfaceObject(&s->scene, s->envEmission);

@@ -39,6 +39,11 @@ class EnvMap(C.Structure):
                 ("map_width", C.c_uint32), ("map_height", C.c_uint32), ("importance", C.c_void_p)]
 
 
+class UpsamplingTables(C.Structure):
+    _fields_ = [("grid_width", C.c_uint32), ("grid_height", C.c_uint32), ("cells", C.c_void_p), ("num_points", C.c_uint32),
+                ("point_uv", C.c_void_p), ("point_spectrum", C.c_void_p)]
+
+
 class SceneDesc(C.Structure):
     _fields_ = [("vertices", C.c_void_p), ("num_vertices", C.c_uint32),
                 ("triangles", C.c_void_p), ("num_triangles", C.c_uint32),
@@ -46,7 +51,8 @@ class SceneDesc(C.Structure):
                 ("spectra", C.c_void_p), ("num_spectra", C.c_uint32),
                 ("spectrum_data", C.c_void_p), ("num_spectrum_data", C.c_uint32),
                 ("camera", Camera),
-                ("env", C.POINTER(EnvMap))]
+                ("env", C.POINTER(EnvMap)),
+                ("upsampling", C.POINTER(UpsamplingTables))]
 
 
 class RenderSettings(C.Structure):
@@ -91,13 +97,21 @@ class Scene:
         self.camera = camera
         self.env_texels = None
         self.env = None
+        self.env_uvs = None
+        self._tables = None
         if env is not None:
-            texels, scale, importance = env
+            # (texels rgb, scale, importance) or, for both modes, (texels rgb, scale, importance rgb, texels uvs, importance uvs)
+            texels, scale, importance = env[:3]
             self.env_texels = np.ascontiguousarray(texels, dtype=np.float32)
             self.env_importance = np.ascontiguousarray(importance, dtype=np.float32)
             self.env_scale = float(scale)
             self.env = EnvMap(self.env_texels.shape[1], self.env_texels.shape[0], self.env_texels.ctypes.data, float(scale),
                               self.env_importance.shape[1], self.env_importance.shape[0], self.env_importance.ctypes.data)
+            if len(env) == 5:
+                self.env_texels_uvs = np.ascontiguousarray(env[3], dtype=np.float32)
+                self.env_importance_uvs = np.ascontiguousarray(env[4], dtype=np.float32)
+                self.env_uvs = EnvMap(self.env_texels_uvs.shape[1], self.env_texels_uvs.shape[0], self.env_texels_uvs.ctypes.data, float(scale),
+                                      self.env_importance_uvs.shape[1], self.env_importance_uvs.shape[0], self.env_importance_uvs.ctypes.data)
         self.name = name
         self._validate()
 
@@ -114,7 +128,19 @@ class Scene:
         if self.materials["spectrum"].max() >= ns or self.materials["emittance"].max() >= ns:
             raise ValueError("material references a spectrum out of range")
 
-    def desc(self):
+    def upsampling_tables(self):
+        if self._tables is None:
+            from . import spectra
+            t = spectra.tables()
+            cells = np.zeros((len(t["grid_inside"]), 8), np.uint8)
+            cells[:, 0], cells[:, 1], cells[:, 2:8] = t["grid_inside"], t["grid_num_points"], t["grid_idx"]
+            self._table_arrays = (np.ascontiguousarray(cells), np.ascontiguousarray(t["point_uv"], np.float32),
+                                  np.ascontiguousarray(t["point_spectrum"], np.float32))
+            self._tables = UpsamplingTables(spectra.GRID_WIDTH, spectra.GRID_HEIGHT, self._table_arrays[0].ctypes.data, len(self._table_arrays[1]),
+                                            self._table_arrays[1].ctypes.data, self._table_arrays[2].ctypes.data)
+        return self._tables
+
+    def desc(self, mode=MODE_RGB):
         d = SceneDesc()
         d.vertices, d.num_vertices = self.vertices.ctypes.data, len(self.vertices)
         d.triangles, d.num_triangles = self.triangles.ctypes.data, len(self.triangles)
@@ -122,7 +148,9 @@ class Scene:
         d.spectra, d.num_spectra = self.spectra.ctypes.data, len(self.spectra)
         d.spectrum_data, d.num_spectrum_data = self.spectrum_data.ctypes.data, len(self.spectrum_data)
         d.camera = self.camera
-        d.env = C.pointer(self.env) if self.env is not None else None
+        env = self.env_uvs if (mode == MODE_SPECTRAL and self.env_uvs is not None) else self.env
+        d.env = C.pointer(env) if env is not None else None
+        d.upsampling = C.pointer(self.upsampling_tables()) if (env is not None and mode == MODE_SPECTRAL) else None
         return d
 
 

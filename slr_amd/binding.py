@@ -88,7 +88,7 @@ class Context:
 
     def upload_scene(self, scene):
         self._scene = scene
-        desc = scene.desc()
+        desc = scene.desc(self.mode)
         _check(self.lib, self.lib.slrhip_upload_scene(self.handle, C.byref(desc)), "slrhip_upload_scene")
 
     def render_begin(self, settings, shard=(0, 1)):

@@ -37,6 +37,11 @@ struct DevScene {
     const float* envTopCDF;
     const float* envRowPDF;       // [mapHeight][mapWidth]
     const float* envRowCDF;       // [mapHeight][mapWidth + 1]
+    // spectral mode: the environment texels are (u, v, s); the Meng-15 tables to look them up at run time (slrhip_upsampling_tables)
+    uint32_t gridWidth, gridHeight;
+    const uint8_t* gridCells;     // 8 bytes per cell: inside, num_points, idx[6]
+    const float* pointUV;         // 2 per data point
+    const float* pointSpectrum;   // 95 per data point
     DevCamera camera;
 };
 

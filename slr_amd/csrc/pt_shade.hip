@@ -204,10 +204,91 @@ __device__ __forceinline__ RGB envEmittance(const DevScene& sc, float tcU, float
     const float* t = sc.envTexels + ((size_t)py * sc.envWidth + px) * 3;
     return ((float)kPi * RGB(t[0], t[1], t[2])) * sc.envScale;
 }
-template <class S> __device__ __forceinline__ S envEmittanceS(const DevScene& sc, float u, float v);
-template <> __device__ __forceinline__ RGB envEmittanceS<RGB>(const DevScene& sc, float u, float v) { return envEmittance(sc, u, v); }
-template <> __device__ __forceinline__ Spec16 envEmittanceS<Spec16>(const DevScene&, float, float) { return Spec16(); }   // rejected at upload
-template <> __device__ __forceinline__ SpecQ envEmittanceS<SpecQ>(const DevScene&, float, float) { return SpecQ(); }
+// UpsampledContinuousSpectrumTemplate::evaluate with its grid look-up (SpectrumTypes.h:239-339) at run time: the spectral
+// build's environment texels are (u, v, s) (image_textures.cpp:23-32).  Cell search and weights are per path (scalar), the
+// 16-wavelength interpolation goes through S::make like every other spectrum.
+template <class S>
+__device__ __forceinline__ S evaluateUpsampledRuntime(const DevScene& sc, float u, float v, float scale, float wlOffset) {
+    if (u < 0.0f || u >= (float)sc.gridWidth || v < 0.0f || v >= (float)sc.gridHeight) return S();
+    const int32_t ui = (int32_t)u, vi = (int32_t)v;
+    const uint8_t* cell = sc.gridCells + (size_t)(ui + (int32_t)sc.gridWidth * vi) * 8;
+    const uint2 cw = *reinterpret_cast<const uint2*>(cell);                      // inside, num_points, idx[0..5]
+    const uint32_t inside = cw.x & 0xFFu, numPoints = (cw.x >> 8) & 0xFFu;
+    const uint32_t idx6[6] = {(cw.x >> 16) & 0xFFu, cw.x >> 24, cw.y & 0xFFu, (cw.y >> 8) & 0xFFu, (cw.y >> 16) & 0xFFu, cw.y >> 24};
+    uint32_t used0 = 255u, used1 = 255u, used2 = 255u, used3 = 255u;
+    float w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+    if (inside) {
+        const float s = u - (float)ui, t = v - (float)vi;
+        w0 = (1 - s) * (1 - t); w1 = s * (1 - t); w2 = (1 - s) * t; w3 = s * t;
+        used0 = idx6[0]; used1 = idx6[1]; used2 = idx6[2]; used3 = idx6[3];
+    }
+    else {
+        const float2* uv = reinterpret_cast<const float2*>(sc.pointUV);
+        const float2 p0 = uv[idx6[0]], p1 = uv[idx6[1]];
+        const float ex = u - p0.x, ey = v - p0.y;
+        float e0x = p1.x - p0.x, e0y = p1.y - p0.y;
+        float uu = e0x * ey - ex * e0y;
+        for (uint32_t i = 1; i < numPoints; ++i) {
+            const uint32_t k = i % (numPoints - 1) + 1;
+            // idx6[k] with a run-time k: select chain over the six bytes
+            const uint32_t idx = k == 1 ? idx6[1] : k == 2 ? idx6[2] : k == 3 ? idx6[3] : k == 4 ? idx6[4] : idx6[5];
+            const uint32_t idxI = i == 1 ? idx6[1] : i == 2 ? idx6[2] : i == 3 ? idx6[3] : i == 4 ? idx6[4] : idx6[5];
+            const float2 pk = uv[idx];
+            const float e1x = pk.x - p0.x, e1y = pk.y - p0.y;
+            const float vv = ex * e1y - e1x * ey;
+            const float area = e0x * e1y - e1x * e0y;
+            const float bu = uu / area, bv = vv / area;
+            const float bw = 1.0f - bu - bv;
+            if ((double)bu < -1e-6 || (double)bv < -1e-6 || (double)bw < -1e-6) {
+                uu = -vv;
+                e0x = e1x;
+                e0y = e1y;
+                continue;
+            }
+            w0 = bu; w1 = bv; w2 = bw;
+            used0 = idx; used1 = idxI; used2 = idx6[0];
+            break;
+        }
+    }
+    if (used0 == 255u) return S();
+    const uint32_t nw = 95;
+    const float* t0 = sc.pointSpectrum + (size_t)used0 * nw;
+    const float* t1 = sc.pointSpectrum + (size_t)used1 * nw;
+    const float* t2 = sc.pointSpectrum + (size_t)used2 * nw;
+    const float* t3 = sc.pointSpectrum + (size_t)(used3 == 255u ? used0 : used3) * nw;
+    const bool four = used3 != 255u;
+    S ret = S::make([&](int i) {
+        float p = (wavelengthOf(i, wlOffset) - 360.0f) / (830.0f - 360.0f);
+        float sBinF = p * (float)(nw - 1);
+        uint32_t sBin = (uint32_t)sBinF;
+        uint32_t sBinNext = (sBin + 1 < nw) ? (sBin + 1) : (nw - 1);
+        float t = sBinF - (float)sBin;
+        float r = 0.0f;
+        r += w0 * (t0[sBin] * (1 - t) + t0[sBinNext] * t);
+        r += w1 * (t1[sBin] * (1 - t) + t1[sBinNext] * t);
+        r += w2 * (t2[sBin] * (1 - t) + t2[sBinNext] * t);
+        if (four) r += w3 * (t3[sBin] * (1 - t) + t3[sBinNext] * t);
+        return r;
+    });
+    return ret * scale;
+}
+template <class S>
+__device__ __forceinline__ S envEmittanceSpectral(const DevScene& sc, float tcU, float tcV, float wlOffset) {
+    float u = fmodf(tcU, 1.0f);
+    float v = fmodf(tcV, 1.0f);
+    u += u < 0 ? 1.0f : 0.0f;
+    v += v < 0 ? 1.0f : 0.0f;
+    uint32_t px = min((uint32_t)((float)sc.envWidth * u), sc.envWidth - 1);
+    uint32_t py = min((uint32_t)((float)sc.envHeight * v), sc.envHeight - 1);
+    const float* t = sc.envTexels + ((size_t)py * sc.envWidth + px) * 3;
+    const float kEqualEnergyReflectance = 0.009355121400914532f;                 // Upsampling::EqualEnergyReflectance
+    const S tex = evaluateUpsampledRuntime<S>(sc, t[0], t[1], t[2] / kEqualEnergyReflectance, wlOffset);
+    return ((float)kPi * tex) * sc.envScale;                                     // IBLEmission::emittance
+}
+template <class S> __device__ __forceinline__ S envEmittanceS(const DevScene& sc, float u, float v, float wlOffset);
+template <> __device__ __forceinline__ RGB envEmittanceS<RGB>(const DevScene& sc, float u, float v, float) { return envEmittance(sc, u, v); }
+template <> __device__ __forceinline__ Spec16 envEmittanceS<Spec16>(const DevScene& sc, float u, float v, float o) { return envEmittanceSpectral<Spec16>(sc, u, v, o); }
+template <> __device__ __forceinline__ SpecQ envEmittanceS<SpecQ>(const DevScene& sc, float u, float v, float o) { return envEmittanceSpectral<SpecQ>(sc, u, v, o); }
 // InfiniteSphereSurfaceObject::evaluateAreaPDF, SurfaceObject.cpp:217-222 (RegularConstantContinuous2D::evaluatePDF :218-224)
 __device__ __forceinline__ float envAreaPDF(const DevScene& sc, float phi, float theta) {
     float d0 = (float)((double)phi / (2 * kPi)), d1 = (float)((double)theta / kPi);
@@ -381,7 +462,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_logic(DevScene sc, PathBuffers 
                     float phi = fmodf((float)((double)atan2f(-rayDir.x, rayDir.z) + 2 * kPi), (float)(2 * kPi));
                     float texU = (float)((double)phi / (2 * kPi)), texV = (float)((double)theta / kPi);
                     // emittance x IBLEDF::evaluate = 1 / pi (EDFs/IBLEDF.cpp:19-23)
-                    S Le = envEmittanceS<S>(sc, texU, texV) * S((float)(1.0 / kPi));
+                    S Le = envEmittanceS<S>(sc, texU, texV, wlOffset) * S((float)(1.0 / kPi));
                     if (state == ST_FIRST_HIT) {
                         sp.add(pb, slot, rp.numSlots, alpha * Le);             // :152-157, atInfinity -> return sp
                     }
@@ -486,7 +567,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_logic(DevScene sc, PathBuffers 
                             lf.z = lgn;
                             lf.y = cross(lf.z, lf.x);
                             areaPDF = (float)((double)uvPDF / (2 * kPi * kPi * (double)sinf(theta)));
-                            M = envEmittanceS<S>(sc, (float)((double)phi / (2 * kPi)), (float)((double)theta / kPi));
+                            M = envEmittanceS<S>(sc, (float)((double)phi / (2 * kPi)), (float)((double)theta / kPi), wlOffset);
                             sdir = normalize(lp);                              // Scene::testVisibility :421-423: [eps, FLT_MAX]
                             shadowTmax = 3.402823466e+38f;
                         }

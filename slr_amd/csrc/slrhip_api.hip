@@ -106,6 +106,8 @@ struct slrhip_ctx {
     DevArray<float> spectrumPool;
     DevArray<float> lightPMF, lightCDF;
     DevArray<float> envTexels, envTopPDF, envTopCDF, envRowPDF, envRowCDF;
+    DevArray<uint8_t> gridCells;
+    DevArray<float> pointUV, pointSpectrum;
     DevScene scene;
     uint32_t bvhDepth = 0;
     double buildSeconds = 0.0;
@@ -196,8 +198,18 @@ int slrhip_upload_scene(slrhip_ctx* ctx, const slrhip_scene_desc* d) {
         return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: empty scene");
     if (d->env) {
         const slrhip_envmap& e = *d->env;
-        if (ctx->config.mode != SLRHIP_MODE_RGB)
-            return fail(SLRHIP_ERR_UNSUPPORTED, "slrhip_upload_scene: the environment light is implemented for RGB mode only");
+        if (ctx->config.mode == SLRHIP_MODE_SPECTRAL) {
+            const slrhip_upsampling_tables* t = d->upsampling;
+            if (!t || !t->cells || !t->point_uv || !t->point_spectrum || t->grid_width == 0 || t->grid_height == 0 || t->num_points == 0 ||
+                t->num_points > 255)
+                return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: an environment map in spectral mode needs slrhip_scene_desc::upsampling");
+            for (size_t c = 0; c < (size_t)t->grid_width * t->grid_height; ++c) {          // the kernels index with these bytes
+                const uint8_t* cell = t->cells + c * 8;
+                if (cell[1] > 6) return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: upsampling cell with more than 6 points");
+                for (int k = 0; k < (cell[0] ? 4 : cell[1]); ++k)
+                    if (cell[2 + k] >= t->num_points) return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: upsampling point index out of range");
+            }
+        }
         if (!e.texels || !e.importance || e.width == 0 || e.height == 0 || e.map_width == 0 || e.map_height == 0 ||
             e.width > 32768 || e.height > 32768 || e.map_width > 32768 || e.map_height > 32768)
             return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: bad environment map");
@@ -453,6 +465,20 @@ int slrhip_upload_scene(slrhip_ctx* ctx, const slrhip_scene_desc* d) {
         sc.envWidth = d->env->width; sc.envHeight = d->env->height;
         sc.envMapWidth = d->env->map_width; sc.envMapHeight = d->env->map_height;
         sc.envScale = d->env->scale;
+    }
+    {
+        std::vector<uint8_t> cells;
+        std::vector<float> puv, psp;
+        sc.gridWidth = sc.gridHeight = 0;
+        if (d->env && spectral) {
+            const slrhip_upsampling_tables* t = d->upsampling;
+            cells.assign(t->cells, t->cells + (size_t)t->grid_width * t->grid_height * 8);
+            puv.assign(t->point_uv, t->point_uv + (size_t)t->num_points * 2);
+            psp.assign(t->point_spectrum, t->point_spectrum + (size_t)t->num_points * 95);
+            sc.gridWidth = t->grid_width; sc.gridHeight = t->grid_height;
+        }
+        HIP_TRY(ctx->gridCells.upload(cells)); HIP_TRY(ctx->pointUV.upload(puv)); HIP_TRY(ctx->pointSpectrum.upload(psp));
+        sc.gridCells = ctx->gridCells.ptr; sc.pointUV = ctx->pointUV.ptr; sc.pointSpectrum = ctx->pointSpectrum.ptr;
     }
     sc.envTexels = ctx->envTexels.ptr;
     sc.envTopPDF = ctx->envTopPDF.ptr; sc.envTopCDF = ctx->envTopCDF.ptr;

@@ -312,6 +312,69 @@ def ibl_importance(texels):
     return out
 
 
+_SRGB_TO_XYZ = [(0.4124564, 0.3575761, 0.1804375), (0.2126729, 0.7151522, 0.0721750), (0.0193339, 0.1191920, 0.9503041)]
+
+
+def _f16(a):
+    return np.asarray(a, dtype=np.float32).astype(np.float16).astype(np.float32)
+
+
+def sky_to_uvs(texels):
+    """What the reference's spectral build stores for an RGB radiance image: Upsampling::sRGB_to_uvs(Illuminant) per texel
+    (BasicTypes/Spectrum.h:148-171: sRGB -> XYZ with double literals, b = X + Y + Z, xy, xy_to_uv, s = b) kept as halves
+    (Core/Image.h:39-40,265-310)."""
+    f = np.float32
+    rgb = np.asarray(texels, dtype=np.float32).astype(np.float64)
+    xyz = [(_SRGB_TO_XYZ[i][0] * rgb[..., 0] + _SRGB_TO_XYZ[i][1] * rgb[..., 1] + _SRGB_TO_XYZ[i][2] * rgb[..., 2]).astype(f) for i in range(3)]
+    b = (xyz[0] + xyz[1]).astype(f) + xyz[2]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        x, y = (xyz[0] / b).astype(f), (xyz[1] / b).astype(f)
+    third = f(1.0 / 3.0)
+    x, y = np.where(b == 0, third, x), np.where(b == 0, third, y)
+    u = (16.730260708356887 * x.astype(np.float64) + 7.7801960340706 * y.astype(np.float64) - 2.170152247475828).astype(f)
+    v = (-7.530081094743006 * x.astype(np.float64) + 16.192422314095225 * y.astype(np.float64) + 1.1125529268825947).astype(f)
+    return _f16(np.stack([u, v, b.astype(f)], axis=-1))
+
+
+def _area_average_4x4(plane):
+    """Image2D::areaAverage over each 4x4 block (Core/Image.cpp:19-120): corners, edges, interior Kahan-summed in that order with
+    unit coefficients, divided by the area, stored back as binary16."""
+    f = np.float32
+    h, w = plane.shape
+    order = [(0, 0), (3, 0), (0, 3), (3, 3)]
+    for x in (1, 2):
+        order += [(x, 0), (x, 3)]
+    for y in (1, 2):
+        order += [(0, y), (3, y)]
+    order += [(x, y) for y in (1, 2) for x in (1, 2)]
+    blocks = plane.reshape(h // 4, 4, w // 4, 4)
+    s = np.zeros((h // 4, w // 4), f)
+    comp = np.zeros_like(s)
+    for (x, y) in order:
+        val = blocks[:, y, :, x].astype(f)
+        ci = (val - comp).astype(f)
+        t = (s + ci).astype(f)
+        comp = ((t - s).astype(f) - ci).astype(f)
+        s = t
+    return _f16(s / f(16.0))
+
+
+def ibl_importance_uvs(uvs):
+    """createIBLImportanceMap for a uvs image (image_textures.cpp:81-132): area-average u, v, s per 4x4 block, uvs_to_sRGB
+    (Spectrum.h:174-195, Illuminant: uv_to_xy, XYZ = (x b, y b, b - X - Y), XYZ_to_sRGB), luminance in float."""
+    f = np.float32
+    au, av, asum = (_area_average_4x4(uvs[..., k]) for k in range(3))
+    x = (0.0491440520940413 * au.astype(np.float64) - 0.02361291916573777 * av.astype(np.float64) + 0.13292069743203658).astype(f)
+    y = (0.022853819546830627 * au.astype(np.float64) + 0.05077639329371236 * av.astype(np.float64) - 0.006895157122499944).astype(f)
+    X, Y = (x * asum).astype(f), (y * asum).astype(f)
+    Z = ((asum - X).astype(f) - Y).astype(f)
+    Xd, Yd, Zd = X.astype(np.float64), Y.astype(np.float64), Z.astype(np.float64)
+    r = (3.2404542 * Xd - 1.5371385 * Yd - 0.4985314 * Zd).astype(f)
+    g = (-0.9692660 * Xd + 1.8760108 * Yd + 0.0415560 * Zd).astype(f)
+    b = (0.0556434 * Xd - 0.2040259 * Yd + 1.0572252 * Zd).astype(f)
+    return ((f(0.222485) * r).astype(f) + (f(0.716905) * g).astype(f)).astype(f) + (f(0.060610) * b).astype(f)
+
+
 def ibl_test_scene(aspect=1.0, env_size=(256, 128), segments=24, rings=12, area_light=False):
     """Config 4 of BASELINE.json, IBL_Test-shaped (TestScenes/IBL_Test.txt:34-70): a 6x4 checker floor of matte patches,
     a mirror sphere of radius 0.4 standing on it, no area light: the only emitter is the environment sphere
@@ -332,7 +395,8 @@ def ibl_test_scene(aspect=1.0, env_size=(256, 128), segments=24, rings=12, area_
         b.add_quad([(-0.3, 1.6, -0.3), (0.3, 1.6, -0.3), (0.3, 1.6, 0.3), (-0.3, 1.6, 0.3)], (0, -1, 0), (1, 0, 0), lm)
     cam = make_camera(_translate(0.0, 0.9, 3.2) @ _rotate(3.1415926536, (0, 1, 0)) @ _rotate(0.2, (1, 0, 0)), aspect, 0.6, 0.02, 1.0, 3.2)
     sky = synthetic_sky(*env_size)
-    return b.build(cam, env=(sky, 4.0, ibl_importance(sky)), name="ibl_test")
+    uvs = sky_to_uvs(sky)
+    return b.build(cam, env=(sky, 4.0, ibl_importance(sky), uvs, ibl_importance_uvs(uvs)), name="ibl_test")
 
 
 def _hash_lattice(ix, iz, seed):

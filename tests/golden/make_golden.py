@@ -26,6 +26,9 @@ def scene_arrays(sc):
         # texels are binary16-exact (scenes.synthetic_sky): float16 storage is lossless
         assert np.array_equal(sc.env_texels.astype(np.float16).astype(np.float32), sc.env_texels)
         env = dict(env_texels=sc.env_texels.astype(np.float16), env_scale=np.float32(sc.env_scale), env_importance=sc.env_importance)
+        if sc.env_uvs is not None:
+            assert np.array_equal(sc.env_texels_uvs.astype(np.float16).astype(np.float32), sc.env_texels_uvs)
+            env.update(env_texels_uvs=sc.env_texels_uvs.astype(np.float16), env_importance_uvs=sc.env_importance_uvs)
     return dict(env, vertices=sc.vertices, triangles=sc.triangles, materials=sc.materials, spectra=sc.spectra,
                 spectrum_data=sc.spectrum_data,
                 camera=np.array(list(cam.local_to_world) + list(cam.world_to_local) +
@@ -123,6 +126,7 @@ def main():
     make("spectral_ggx_glass", scenes.cornell_lobes("ggx_glass", segments=10, rings=5), spec, 32, 32, 8, 2)
     make("rgb_ibl", scenes.ibl_test_scene(1.0, (128, 64), 12, 6), lib, 40, 40, 8, 2)
     make("rgb_ibl_area", scenes.ibl_test_scene(1.0, (128, 64), 12, 6, area_light=True), lib, 40, 40, 8, 2)
+    make("spectral_ibl", scenes.ibl_test_scene(1.0, (128, 64), 12, 6, area_light=True), spec, 32, 32, 8, 2)
     make("rgb_cornell_matte", scenes.cornell_box_spheres(4.0 / 3.0, 16, 8, "matte"), lib, 48, 36, 8, 2)
 
 

@@ -21,6 +21,8 @@ def scene_from_golden(g, name="golden"):
     env = None
     if "env_texels" in g.files:
         env = (g["env_texels"].astype(np.float32), float(g["env_scale"]), g["env_importance"])
+        if "env_texels_uvs" in g.files:
+            env = env + (g["env_texels_uvs"].astype(np.float32), g["env_importance_uvs"])
     return abi.Scene(g["vertices"], g["triangles"], g["materials"], g["spectra"], g["spectrum_data"], cam, env, name)
 
 

@@ -261,10 +261,31 @@ def test_environment_light_full_size_against_oracle(ctx, oracle_rgb):
     assert abs(int(c.shadow_rays) - int(ctr.shadow_rays)) <= ctr.shadow_rays * 1e-3
 
 
-def test_environment_light_is_rgb_only(sctx):
+def test_spectral_environment_light_matches_reference_golden_within_tolerance(sctx):
+    """Spectral build: environment texels are (u, v, s) and every look-up runs UpsampledContinuousSpectrum::evaluate with its grid
+    search (SpectrumTypes.h:239-339) on the device.  Same float-libm tolerance as the RGB environment test."""
+    g = load_golden("spectral_ibl")
+    st = ob.settings(int(g["width"]), int(g["height"]), int(g["seed"]))
+    fb = sctx.render_image(scene_from_golden(g), st, int(g["spp"]))
+    want = g["framebuffer"]
+    assert fb.shape == want.shape and fb.shape[2] == 16
+    close = np.isclose(fb, want, rtol=1e-4, atol=1e-9)
+    assert close.mean() >= 0.95, close.mean()
+    cap = 10 * float(want.mean())
+    sc = frame_stats(np.minimum(fb, cap), np.minimum(want, cap))
+    assert sc["rmse"] <= 1e-3 * sc["mean"], sc
+    assert np.isfinite(fb).all()
+
+
+def test_spectral_environment_needs_the_upsampling_tables(sctx):
+    import ctypes as C
     from slr_amd.binding import SlrHipError
+    scn = scenes.ibl_test_scene(1.0, (64, 32), 8, 4)
+    desc = scn.desc(abi.MODE_SPECTRAL)
+    desc.upsampling = None
     with pytest.raises(SlrHipError):
-        sctx.upload_scene(scenes.ibl_test_scene(1.0, (64, 32), 8, 4))
+        from slr_amd import binding
+        binding._check(sctx.lib, sctx.lib.slrhip_upload_scene(sctx.handle, C.byref(desc)), "slrhip_upload_scene")
 
 
 def test_boxes_scene_against_oracle(ctx, oracle_rgb):

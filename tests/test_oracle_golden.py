@@ -109,7 +109,8 @@ def test_rejects_bad_scene(oracle_rgb):
         abi.Scene(sc.vertices[:2], sc.triangles, sc.materials, sc.spectra, sc.spectrum_data, sc.camera)
 
 
-SPECTRAL_SCENES = ["spectral_cornell_glass", "spectral_cornell_matte", "spectral_oren_nayar", "spectral_ggx_metal", "spectral_ggx_glass"]
+SPECTRAL_SCENES = ["spectral_cornell_glass", "spectral_cornell_matte", "spectral_oren_nayar", "spectral_ggx_metal", "spectral_ggx_glass",
+                   "spectral_ibl"]     # environment texels as (u, v, s), looked up in the Meng-15 grid at run time, + an area light
 
 
 @pytest.mark.parametrize("name", SPECTRAL_SCENES)
