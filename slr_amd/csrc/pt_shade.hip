@@ -7,17 +7,17 @@
 //                    pass order — the Kahan sum of RGBStorage::add (RGBTypes.h:176-179), so the
 //                    framebuffer needs no atomics — then start the next sample of the same pixel:
 //                    Job::kernel's camera-ray half (PathTracingRenderer.cpp:100-120).
-//   k_trace_closest  extension-ray queue   (pt_trace.hip)
-//   k_trace_shadow   shadow-ray queue      (pt_trace.hip)
+//   k_trace_ws       every slot with a ray in flight (state flag) + the shadow-ray queue, one launch (pt_trace_ws.hip;
+//                    or the two batch kernels of pt_trace.hip)
 //   k_logic          every live slot: resolve the pending next-event estimate, shade the hit
 //                    (getSurfacePoint, emission + MIS, Russian roulette), then the next bounce: light
-//                    sampling + BSDF sampling (:161-221).  Emits the next extension ray, a shadow ray
-//                    and/or the slot index into the regen queue.
+//                    sampling + BSDF sampling (:161-221).  Emits the next extension ray in place, a shadow ray
+//                    (slot index into the shadow queue) and/or the slot index into the regen queue.
 //
-// Queues are slot-index lists in HBM built by wave ballot + popcount prefix with one atomic per wave
-// per queue; all path state is SoA in 16-byte records so a wave's loads are 1 KiB bursts.  The state
-// loads of k_logic are issued together at the top (the kernel is latency-bound: PMC shows > 80 % of
-// wave cycles waiting on memory), and the material / light tables live in LDS.
+// Queues are slot-index lists in HBM, 16 regions (one per blockIdx % 16), filled by wave ballot + popcount prefix with ONE
+// atomic per workgroup per queue on a counter that has its own 128-byte line (per-wave atomics on one word were the
+// bottleneck of the first version).  All path state is SoA in 16-byte records so a wave's loads are 1 KiB bursts; the state
+// loads of k_logic are issued together at the top, and the material / light / spectrum tables live in LDS.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 

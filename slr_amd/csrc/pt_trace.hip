@@ -4,9 +4,10 @@
 // (Core/SurfaceObject.cpp:408-416,267-269; Accelerator/QBVH.h:295-339), Triangle::intersect
 // (Surface/TriangleMesh.cpp:131-178) and Scene::testVisibility (SurfaceObject.cpp:418-430).
 //
-// Persistent workgroups (a fixed number per CU) stage the top of the tree — the first kTopNodes
-// breadth-first nodes — in LDS once, then each WAVE pulls 64-ray chunks from the ray queue with
-// one atomic.  One lane = one ray; per node four child slabs are tested from six 16-byte loads
+// The 64-ray-BATCH schedule (SLRHIP_FLAG_TRACE_BATCH; the default is the wave-specialised kernel of pt_trace_ws.hip, same
+// results): persistent workgroups (a fixed number per CU) stage the top of the tree — the first kTopNodes breadth-first
+// nodes — in LDS once, then stride over the slots (extension rays) or their region of the shadow queue, 64 rays per wave at a
+// time.  Also serves slrhip_trace_rays (k_trace_batch).  One lane = one ray; per node four child slabs are tested from six 16-byte loads
 // whose near/far selection (QBVH.h:66-71: invRayDir > 0 ? min : max) is folded into per-ray load
 // offsets.  The nearest hit child is descended into directly, the others go on a per-lane stack in
 // LDS ([entry][lane]: conflict-free) that spills to scratch beyond kLdsStack entries.
