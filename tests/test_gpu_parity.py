@@ -130,6 +130,19 @@ def test_ragged_sizes_against_oracle(oracle_rgb, size, spp, stripes):
         assert np.allclose(fb, want, rtol=2e-6, atol=1e-9)
 
 
+def test_large_image_against_oracle(oracle_rgb):
+    """3.1 M pixels x 4 spp (12.6 M samples, automatic stripes = 2): sample and ray counts exact, every pixel close."""
+    sc = scenes.cornell_box_spheres(4.0 / 3.0, 16, 8, "glass")
+    st = ob.settings(2048, 1536, seed=31)
+    want, ctr = oracle_rgb.scene(sc).render(st, 4)
+    c = Context()
+    fb = c.render_image(sc, st, 4)
+    k = c.counters()
+    c.close()
+    assert (int(k.samples), int(k.extension_rays), int(k.shadow_rays)) == (int(ctr.samples), int(ctr.extension_rays), int(ctr.shadow_rays))
+    assert np.allclose(fb, want, rtol=2e-6, atol=1e-9)
+
+
 def test_empty_shards_and_empty_renders(ctx):
     """More shards than tiles: the surplus shards own no pixel and must render (nothing) without error; zero passes is a no-op."""
     sc = scenes.tiny_box(1.0)
