@@ -118,7 +118,13 @@ enum {
     SLRHIP_MATERIAL_MICROFACET_METAL = 3,
     /* MicrofacetScattering MicrofacetSurfaceMaterial.cpp:23-28 -> MicrofacetBSDF(GGX, dielectric).
      * spectrum = {-, etaExt, etaInt}, param = alpha_g.                                */
-    SLRHIP_MATERIAL_MICROFACET_GLASS = 4
+    SLRHIP_MATERIAL_MICROFACET_GLASS = 4,
+    /* ModifiedWardDurReflection SurfaceMaterials/ModifiedWardDurReflection.cpp:14-19 -> ModifiedWardDurBRDF
+     * (BSDFs/ModifiedWardDurBRDF.cpp:11-87).  spectrum = {R, -, -}, param = anisoX, param2 = anisoY.        */
+    SLRHIP_MATERIAL_WARD = 5,
+    /* AshikhminShirleyReflection SurfaceMaterials/AshikhminShirleyReflection.cpp:14-20 -> AshikhminShirleyBRDF
+     * (BSDFs/AshikhminShirleyBRDF.cpp:12-170).  spectrum = {Rs, Rd, -}, param = nu, param2 = nv.            */
+    SLRHIP_MATERIAL_ASHIKHMIN = 6
 };
 typedef struct slrhip_material {
     uint32_t type;
@@ -127,6 +133,8 @@ typedef struct slrhip_material {
     /* EmitterSurfaceMaterial(mat, DiffuseEmission(emittance)) surface_material.h:55-69,
      * DiffuseEmission.cpp:15-21: index of the emittance spectrum, or -1 if not emitting. */
     int32_t emittance;
+    float param2;          /* second scalar of the anisotropic lobes (Ward anisoY, Ashikhmin nv), else 0 */
+    uint32_t reserved;
 } slrhip_material;
 
 /* ---- camera ---------------------------------------------------------------------- */

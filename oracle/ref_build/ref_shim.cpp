@@ -42,7 +42,9 @@
 #include "Core/distributions.h"
 #include "SurfaceMaterials/DiffuseEmission.h"
 #include "SurfaceMaterials/IBLEmission.h"
+#include "SurfaceMaterials/AshikhminShirleyReflection.h"
 #include "SurfaceMaterials/MicrofacetSurfaceMaterial.h"
+#include "SurfaceMaterials/ModifiedWardDurReflection.h"
 #include "SurfaceMaterials/basic_SurfaceMaterials.h"
 #include "Textures/constant_textures.h"
 
@@ -206,6 +208,18 @@ slr_oracle_scene* slr_ref_create(const slrhip_scene_desc* d, int mode) {
             FloatTexture* a = new ConstantFloatTexture(m.param); s->floatTextures.push_back(a);
             SVMicrofacetDistribution* dist = new SVGGX(a); s->mfDists.push_back(dist);
             base = new MicrofacetScattering(tex(m.spectrum[1]), tex(m.spectrum[2]), dist);
+            break;
+        }
+        case SLRHIP_MATERIAL_WARD: {
+            FloatTexture* ax = new ConstantFloatTexture(m.param); s->floatTextures.push_back(ax);
+            FloatTexture* ay = new ConstantFloatTexture(m.param2); s->floatTextures.push_back(ay);
+            base = new ModifiedWardDurReflection(tex(m.spectrum[0]), ax, ay);
+            break;
+        }
+        case SLRHIP_MATERIAL_ASHIKHMIN: {
+            FloatTexture* nu = new ConstantFloatTexture(m.param); s->floatTextures.push_back(nu);
+            FloatTexture* nv = new ConstantFloatTexture(m.param2); s->floatTextures.push_back(nv);
+            base = new AshikhminShirleyReflection(tex(m.spectrum[0]), tex(m.spectrum[1]), nu, nv);      // (Rs, Rd, nu, nv)
             break;
         }
         default:

@@ -791,7 +791,8 @@ struct BSDF {
     uint32_t kind;      // SLRHIP_MATERIAL_*
     uint32_t type;      // DirectionType of the lobe
     Spec<N> a, b, c;    // matte: a = R;  metal: a = coeffR, b = eta, c = k;  glass: a = coeff, b = etaExt, c = etaInt
-    float param;        // matte: sigma (< 0: Lambert);  microfacet: alpha_g
+    float param;        // matte: sigma (< 0: Lambert);  microfacet: alpha_g;  Ward: anisoX;  Ashikhmin: nu
+    float param2;       // Ward: anisoY;  Ashikhmin: nv
     float onA, onB;     // Oren-Nayar m_A, m_B (OrenNayerBRDF.h:28-30)
 };
 
@@ -932,6 +933,41 @@ inline float fresnelDielectric1(const Spec<N>& etaExt, const Spec<N>& etaInt, fl
     return fresnelEvalF(eEnter, eExit, cosEnter, cosExit);
 }
 
+// ---- ModifiedWardDurBRDF (BSDFs/ModifiedWardDurBRDF.cpp:11-87): a = R, param = anisoX, param2 = anisoY ------------------------
+template <int N>
+inline float wardTerms(const BSDF<N>& f, V3 halfv, V3 dirL, float* dotHI, float* dotHN) {
+    float hx_ax = halfv.x / f.param;
+    float hy_ay = halfv.y / f.param2;
+    *dotHN = std::fabs(halfv.z);
+    *dotHI = dot(halfv, dirL);
+    return std::exp(-(hx_ax * hx_ax + hy_ay * hy_ay) / (*dotHN * *dotHN));      // the numerator
+}
+// ---- AshikhminShirleyBRDF (BSDFs/AshikhminShirleyBRDF.cpp:12-170): a = Rs, b = Rd, param = nu, param2 = nv ----------------------
+// std::pow(float, int) promotes to double (C++11), so the Schlick / Fresnel-like terms are evaluated in double
+template <int N>
+inline void ashikhminWeights(const BSDF<N>& f, int16_t wlHint, float absCos, float* specularWeight, float* diffuseWeight) {
+    float iRs = importance(f.a, wlHint);
+    float iRd = importance(f.b, wlHint);
+    *specularWeight = (float)(iRs + (1 - iRs) * std::pow(1.0f - absCos, 5));
+    float transmissionTerm = (float)(1 - std::pow(1 - absCos * 0.5f, 5));
+    *diffuseWeight = 28 * iRd / 23 * (1 - iRs) * transmissionTerm * transmissionTerm;
+}
+// commonTerm = specular direction PDF (:41-43,:116-118,:138-140)
+template <int N>
+inline float ashikhminCommon(const BSDF<N>& f, V3 halfv, float dotHV) {
+    float exp = (f.param * halfv.x * halfv.x + f.param2 * halfv.y * halfv.y) / (1 - halfv.z * halfv.z);
+    return (float)(std::sqrt((f.param + 1) * (f.param2 + 1)) / (8 * M_PI * dotHV) * std::pow(std::fabs(halfv.z), exp));
+}
+template <int N>
+inline Spec<N> ashikhminFs(const BSDF<N>& f, float commonTerm, float dotHV, float zQuery, float zDir) {
+    Spec<N> F = f.a + (Spec<N>(1.0f) - f.a) * (float)std::pow(1.0f - dotHV, 5);
+    Spec<N> specular_fs = commonTerm / std::fmax(std::fabs(zQuery), std::fabs(zDir)) * F;
+    Spec<N> diffuse_fs = (28 * f.b / (float)(23 * M_PI) * (Spec<N>(1.0f) - f.a) *
+                          (float)(1.0f - std::pow(1.0f - std::fabs(zQuery) / 2, 5)) *
+                          (float)(1.0f - std::pow(1.0f - std::fabs(zDir) / 2, 5)));
+    return specular_fs + diffuse_fs;
+}
+
 // sampleInternal of each lobe.  Returns fs_sn; result->dirPDF == 0 signals failure.
 template <int N>
 Spec<N> bsdfSampleInternal(const BSDF<N>& f, const BSDFQuery<N>& q, float uComponent, const float uDir[2], BSDFResult* result) {
@@ -952,6 +988,60 @@ Spec<N> bsdfSampleInternal(const BSDF<N>& f, const BSDFQuery<N>& q, float uCompo
         result->dirType = f.type;
         result->dir_sn.z *= dot(q.dir_sn, q.gNormal_sn) > 0 ? 1 : -1;
         return f.a / (float)M_PI;
+    }
+    case SLRHIP_MATERIAL_WARD: {
+        // ModifiedWardDurBRDF.cpp:11-40
+        float quad = (float)(2 * M_PI * uDir[1]);
+        float phi_h = std::atan2(f.param2 * std::sin(quad), f.param * std::cos(quad));
+        float cosphi_ax = std::cos(phi_h) / f.param;
+        float sinphi_ay = std::sin(phi_h) / f.param2;
+        float theta_h = std::atan(std::sqrt(-std::log(1 - uDir[0]) / (cosphi_ax * cosphi_ax + sinphi_ay * sinphi_ay)));
+        V3 halfv(std::sin(theta_h) * std::cos(phi_h), std::sin(theta_h) * std::sin(phi_h), std::cos(theta_h));
+        halfv.z *= q.dir_sn.z > 0 ? 1 : -1;
+        result->dir_sn = 2 * dot(q.dir_sn, halfv) * halfv - q.dir_sn;
+        if (result->dir_sn.z * q.dir_sn.z <= 0) { result->dirPDF = 0.0f; return Spec<N>(); }
+        float dotHI, dotHN;
+        float numerator = wardTerms(f, halfv, result->dir_sn, &dotHI, &dotHN);
+        float commonDenom = (float)(4 * M_PI * f.param * f.param2 * dotHI * dotHN * dotHN * dotHN);
+        result->dirPDF = numerator / commonDenom;
+        result->dirType = f.type;
+        return f.a * (numerator / (commonDenom * dotHI * dotHN));
+    }
+    case SLRHIP_MATERIAL_ASHIKHMIN: {
+        // AshikhminShirleyBRDF.cpp:12-92
+        float specularWeight, diffuseWeight;
+        ashikhminWeights(f, q.wlHint, std::fabs(q.dir_sn.z), &specularWeight, &diffuseWeight);
+        float sumWeights = specularWeight + diffuseWeight;
+        float specularDirPDF, diffuseDirPDF;
+        Spec<N> fs;
+        if (uComponent * sumWeights < specularWeight) {
+            result->dirType = DT_Reflection | DT_HighFreq;
+            float quad = (float)(2 * M_PI * uDir[1]);
+            float phi_h = std::atan2(std::sqrt(f.param + 1) * std::sin(quad), std::sqrt(f.param2 + 1) * std::cos(quad));
+            float cosphi = std::cos(phi_h);
+            float sinphi = std::sin(phi_h);
+            float theta_h = std::acos(std::pow(1 - uDir[0], 1.0f / (f.param * cosphi * cosphi + f.param2 * sinphi * sinphi + 1)));
+            if (q.dir_sn.z < 0) theta_h = (float)(M_PI - theta_h);
+            V3 halfv(std::sin(theta_h) * std::cos(phi_h), std::sin(theta_h) * std::sin(phi_h), std::cos(theta_h));
+            result->dir_sn = 2 * dot(q.dir_sn, halfv) * halfv - q.dir_sn;
+            if (result->dir_sn.z * q.dir_sn.z <= 0) { result->dirPDF = 0.0f; return Spec<N>(); }
+            float dotHV = dot(halfv, q.dir_sn);
+            specularDirPDF = ashikhminCommon(f, halfv, dotHV);
+            diffuseDirPDF = (float)(std::fabs(result->dir_sn.z) / M_PI);
+            fs = ashikhminFs(f, specularDirPDF, dotHV, q.dir_sn.z, result->dir_sn.z);
+        }
+        else {
+            result->dirType = DT_Reflection | DT_LowFreq;
+            result->dir_sn = cosineSampleHemisphere(uDir[0], uDir[1]);
+            diffuseDirPDF = (float)(result->dir_sn.z / M_PI);
+            result->dir_sn.z *= dot(q.dir_sn, q.gNormal_sn) > 0 ? 1 : -1;
+            V3 halfv = normalize(q.dir_sn + result->dir_sn);
+            float dotHV = dot(halfv, q.dir_sn);
+            specularDirPDF = ashikhminCommon(f, halfv, dotHV);
+            fs = ashikhminFs(f, specularDirPDF, dotHV, q.dir_sn.z, result->dir_sn.z);
+        }
+        result->dirPDF = (specularDirPDF * specularWeight + diffuseDirPDF * diffuseWeight) / sumWeights;
+        return fs;
     }
     case SLRHIP_MATERIAL_METAL: {
         // basic_BSDFs.cpp:61-71  SpecularBRDF::sampleInternal
@@ -1088,6 +1178,24 @@ Spec<N> bsdfEvaluate(const BSDF<N>& f, const BSDFQuery<N>& q, V3 dir) {
         else if (f.param >= 0.0f) fs_sn = orenNayar(f, dir, q.dir_sn, false);
         else fs_sn = f.a / (float)M_PI;
         break;
+    case SLRHIP_MATERIAL_WARD: {
+        // ModifiedWardDurBRDF.cpp:42-59
+        if (dir.z * q.dir_sn.z <= 0) { fs_sn = Spec<N>(); break; }
+        V3 halfv = normalize(q.dir_sn + dir);
+        float dotHI, dotHN;
+        float numerator = wardTerms(f, halfv, dir, &dotHI, &dotHN);
+        float denominator = (float)(4 * M_PI * f.param * f.param2 * dotHI * dotHI * dotHN * dotHN * dotHN * dotHN);
+        fs_sn = f.a * numerator / denominator;
+        break;
+    }
+    case SLRHIP_MATERIAL_ASHIKHMIN: {
+        // AshikhminShirleyBRDF.cpp:94-113
+        if (dir.z * q.dir_sn.z <= 0) { fs_sn = Spec<N>(); break; }
+        V3 halfv = normalize(q.dir_sn + dir);
+        float dotHV = dot(halfv, q.dir_sn);
+        fs_sn = ashikhminFs(f, ashikhminCommon(f, halfv, dotHV), dotHV, q.dir_sn.z, dir.z);
+        break;
+    }
     case SLRHIP_MATERIAL_MICROFACET_METAL: {
         // MicrofacetBSDF.cpp:47-71  MicrofacetBRDF::evaluateInternal
         if (dir.z * q.dir_sn.z <= 0) { fs_sn = Spec<N>(); break; }
@@ -1154,6 +1262,27 @@ float bsdfEvaluatePDF(const BSDF<N>& f, const BSDFQuery<N>& q, V3 dir) {
         // basic_BSDFs.cpp:41-50, OrenNayerBRDF.cpp:58-66 (identical)
         if (q.dir_sn.z * dir.z <= 0.0f) return 0.0f;
         return (float)((double)std::abs(dir.z) / M_PI);
+    case SLRHIP_MATERIAL_WARD: {
+        // ModifiedWardDurBRDF.cpp:61-77
+        if (dir.z * q.dir_sn.z <= 0) return 0.0f;
+        V3 halfv = normalize(q.dir_sn + dir);
+        float dotHI, dotHN;
+        float numerator = wardTerms(f, halfv, dir, &dotHI, &dotHN);
+        float denominator = (float)(4 * M_PI * f.param * f.param2 * dotHI * dotHN * dotHN * dotHN);
+        return numerator / denominator;
+    }
+    case SLRHIP_MATERIAL_ASHIKHMIN: {
+        // AshikhminShirleyBRDF.cpp:115-153
+        if (dir.z * q.dir_sn.z <= 0) return 0.0f;
+        V3 halfv = normalize(q.dir_sn + dir);
+        float dotHV = dot(halfv, q.dir_sn);
+        float specularDirPDF = ashikhminCommon(f, halfv, dotHV);
+        float diffuseDirPDF = (float)(std::fabs(dir.z) / M_PI);
+        float specularWeight, diffuseWeight;
+        ashikhminWeights(f, q.wlHint, std::fabs(q.dir_sn.z), &specularWeight, &diffuseWeight);
+        float sumWeights = specularWeight + diffuseWeight;
+        return (specularDirPDF * specularWeight + diffuseDirPDF * diffuseWeight) / sumWeights;
+    }
     case SLRHIP_MATERIAL_MICROFACET_METAL: {
         // MicrofacetBSDF.cpp:73-100
         if (dir.z * q.dir_sn.z <= 0) return 0.0f;
@@ -1209,8 +1338,18 @@ BSDF<N> createBSDF(const Scene& s, const SurfPt& sp, const Wls<N>& wls) {
     BSDF<N> f;
     f.kind = m.type;
     f.param = m.param;
+    f.param2 = m.param2;
     f.onA = f.onB = 0.0f;
     switch (m.type) {
+    case SLRHIP_MATERIAL_WARD:
+        f.type = DT_Reflection | DT_HighFreq;                                  // ModifiedWardDurBRDF.h:29
+        f.a = 1.0f * EvalSpectrum<N>::eval(s, m.spectrum[0], wls);
+        break;
+    case SLRHIP_MATERIAL_ASHIKHMIN:
+        f.type = DT_Reflection | DT_HighFreq | DT_LowFreq;                     // AshikhminShirleyBRDF.h:29
+        f.a = 1.0f * EvalSpectrum<N>::eval(s, m.spectrum[0], wls);             // scale * Rs
+        f.b = 1.0f * EvalSpectrum<N>::eval(s, m.spectrum[1], wls);             // scale * Rd
+        break;
     case SLRHIP_MATERIAL_MATTE:
         f.type = DT_Reflection | DT_LowFreq;                                   // basic_BSDFs.h:27, OrenNayerBRDF.h:29
         f.a = 1.0f * EvalSpectrum<N>::eval(s, m.spectrum[0], wls);

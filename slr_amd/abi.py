@@ -14,14 +14,14 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 MODE_RGB, MODE_SPECTRAL = 0, 1
-MAT_MATTE, MAT_METAL, MAT_GLASS, MAT_MF_METAL, MAT_MF_GLASS = 0, 1, 2, 3, 4
+MAT_MATTE, MAT_METAL, MAT_GLASS, MAT_MF_METAL, MAT_MF_GLASS, MAT_WARD, MAT_ASHIKHMIN = 0, 1, 2, 3, 4, 5, 6
 SPEC_RGB_ONLY, SPEC_UPSAMPLED, SPEC_REGULAR, SPEC_IRREGULAR = 0, 1, 2, 3
 
 # numpy dtypes with the exact layout of the C structs (checked in tests/test_abi.py)
 vertex_dtype = np.dtype([("position", "<f4", 3), ("normal", "<f4", 3), ("tangent", "<f4", 3),
                          ("texcoord", "<f4", 2)])
 triangle_dtype = np.dtype([("v", "<u4", 3), ("material", "<u4")])
-material_dtype = np.dtype([("type", "<u4"), ("spectrum", "<i4", 3), ("param", "<f4"), ("emittance", "<i4")])
+material_dtype = np.dtype([("type", "<u4"), ("spectrum", "<i4", 3), ("param", "<f4"), ("emittance", "<i4"), ("param2", "<f4"), ("reserved", "<u4")])
 spectrum_dtype = np.dtype([("kind", "<u4"), ("rgb", "<f4", 3), ("u", "<f4"), ("v", "<f4"), ("scale", "<f4"),
                            ("lambda_min", "<f4"), ("lambda_max", "<f4"), ("num_samples", "<u4"),
                            ("data_offset", "<u4"), ("reserved", "<u4")])
@@ -91,7 +91,13 @@ class Scene:
     def __init__(self, vertices, triangles, materials, spectra, spectrum_data, camera, env=None, name="scene"):
         self.vertices = np.ascontiguousarray(vertices, dtype=vertex_dtype)
         self.triangles = np.ascontiguousarray(triangles, dtype=triangle_dtype)
-        self.materials = np.ascontiguousarray(materials, dtype=material_dtype)
+        mats = np.asarray(materials)
+        if mats.dtype != material_dtype:           # e.g. fixtures written before param2 existed: copy the common fields
+            conv = np.zeros(len(mats), dtype=material_dtype)
+            for name in mats.dtype.names:
+                conv[name] = mats[name]
+            mats = conv
+        self.materials = np.ascontiguousarray(mats, dtype=material_dtype)
         self.spectra = np.ascontiguousarray(spectra, dtype=spectrum_dtype)
         self.spectrum_data = np.ascontiguousarray(spectrum_data, dtype=np.float32)
         self.camera = camera

@@ -47,8 +47,8 @@ void Scene::setEnvironment(const float* texels, uint32_t width, uint32_t height,
     m_env.map_width = mapWidth; m_env.map_height = mapHeight;
     m_hasEnv = true;
 }
-uint32_t Scene::addMaterial(uint32_t type, int32_t s0, int32_t s1, int32_t s2, float param, int32_t emittance) {
-    slrhip_material m = {type, {s0, s1, s2}, param, emittance};
+uint32_t Scene::addMaterial(uint32_t type, int32_t s0, int32_t s1, int32_t s2, float param, int32_t emittance, float param2) {
+    slrhip_material m = {type, {s0, s1, s2}, param, emittance, param2, 0u};
     m_materials.push_back(m);
     return (uint32_t)m_materials.size() - 1;
 }

@@ -56,7 +56,7 @@ public:
     // `scale` of IBLEmission, and the quarter-resolution luminance map ImageSpectrumTexture::createIBLImportanceMap would build.
     void setEnvironment(const float* texels, uint32_t width, uint32_t height, float scale, const float* importance, uint32_t mapWidth,
                         uint32_t mapHeight);
-    uint32_t addMaterial(uint32_t type, int32_t s0, int32_t s1, int32_t s2, float param, int32_t emittance);
+    uint32_t addMaterial(uint32_t type, int32_t s0, int32_t s1, int32_t s2, float param, int32_t emittance, float param2 = 0.0f);
     void setCamera(const slrhip_camera& camera) { m_camera = camera; }
     const slrhip_camera& camera() const { return m_camera; }
     slrhip_scene_desc desc() const;

@@ -257,6 +257,40 @@ SLR_DEV float mfTransmissionWl(const GGX& D_, const Mat<S>& m, const S& eEnter, 
     return (float)((double)(fabsf(dotHV_wl * dotHL_wl) * (1 - F_wl) * G_wl * D_wl) / (den * den));
 }
 
+// ---- ModifiedWardDurBRDF (BSDFs/ModifiedWardDurBRDF.cpp:11-87): a = R, param = anisoX, onA = anisoY (the material's param2) ----
+// ---- AshikhminShirleyBRDF (BSDFs/AshikhminShirleyBRDF.cpp:12-170): a = Rs, b = Rd, param = nu, onA = nv ---------------------------
+// Both are float-libm lobes (exp, log, atan, atan2, acos, pow); std::pow(float, int) in the reference promotes to double.
+SLR_DEV double pow5d(float x) { return pow((double)x, 5.0); }
+template <class S>
+SLR_DEV float wardNumerator(const Mat<S>& m, V3 halfv, V3 dirL, float* dotHI, float* dotHN) {
+    float hx_ax = halfv.x / m.param;
+    float hy_ay = halfv.y / m.onA;
+    *dotHN = fabsf(halfv.z);
+    *dotHI = dot(halfv, dirL);
+    return expf(-(hx_ax * hx_ax + hy_ay * hy_ay) / (*dotHN * *dotHN));
+}
+template <class S>
+SLR_DEV void ashikhminWeights(const Mat<S>& m, uint32_t wl, float absCos, float* specularWeight, float* diffuseWeight) {
+    float iRs = importance(m.a, wl);
+    float iRd = importance(m.b, wl);
+    *specularWeight = (float)((double)iRs + (double)(1 - iRs) * pow5d(1.0f - absCos));
+    float transmissionTerm = (float)(1.0 - pow5d(1 - absCos * 0.5f));
+    *diffuseWeight = 28 * iRd / 23 * (1 - iRs) * transmissionTerm * transmissionTerm;
+}
+template <class S>
+SLR_DEV float ashikhminCommon(const Mat<S>& m, V3 halfv, float dotHV) {
+    float e = (m.param * halfv.x * halfv.x + m.onA * halfv.y * halfv.y) / (1 - halfv.z * halfv.z);
+    return (float)((double)sqrtf((m.param + 1) * (m.onA + 1)) / (8 * kPi * (double)dotHV) * (double)powf(fabsf(halfv.z), e));
+}
+template <class S>
+SLR_DEV S ashikhminFs(const Mat<S>& m, float commonTerm, float dotHV, float zQuery, float zDir) {
+    S F = m.a + (S(1.0f) - m.a) * (float)pow5d(1.0f - dotHV);
+    S specular_fs = (commonTerm / fmaxf(fabsf(zQuery), fabsf(zDir))) * F;
+    S diffuse_fs = (28.0f * m.b) / (float)(23 * kPi) * (S(1.0f) - m.a) * (float)(1.0 - pow5d(1.0f - fabsf(zQuery) / 2)) *
+                   (float)(1.0 - pow5d(1.0f - fabsf(zDir) / 2));
+    return specular_fs + diffuse_fs;
+}
+
 struct BsdfSample {
     V3 dir_sn;
     float dirPDF;
@@ -272,6 +306,8 @@ SLR_DEV uint32_t bsdfType(uint32_t matType, uint32_t wlFlags) {
     case SLRHIP_MATERIAL_GLASS: return DT_Reflection | DT_Transmission | DT_Delta0D | ((wlFlags & 1u) ? 0u : (uint32_t)DT_Dispersive);
     case SLRHIP_MATERIAL_MICROFACET_METAL: return DT_Reflection | DT_HighFreq;                     // MicrofacetBSDF.h:27-28
     case SLRHIP_MATERIAL_MICROFACET_GLASS: return DT_Reflection | DT_Transmission | DT_HighFreq;   // MicrofacetBSDF.h:44-46
+    case SLRHIP_MATERIAL_WARD: return DT_Reflection | DT_HighFreq;                                 // ModifiedWardDurBRDF.h:29
+    case SLRHIP_MATERIAL_ASHIKHMIN: return DT_Reflection | DT_HighFreq | DT_LowFreq;               // AshikhminShirleyBRDF.h:29
     default: return 0;
     }
 }
@@ -292,6 +328,62 @@ SLR_DEV S bsdfSample(const Mat<S>& m, uint32_t type, V3 dirOut, V3 gNorm, uint32
         res->dirType = type;
         res->dir_sn.z *= dot(dirOut, gNorm) > 0 ? 1 : -1;
         fs_sn = m.param >= 0.0f ? orenNayar(m, res->dir_sn, dirOut, true) : m.a / (float)kPi;
+        break;
+    }
+    case SLRHIP_MATERIAL_WARD: {
+        if (!MF) return S();
+        // ModifiedWardDurBRDF::sampleInternal :11-40
+        float quad = (float)(2 * kPi * (double)u1);
+        float phi_h = atan2f(m.onA * sinf(quad), m.param * cosf(quad));
+        float cosphi_ax = cosf(phi_h) / m.param;
+        float sinphi_ay = sinf(phi_h) / m.onA;
+        float theta_h = atanf(sqrtf(-logf(1 - u0) / (cosphi_ax * cosphi_ax + sinphi_ay * sinphi_ay)));
+        V3 halfv(sinf(theta_h) * cosf(phi_h), sinf(theta_h) * sinf(phi_h), cosf(theta_h));
+        halfv.z *= dirOut.z > 0 ? 1 : -1;
+        res->dir_sn = (2 * dot(dirOut, halfv)) * halfv - dirOut;
+        if (res->dir_sn.z * dirOut.z <= 0) { res->dirPDF = 0.0f; return S(); }
+        float dotHI, dotHN;
+        float numerator = wardNumerator(m, halfv, res->dir_sn, &dotHI, &dotHN);
+        float commonDenom = (float)(4 * kPi * (double)m.param * (double)m.onA * (double)dotHI * (double)dotHN * (double)dotHN * (double)dotHN);
+        res->dirPDF = numerator / commonDenom;
+        res->dirType = type;
+        fs_sn = m.a * (numerator / (commonDenom * dotHI * dotHN));
+        break;
+    }
+    case SLRHIP_MATERIAL_ASHIKHMIN: {
+        if (!MF) return S();
+        // AshikhminShirleyBRDF::sampleInternal :12-92
+        float specularWeight, diffuseWeight;
+        ashikhminWeights(m, wl, fabsf(dirOut.z), &specularWeight, &diffuseWeight);
+        float sumWeights = specularWeight + diffuseWeight;
+        float specularDirPDF, diffuseDirPDF;
+        if (uComp * sumWeights < specularWeight) {
+            res->dirType = DT_Reflection | DT_HighFreq;
+            float quad = (float)(2 * kPi * (double)u1);
+            float phi_h = atan2f(sqrtf(m.param + 1) * sinf(quad), sqrtf(m.onA + 1) * cosf(quad));
+            float cosphi = cosf(phi_h);
+            float sinphi = sinf(phi_h);
+            float theta_h = acosf(powf(1 - u0, 1.0f / (m.param * cosphi * cosphi + m.onA * sinphi * sinphi + 1)));
+            if (dirOut.z < 0) theta_h = (float)(kPi - (double)theta_h);
+            V3 halfv(sinf(theta_h) * cosf(phi_h), sinf(theta_h) * sinf(phi_h), cosf(theta_h));
+            res->dir_sn = (2 * dot(dirOut, halfv)) * halfv - dirOut;
+            if (res->dir_sn.z * dirOut.z <= 0) { res->dirPDF = 0.0f; return S(); }
+            float dotHV = dot(halfv, dirOut);
+            specularDirPDF = ashikhminCommon(m, halfv, dotHV);
+            diffuseDirPDF = (float)((double)fabsf(res->dir_sn.z) / kPi);
+            fs_sn = ashikhminFs(m, specularDirPDF, dotHV, dirOut.z, res->dir_sn.z);
+        }
+        else {
+            res->dirType = DT_Reflection | DT_LowFreq;
+            res->dir_sn = cosineSampleHemisphere(u0, u1);
+            diffuseDirPDF = (float)((double)res->dir_sn.z / kPi);
+            res->dir_sn.z *= dot(dirOut, gNorm) > 0 ? 1 : -1;
+            V3 halfv = normalize(dirOut + res->dir_sn);
+            float dotHV = dot(halfv, dirOut);
+            specularDirPDF = ashikhminCommon(m, halfv, dotHV);
+            fs_sn = ashikhminFs(m, specularDirPDF, dotHV, dirOut.z, res->dir_sn.z);
+        }
+        res->dirPDF = (specularDirPDF * specularWeight + diffuseDirPDF * diffuseWeight) / sumWeights;
         break;
     }
     case SLRHIP_MATERIAL_MICROFACET_METAL: {
@@ -413,6 +505,28 @@ SLR_DEV float bsdfEvaluatePDF(const Mat<S>& m, uint32_t type, V3 dirOut, V3 dir,
         // LambertianBRDF::evaluatePDFInternal basic_BSDFs.cpp:41-50 == OrenNayerBRDF.cpp:58-66
         if (dirOut.z * dir.z <= 0.0f) return 0.0f;
         return (float)((double)fabsf(dir.z) / kPi);
+    case SLRHIP_MATERIAL_WARD: {
+        if (!MF) return 0.0f;
+        // ModifiedWardDurBRDF::evaluatePDFInternal :61-77
+        if (dir.z * dirOut.z <= 0) return 0.0f;
+        V3 halfv = normalize(dirOut + dir);
+        float dotHI, dotHN;
+        float numerator = wardNumerator(m, halfv, dir, &dotHI, &dotHN);
+        float denominator = (float)(4 * kPi * (double)m.param * (double)m.onA * (double)dotHI * (double)dotHN * (double)dotHN * (double)dotHN);
+        return numerator / denominator;
+    }
+    case SLRHIP_MATERIAL_ASHIKHMIN: {
+        if (!MF) return 0.0f;
+        // AshikhminShirleyBRDF::evaluatePDFInternal :115-153
+        if (dir.z * dirOut.z <= 0) return 0.0f;
+        V3 halfv = normalize(dirOut + dir);
+        float dotHV = dot(halfv, dirOut);
+        float specularDirPDF = ashikhminCommon(m, halfv, dotHV);
+        float diffuseDirPDF = (float)((double)fabsf(dir.z) / kPi);
+        float specularWeight, diffuseWeight;
+        ashikhminWeights(m, wl, fabsf(dirOut.z), &specularWeight, &diffuseWeight);
+        return (specularDirPDF * specularWeight + diffuseDirPDF * diffuseWeight) / (specularWeight + diffuseWeight);
+    }
     case SLRHIP_MATERIAL_MICROFACET_METAL: {
         if (!MF) return 0.0f;
         // MicrofacetBSDF.cpp:73-100
@@ -472,6 +586,27 @@ SLR_DEV S bsdfEvaluate(const Mat<S>& m, uint32_t type, V3 dirOut, V3 gNorm, V3 d
         else if (m.param >= 0.0f) fs_sn = orenNayar(m, dir, dirOut, false);
         else fs_sn = m.a / (float)kPi;
         break;
+    case SLRHIP_MATERIAL_WARD: {
+        if (!MF) break;
+        // ModifiedWardDurBRDF::evaluateInternal :42-59
+        if (dir.z * dirOut.z <= 0) break;
+        V3 halfv = normalize(dirOut + dir);
+        float dotHI, dotHN;
+        float numerator = wardNumerator(m, halfv, dir, &dotHI, &dotHN);
+        float denominator = (float)(4 * kPi * (double)m.param * (double)m.onA * (double)dotHI * (double)dotHI * (double)dotHN * (double)dotHN *
+                                    (double)dotHN * (double)dotHN);
+        fs_sn = m.a * numerator / denominator;
+        break;
+    }
+    case SLRHIP_MATERIAL_ASHIKHMIN: {
+        if (!MF) break;
+        // AshikhminShirleyBRDF::evaluateInternal :94-113
+        if (dir.z * dirOut.z <= 0) break;
+        V3 halfv = normalize(dirOut + dir);
+        float dotHV = dot(halfv, dirOut);
+        fs_sn = ashikhminFs(m, ashikhminCommon(m, halfv, dotHV), dotHV, dirOut.z, dir.z);
+        break;
+    }
     case SLRHIP_MATERIAL_MICROFACET_METAL: {
         if (!MF) break;
         // MicrofacetBRDF::evaluateInternal MicrofacetBSDF.cpp:47-71

@@ -233,8 +233,13 @@ int slrhip_upload_scene(slrhip_ctx* ctx, const slrhip_scene_desc* d) {
         std::memset(&dm, 0, sizeof(dm));
         dm.type = m.type;
         dm.param = m.param;
-        if (m.type > SLRHIP_MATERIAL_MICROFACET_GLASS)
+        if (m.type > SLRHIP_MATERIAL_ASHIKHMIN)
             return fail(SLRHIP_ERR_UNSUPPORTED, "slrhip_upload_scene: unknown material type");
+        if (m.type == SLRHIP_MATERIAL_WARD || m.type == SLRHIP_MATERIAL_ASHIKHMIN) {
+            dm.onA = m.param2;          // the lobe's second scalar travels in the Oren-Nayar slot (unused by these types)
+            if (!(m.param > 0.0f) || !(m.param2 > 0.0f))
+                return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: Ward / Ashikhmin need param > 0 and param2 > 0");
+        }
         if (m.type == SLRHIP_MATERIAL_MATTE && m.param >= 0.0f) {
             // OrenNayerBRDF ctor, OrenNayerBRDF.h:28-30: double literals in a float expression
             const float sigma = m.param;
@@ -254,7 +259,11 @@ int slrhip_upload_scene(slrhip_ctx* ctx, const slrhip_scene_desc* d) {
             return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: spectrum index out of range");
         if (m.spectrum[0] < 0 && m.type <= SLRHIP_MATERIAL_GLASS)
             return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: material without its first spectrum");
-        if (m.type >= SLRHIP_MATERIAL_METAL && (m.spectrum[1] < 0 || m.spectrum[2] < 0))
+        if (m.type == SLRHIP_MATERIAL_ASHIKHMIN && (m.spectrum[0] < 0 || m.spectrum[1] < 0))
+            return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: Ashikhmin needs Rs and Rd");
+        if (m.type == SLRHIP_MATERIAL_WARD && m.spectrum[0] < 0)
+            return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: Ward needs R");
+        if (m.type >= SLRHIP_MATERIAL_METAL && m.type <= SLRHIP_MATERIAL_MICROFACET_GLASS && (m.spectrum[1] < 0 || m.spectrum[2] < 0))
             return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: material without its eta / k spectra");
         emitting[i] = m.emittance >= 0;
         mats[i] = dm;
@@ -457,7 +466,7 @@ int slrhip_upload_scene(slrhip_ctx* ctx, const slrhip_scene_desc* d) {
     sc.numLights = (uint32_t)lights.size();
     sc.hasMicrofacet = 0;
     for (const DevMaterial& dm : mats)
-        if (dm.type == SLRHIP_MATERIAL_MICROFACET_METAL || dm.type == SLRHIP_MATERIAL_MICROFACET_GLASS) sc.hasMicrofacet = 1;
+        if (dm.type >= SLRHIP_MATERIAL_MICROFACET_METAL) sc.hasMicrofacet = 1;     // GGX, Ward, Ashikhmin: the kernels with the glossy-lobe code
     sc.lightPow2 = prevPowerOf2(sc.numLights);
     sc.hasEnv = d->env ? 1u : 0u;
     sc.aggImportance = lightIntegral;

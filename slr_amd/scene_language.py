@@ -8,11 +8,11 @@ unassigned parameter of a convertible type; overloads are tried in order: SceneP
 construct a flat `slr_amd.abi.Scene` through `scenes.SceneBuilder` instead of libSLR objects.
 
 What loads: createMesh / createVertex geometry, node hierarchy with static transforms, constant Spectrum / texture
-values, matte / metal / glass / microfacet materials, diffuse emitters, the perspective camera, setRenderer,
+values, matte / metal / glass / microfacet / Ward / Ashikhmin materials, diffuse emitters, the perspective camera, setRenderer,
 setRenderSettings — i.e. the walls, lights, cameras and materials of TestScenes/Cornell_Box_*.txt.  What the image
 lacks (no assimp / OpenEXR, no asset files in the reference tree): load3DModel accepts only the two primitive models
 the test scenes use ("…/sphere.assbin", "…/box.assbin") and substitutes this package's tessellated unit sphere / cube;
-Image2D textures, setEnvironment images, Ward / Ashikhmin lobes and the scan* helpers raise UnsupportedFeature.
+Image2D textures, setEnvironment images, "sum" / "mix" / "inverse" materials and the scan* helpers raise UnsupportedFeature.
 """
 import math
 import re
@@ -609,6 +609,8 @@ class Interpreter:
             "glass": [("coeff", SpectrumTex, D), ("etaExt", SpectrumTex, D), ("etaInt", SpectrumTex, D)],
             "microfacet metal": [("eta", SpectrumTex, D), ("k", SpectrumTex, D), ("alpha_g", FloatTex, D)],
             "microfacet glass": [("etaExt", SpectrumTex, D), ("etaInt", SpectrumTex, D), ("alpha_g", FloatTex, D)],
+            "Ward": [("R", SpectrumTex, D), ("anisoX", FloatTex, D), ("anisoY", FloatTex, D)],
+            "Ashikhmin": [("Rd", SpectrumTex, D), ("Rs", SpectrumTex, D), ("nx", FloatTex, D), ("ny", FloatTex, D)],
             "emitter": [("scatter", Material, D), ("emitter", Emitter, D)],
         }
         kind = a["type"]
@@ -679,6 +681,10 @@ class Interpreter:
                     idx = b.metal(spectrum(p["coeffR"].spectrum), spectrum(p["eta"].spectrum), spectrum(p["k"].spectrum))
                 elif m.kind == "glass":
                     idx = b.glass(spectrum(p["coeff"].spectrum), spectrum(p["etaExt"].spectrum), spectrum(p["etaInt"].spectrum))
+                elif m.kind == "Ward":
+                    idx = b.ward(spectrum(p["R"].spectrum), p["anisoX"].value, p["anisoY"].value)
+                elif m.kind == "Ashikhmin":
+                    idx = b.ashikhmin(spectrum(p["Rd"].spectrum), spectrum(p["Rs"].spectrum), p["nx"].value, p["ny"].value)
                 elif m.kind == "microfacet metal":
                     idx = b.microfacet_metal(spectrum(p["eta"].spectrum), spectrum(p["k"].spectrum), p["alpha_g"].value)
                 else:

@@ -83,9 +83,9 @@ class SceneBuilder:
         return self.sset.ior(name, which, rgb)
 
     # --- materials -----------------------------------------------------------------
-    def material(self, mtype, spectra=(-1, -1, -1), param=-1.0, emittance=-1):
+    def material(self, mtype, spectra=(-1, -1, -1), param=-1.0, emittance=-1, param2=0.0):
         rec = np.zeros((), dtype=abi.material_dtype)
-        rec["type"], rec["spectrum"], rec["param"], rec["emittance"] = mtype, spectra, param, emittance
+        rec["type"], rec["spectrum"], rec["param"], rec["emittance"], rec["param2"] = mtype, spectra, param, emittance, param2
         self.materials.append(rec)
         return len(self.materials) - 1
 
@@ -97,6 +97,14 @@ class SceneBuilder:
 
     def glass(self, coeff, eta_ext, eta_int):
         return self.material(abi.MAT_GLASS, (coeff, eta_ext, eta_int))
+
+    def ward(self, refl, aniso_x, aniso_y):
+        """createSurfaceMaterial("Ward", (R, anisoX, anisoY)) -> ModifiedWardDurBRDF (API.cpp:522-535)."""
+        return self.material(abi.MAT_WARD, (refl, -1, -1), aniso_x, param2=aniso_y)
+
+    def ashikhmin(self, rd, rs, nu, nv):
+        """createSurfaceMaterial("Ashikhmin", (Rd, Rs, nx, ny)) -> AshikhminShirleyBRDF(Rs, Rd, nu, nv) (API.cpp:537-552)."""
+        return self.material(abi.MAT_ASHIKHMIN, (rs, rd, -1), nu, param2=nv)
 
     def microfacet_metal(self, eta, k, alpha):
         return self.material(abi.MAT_MF_METAL, (-1, eta, k), alpha)
@@ -232,7 +240,7 @@ TITANIUM_K_RGB = (3.8143, 3.4345, 3.0235)
 
 
 def cornell_lobes(kind, aspect=1.0, segments=16, rings=8):
-    """Cornell walls + one sphere carrying the lobe under test: 'oren_nayar', 'ggx_metal' or 'ggx_glass'."""
+    """Cornell walls + one sphere carrying the lobe under test: 'oren_nayar', 'ggx_metal', 'ggx_glass', 'ward' or 'ashikhmin'."""
     b = SceneBuilder()
     cornell_walls(b)
     if kind == "oren_nayar":
@@ -241,6 +249,10 @@ def cornell_lobes(kind, aspect=1.0, segments=16, rings=8):
         m = b.microfacet_metal(b.spectrum_ior("Titanium", 0, TITANIUM_ETA_RGB), b.spectrum_ior("Titanium", 1, TITANIUM_K_RGB), 0.1)
     elif kind == "ggx_glass":
         m = b.microfacet_glass(b.spectrum_ior("Air", 0, AIR_ETA_RGB), b.spectrum_ior("Glass_BK7", 0, BK7_ETA_RGB), 0.2)
+    elif kind == "ward":
+        m = b.ward(b.spectrum_srgb_nonlinear(0.8, 0.7, 0.4), 0.15, 0.4)
+    elif kind == "ashikhmin":
+        m = b.ashikhmin(b.spectrum_srgb_nonlinear(0.6, 0.25, 0.2), b.spectrum_grey(0.05), 100.0, 20.0)
     else:
         raise ValueError(kind)
     b.add_uv_sphere(segments, rings, m, _translate(-0.3, 0, -0.5) @ _scale(0.6) @ _translate(0, 1, 0))

@@ -104,6 +104,8 @@ def main():
     make("rgb_oren_nayar", scenes.cornell_lobes("oren_nayar"), lib, 40, 40, 8, 2)
     make("rgb_ggx_metal", scenes.cornell_lobes("ggx_metal"), lib, 40, 40, 8, 2)
     make("rgb_ggx_glass", scenes.cornell_lobes("ggx_glass"), lib, 40, 40, 8, 2)
+    make("rgb_ward", scenes.cornell_lobes("ward"), lib, 40, 40, 8, 2)
+    make("rgb_ashikhmin", scenes.cornell_lobes("ashikhmin"), lib, 40, 40, 8, 2)
     spec = ob.load("ref_spectral")
     if spec is not None:
         # the spectral build's saveImage (16 storage bins -> getRGB -> tone map -> BMP) on a known framebuffer
@@ -126,6 +128,7 @@ def main():
     make("spectral_ggx_glass", scenes.cornell_lobes("ggx_glass", segments=10, rings=5), spec, 32, 32, 8, 2)
     make("rgb_ibl", scenes.ibl_test_scene(1.0, (128, 64), 12, 6), lib, 40, 40, 8, 2)
     make("rgb_ibl_area", scenes.ibl_test_scene(1.0, (128, 64), 12, 6, area_light=True), lib, 40, 40, 8, 2)
+    make("spectral_ashikhmin", scenes.cornell_lobes("ashikhmin", segments=10, rings=5), spec, 32, 32, 8, 2)
     make("spectral_ibl", scenes.ibl_test_scene(1.0, (128, 64), 12, 6, area_light=True), spec, 32, 32, 8, 2)
     make("rgb_cornell_matte", scenes.cornell_box_spheres(4.0 / 3.0, 16, 8, "matte"), lib, 48, 36, 8, 2)
 

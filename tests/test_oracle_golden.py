@@ -7,7 +7,7 @@ from helpers import assert_bit_equal, load_golden, scene_from_golden
 from oracle import binding as ob
 from slr_amd import abi
 
-SCENES = ["rgb_tiny_box", "rgb_cornell_glass", "rgb_cornell_matte", "rgb_oren_nayar", "rgb_ggx_metal", "rgb_ggx_glass",
+SCENES = ["rgb_tiny_box", "rgb_cornell_glass", "rgb_cornell_matte", "rgb_oren_nayar", "rgb_ggx_metal", "rgb_ggx_glass", "rgb_ward", "rgb_ashikhmin",
           "rgb_ibl", "rgb_ibl_area"]     # environment sphere alone / next to a triangle light (Scene::selectLight)
 
 
@@ -109,7 +109,7 @@ def test_rejects_bad_scene(oracle_rgb):
         abi.Scene(sc.vertices[:2], sc.triangles, sc.materials, sc.spectra, sc.spectrum_data, sc.camera)
 
 
-SPECTRAL_SCENES = ["spectral_cornell_glass", "spectral_cornell_matte", "spectral_oren_nayar", "spectral_ggx_metal", "spectral_ggx_glass",
+SPECTRAL_SCENES = ["spectral_cornell_glass", "spectral_cornell_matte", "spectral_oren_nayar", "spectral_ggx_metal", "spectral_ggx_glass", "spectral_ashikhmin",
                    "spectral_ibl"]     # environment texels as (u, v, s), looked up in the Meng-15 grid at run time, + an area light
 
 

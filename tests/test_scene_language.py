@@ -116,7 +116,8 @@ def test_argument_binding_follows_the_reference():
 
 @pytest.mark.parametrize("snippet", ['x = Image2D("images/a.exr");', 'setEnvironment("images/sky.exr", 4);',
                                      'n = load3DModel("models/teapot.assbin");',
-                                     'm = createSurfaceMaterial("Ward", (SpectrumTexture(Spectrum(0.5, 0.5, 0.5)), FloatTexture(0.1), FloatTexture(0.1)));'])
+                                     'm = createSurfaceMaterial("sum", (createSurfaceMaterial("matte", (SpectrumTexture(Spectrum(0.5, 0.5, 0.5)),)), '
+                                     'createSurfaceMaterial("matte", (SpectrumTexture(Spectrum(0.1, 0.1, 0.1)),))));'])
 def test_missing_assets_and_lobes_are_refused_loudly(snippet):
     with pytest.raises(sl.UnsupportedFeature):
         sl.Interpreter().run(snippet)
