@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SLRHIP_VERSION 1
+#define SLRHIP_VERSION 2   /* 2: slrhip_material::param2, slrhip_scene_desc::upsampling, Ward / Ashikhmin lobes */
 
 /* ---- status codes -------------------------------------------------------------- */
 enum {
