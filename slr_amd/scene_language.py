@@ -19,7 +19,7 @@ import re
 
 import numpy as np
 
-from . import scenes, spectra
+from . import abi, scenes, spectra
 
 
 class SceneLanguageError(RuntimeError):
@@ -671,24 +671,21 @@ class Interpreter:
                 return material_cache[key]
             p = m.params
             emit = spectrum(m.emitter.emittance) if m.emitter is not None else -1
+            sp = lambda name: spectrum(p[name].spectrum)
             if m.kind == "matte":
-                sigma = -1.0 if p["sigma"] is None else p["sigma"].value
-                idx = b.matte(spectrum(p["reflectance"].spectrum), sigma, emit)
+                idx = b.material(abi.MAT_MATTE, (sp("reflectance"), -1, -1), -1.0 if p["sigma"] is None else p["sigma"].value, emit)
+            elif m.kind == "metal":
+                idx = b.material(abi.MAT_METAL, (sp("coeffR"), sp("eta"), sp("k")), emittance=emit)
+            elif m.kind == "glass":
+                idx = b.material(abi.MAT_GLASS, (sp("coeff"), sp("etaExt"), sp("etaInt")), emittance=emit)
+            elif m.kind == "Ward":
+                idx = b.material(abi.MAT_WARD, (sp("R"), -1, -1), p["anisoX"].value, emit, p["anisoY"].value)
+            elif m.kind == "Ashikhmin":
+                idx = b.material(abi.MAT_ASHIKHMIN, (sp("Rs"), sp("Rd"), -1), p["nx"].value, emit, p["ny"].value)
+            elif m.kind == "microfacet metal":
+                idx = b.material(abi.MAT_MF_METAL, (-1, sp("eta"), sp("k")), p["alpha_g"].value, emit)
             else:
-                if emit >= 0:
-                    raise UnsupportedFeature("emitter on a %s base material" % m.kind)
-                if m.kind == "metal":
-                    idx = b.metal(spectrum(p["coeffR"].spectrum), spectrum(p["eta"].spectrum), spectrum(p["k"].spectrum))
-                elif m.kind == "glass":
-                    idx = b.glass(spectrum(p["coeff"].spectrum), spectrum(p["etaExt"].spectrum), spectrum(p["etaInt"].spectrum))
-                elif m.kind == "Ward":
-                    idx = b.ward(spectrum(p["R"].spectrum), p["anisoX"].value, p["anisoY"].value)
-                elif m.kind == "Ashikhmin":
-                    idx = b.ashikhmin(spectrum(p["Rd"].spectrum), spectrum(p["Rs"].spectrum), p["nx"].value, p["ny"].value)
-                elif m.kind == "microfacet metal":
-                    idx = b.microfacet_metal(spectrum(p["eta"].spectrum), spectrum(p["k"].spectrum), p["alpha_g"].value)
-                else:
-                    idx = b.microfacet_glass(spectrum(p["etaExt"].spectrum), spectrum(p["etaInt"].spectrum), p["alpha_g"].value)
+                idx = b.material(abi.MAT_MF_GLASS, (-1, sp("etaExt"), sp("etaInt")), p["alpha_g"].value, emit)
             material_cache[key] = idx
             return idx
 

@@ -114,6 +114,30 @@ def test_argument_binding_follows_the_reference():
         it.run('Spectrum("nonsense": 1);')
 
 
+def test_glossy_lobes_and_emitters_on_any_base():
+    it = sl.Interpreter()
+    it.run('''
+        lamp = createSurfaceMaterial("emitter", (createSurfaceMaterial("metal", (SpectrumTexture(Spectrum("Reflectance", 1.0)),
+               SpectrumTexture(Spectrum("ID": "Aluminium", 0)), SpectrumTexture(Spectrum("ID": "Aluminium", 1)))),
+               createEmitterSurfaceProperty("diffuse", (SpectrumTexture(Spectrum("ID": "D65")),))));
+        w = createSurfaceMaterial("Ward", (SpectrumTexture(Spectrum(0.5, 0.5, 0.5)), FloatTexture(0.1), FloatTexture(0.2)));
+        a = createSurfaceMaterial("Ashikhmin", (SpectrumTexture(Spectrum(0.5, 0.2, 0.2)), SpectrumTexture(Spectrum("Reflectance", 0.05)),
+                                                FloatTexture(100), FloatTexture(50)));
+        q = createMesh((((0, 0, 0), (0, 1, 0), (1, 0, 0), (0, 0)), ((1, 0, 0), (0, 1, 0), (1, 0, 0), (1, 0)), ((1, 0, 1), (0, 1, 0), (1, 0, 0), (1, 1))),
+                       ((lamp, ((0, 1, 2),)), (w, ((0, 2, 1),)), (a, ((1, 2, 0),))));
+        addChild(root, q);
+        c = createNode(); addChild(c, createPerspectiveCamera()); addChild(root, c);
+    ''')
+    sc = it.build()
+    from slr_amd import abi
+    assert list(sc.materials["type"]) == [abi.MAT_METAL, abi.MAT_WARD, abi.MAT_ASHIKHMIN]
+    assert sc.materials["emittance"][0] >= 0 and (sc.materials["emittance"][1:] == -1).all()
+    assert (float(sc.materials["param"][1]), float(sc.materials["param2"][1])) == (np.float32(0.1), np.float32(0.2))
+    rs, rd = sc.materials["spectrum"][2][:2]                    # Ashikhmin: spectrum = {Rs, Rd}; the script passes (Rd, Rs, nx, ny)
+    assert tuple(sc.spectra[rs]["rgb"]) == (np.float32(0.05),) * 3 and sc.spectra[rd]["rgb"][0] > sc.spectra[rd]["rgb"][1]
+    assert (float(sc.materials["param"][2]), float(sc.materials["param2"][2])) == (100.0, 50.0)
+
+
 @pytest.mark.parametrize("snippet", ['x = Image2D("images/a.exr");', 'setEnvironment("images/sky.exr", 4);',
                                      'n = load3DModel("models/teapot.assbin");',
                                      'm = createSurfaceMaterial("sum", (createSurfaceMaterial("matte", (SpectrumTexture(Spectrum(0.5, 0.5, 0.5)),)), '
