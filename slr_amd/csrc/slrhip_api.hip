@@ -130,9 +130,16 @@ struct slrhip_ctx {
 
     // SLRHIP_FLAG_TIME_KERNELS: 4 events per iteration (before closest, after closest, after shadow, after shade)
     std::vector<hipEvent_t> events;
+    // hipGraph of one block of iterations (slrhip_render): captured on the context's own stream, replayed until no slot is live
+    hipStream_t workStream = nullptr;
+    hipEvent_t userReady = nullptr;
     uint64_t profLaunches[SLRHIP_KERNEL_COUNT] = {0, 0, 0, 0};
     double profMs[SLRHIP_KERNEL_COUNT] = {0, 0, 0, 0};
-    ~slrhip_ctx() { for (hipEvent_t e : events) (void)hipEventDestroy(e); }
+    ~slrhip_ctx() {
+        for (hipEvent_t e : events) (void)hipEventDestroy(e);
+        if (userReady) (void)hipEventDestroy(userReady);
+        if (workStream) (void)hipStreamDestroy(workStream);
+    }
 };
 
 // Sum the sharded statistics words (pt_kernels.h: totalIndex).
@@ -620,6 +627,57 @@ int slrhip_render(slrhip_ctx* ctx, uint32_t sppBegin, uint32_t sppCount, void* s
     }
     const uint64_t maxIterations = (uint64_t)(sppCount / rp.stripes + 2) * 128 + 1024;   // paths are <= 100 vertices long
     uint64_t it = 0;
+
+    // The block of kCheckEvery iterations is the same sequence of launches every time (the parity alternates inside it and is
+    // back to 0 at its end), so it is captured ONCE per call into a hipGraph and replayed: one submission per block instead
+    // of 32-48 launches with their dispatch gaps — what is left of the cost of the nearly empty iterations at the end of a
+    // render.  Capture needs a real stream, so the work runs on the context's own stream, ordered after the caller's by an
+    // event; render() returns only after that stream is idle, which orders the caller's later work after it.
+    static const bool noGraph = [] { const char* e = getenv("SLRHIP_GRAPH"); return e && std::string(e) == "0"; }();
+    if (!timeKernels && !noGraph && rp.numSlots >= (1u << 18)) {
+        if (!ctx->workStream) {
+            HIP_TRY(hipStreamCreateWithFlags(&ctx->workStream, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&ctx->userReady, hipEventDisableTiming));
+        }
+        hipStream_t ws = ctx->workStream;
+        HIP_TRY(hipEventRecord(ctx->userReady, stream));          // the reset kernel above and whatever the caller queued before
+        HIP_TRY(hipStreamWaitEvent(ws, ctx->userReady, 0));
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        HIP_TRY(hipStreamBeginCapture(ws, hipStreamCaptureModeThreadLocal));
+        for (int k = 0; k < kCheckEvery; ++k) {
+            launchRegen(ctx->scene, ctx->buffers, rp, (uint32_t)(k & 1), ws);
+            if (useWs) launchTraceWs(ctx->scene, ctx->buffers, rp, (uint32_t)(k & 1), traceBlocks, count, ws);
+            else {
+                launchTraceClosest(ctx->scene, ctx->buffers, rp, (uint32_t)(k & 1), traceBlocks, count, ws);
+                launchTraceShadow(ctx->scene, ctx->buffers, rp, (uint32_t)(k & 1), traceBlocks, count, ws);
+            }
+            launchLogic(ctx->scene, ctx->buffers, rp, (uint32_t)(k & 1), ws);
+        }
+        hipError_t ce = hipStreamEndCapture(ws, &graph);
+        if (ce == hipSuccess) ce = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        if (ce != hipSuccess) {
+            if (graph) (void)hipGraphDestroy(graph);
+            return fail(SLRHIP_ERR_HIP, std::string("slrhip_render: hipGraph capture failed: ") + hipGetErrorString(ce));
+        }
+        int rc = SLRHIP_OK;
+        while (active > 0 && rc == SLRHIP_OK) {
+            hipError_t e = hipGraphLaunch(exec, ws);
+            if (e == hipSuccess) e = hipMemcpyAsync(&active, ctx->activeSlots.ptr, sizeof(uint32_t), hipMemcpyDeviceToHost, ws);
+            if (e == hipSuccess) e = hipStreamSynchronize(ws);
+            if (e != hipSuccess) rc = fail(SLRHIP_ERR_HIP, std::string("slrhip_render: ") + hipGetErrorString(e));
+            it += kCheckEvery;
+            if (rc == SLRHIP_OK && it > maxIterations) rc = fail(SLRHIP_ERR_HIP, "slrhip_render: iteration bound exceeded (internal error)");
+        }
+        (void)hipGraphExecDestroy(exec);
+        (void)hipGraphDestroy(graph);
+        if (rc != SLRHIP_OK) return rc;
+        ctx->iterations += it;
+        ctx->samplesDone += (uint64_t)rp.numPixels * sppCount;
+        HIP_TRY(hipGetLastError());
+        return SLRHIP_OK;
+    }
+
     while (active > 0) {
         for (int k = 0; k < kCheckEvery; ++k) {
             hipEvent_t* ev = timeKernels ? &ctx->events[(size_t)k * kEv] : nullptr;
