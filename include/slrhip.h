@@ -318,6 +318,18 @@ int slrhip_get_profile(slrhip_ctx* ctx, slrhip_profile* out);
  * (Intersection::dist, ::u, ::v; TriangleMesh.cpp:169-173).  Host arrays; synchronises.        */
 int slrhip_trace_rays(slrhip_ctx* ctx, const float* rays, uint32_t n, float* hits);
 
+/* Diagnostic: function-level BSDF queries against material `material` of the uploaded scene,
+ * through the same device functions the shading kernel calls: BSDF::sample / evaluate /
+ * evaluatePDF (directional_distribution_functions.h:231-279; flags = All, non-adjoint) on the
+ * BSDF that SurfaceMaterial::getBSDF (surface_material.h:22) builds for wavelengths
+ * WavelengthSamples::createWithEqualOffsets(wl_offset, u_lambda) (SpectrumTypes.h:54-64).
+ *   queries[12 i ..]     = dirOut_sn[3], gNormal_sn[3], dirIn_sn[3], uComponent, uDir[2]
+ *   out[(6 + 2C) i ..]   = sampled dir_sn[3], dirPDF, dirType, fs(sample)[C], fs(evaluate)[C],
+ *                          evaluatePDF        (C = slrhip_components; zeros when dirPDF == 0)
+ * Directions are in the shading frame (z = shading normal).  Host arrays; synchronises.        */
+int slrhip_bsdf_queries(slrhip_ctx* ctx, uint32_t material, uint32_t n, const float* queries,
+                        float wl_offset, float u_lambda, float* out);
+
 /* The per-(pixel, sample) seeding contract (pure function, also used by the oracle).      */
 int32_t slrhip_sample_seed(int32_t rng_seed, uint32_t pixel_x, uint32_t pixel_y, uint32_t pass);
 

@@ -50,6 +50,7 @@ class OracleLib:
         f("rng").argtypes = [C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p]
         f("rng").restype = None
         f("components").argtypes = [C.c_void_p]
+        f("bsdf_kat").argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_float, C.c_float, C.c_void_p]
         f("render_serial").argtypes = [C.c_void_p, C.POINTER(abi.RenderSettings), C.c_uint32, C.c_void_p,
                                        C.POINTER(OracleCounters)]
 
@@ -114,6 +115,16 @@ class OracleScene:
         if rc != 0:
             raise RuntimeError("oracle trace failed: %d" % rc)
         return hits
+
+    def bsdf_kat(self, material, queries, wl_offset=0.5, u_lambda=0.5):
+        """BSDF sample / evaluate / evaluatePDF of one scene material; queries [n][12], returns [n][6 + 2C]
+        (layout in slr_oracle.h)."""
+        q = np.ascontiguousarray(queries, dtype=np.float32).reshape(-1, 12)
+        out = np.zeros((len(q), 6 + 2 * self.components), np.float32)
+        rc = self.lib._f("bsdf_kat")(self.handle, material, len(q), q.ctypes.data, wl_offset, u_lambda, out.ctypes.data)
+        if rc != 0:
+            raise RuntimeError("oracle bsdf_kat failed: %d" % rc)
+        return out
 
     def render_serial(self, settings, spp):
         h, w = settings.image_height, settings.image_width

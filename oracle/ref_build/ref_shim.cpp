@@ -372,6 +372,46 @@ int slr_ref_sample(slr_oracle_scene* s, const slrhip_render_settings* st, uint32
     return 0;
 }
 
+// Function-level known answers: the reference's own BSDF objects, obtained the way the integrator obtains them
+// (SurfaceMaterial::getBSDF, surface_material.h:22) and queried through the public BSDF interface (DDF.h:231-279).
+int slr_ref_bsdf_kat(slr_oracle_scene* s, uint32_t material, uint32_t n, const float* in, float wlOffset, float uLambda, float* out) {
+    if (!s || !in || !out || material >= s->materials.size()) return 1;
+    float wlPDF;
+    WavelengthSamples wls = WavelengthSamples::createWithEqualOffsets(wlOffset, uLambda, &wlPDF);
+    SurfacePoint surfPt;
+    surfPt.p = Point3D(0, 0, 0);
+    surfPt.atInfinity = false;
+    surfPt.gNormal = Normal3D(0, 0, 1);
+    surfPt.u = surfPt.v = 0.0f;
+    surfPt.texCoord = TexCoord2D(0.0f, 0.0f);
+    surfPt.texCoord0Dir = Vector3D(1, 0, 0);
+    surfPt.shadingFrame.x = Vector3D(1, 0, 0);
+    surfPt.shadingFrame.y = Vector3D(0, 1, 0);
+    surfPt.shadingFrame.z = Vector3D(0, 0, 1);
+    surfPt.obj = nullptr;
+    ArenaAllocator mem;
+    BSDF* bsdf = s->materials[material]->getBSDF(surfPt, wls, mem);
+    const int stride = 6 + 2 * kComponents;
+    for (uint32_t i = 0; i < n; ++i) {
+        const float* q = in + 12 * (size_t)i;
+        float* o = out + stride * (size_t)i;
+        BSDFQuery query(Vector3D(q[0], q[1], q[2]), Normal3D(q[3], q[4], q[5]), (int16_t)wls.selectedLambda, DirectionType::All);
+        Vector3D dirIn(q[6], q[7], q[8]);
+        BSDFQueryResult r;
+        r.dirPDF = 0.0f;
+        SampledSpectrum fs = bsdf->sample(query, BSDFSample(q[9], q[10], q[11]), &r);
+        for (int k = 0; k < stride; ++k) o[k] = 0.0f;
+        if (r.dirPDF != 0.0f) {
+            o[0] = r.dir_sn.x; o[1] = r.dir_sn.y; o[2] = r.dir_sn.z; o[3] = r.dirPDF; o[4] = (float)(uint32_t)r.dirType.value;
+            for (int k = 0; k < kComponents; ++k) o[5 + k] = fs[k];
+        }
+        SampledSpectrum fe = bsdf->evaluate(query, dirIn);
+        for (int k = 0; k < kComponents; ++k) o[5 + kComponents + k] = fe[k];
+        o[5 + 2 * kComponents] = bsdf->evaluatePDF(query, dirIn);
+    }
+    return 0;
+}
+
 int slr_ref_trace(slr_oracle_scene* s, const slr_oracle_ray* rays, uint32_t n, slr_oracle_hit* hits) {
     if (!s || !rays || !hits) return 1;
     for (uint32_t i = 0; i < n; ++i) {

@@ -1332,9 +1332,8 @@ float bsdfEvaluatePDF(const BSDF<N>& f, const BSDFQuery<N>& q, V3 dir) {
 // (basic_SurfaceMaterials.cpp:15-43; EmitterSurfaceMaterial forwards to its base material,
 //  surface_material.h:65).  `scale * spectrum` with scale = 1.0f is an exact multiply.
 template <int N>
-BSDF<N> createBSDF(const Scene& s, const SurfPt& sp, const Wls<N>& wls) {
+BSDF<N> createBSDFOf(const Scene& s, const slrhip_material& m, const Wls<N>& wls) {
     const uint16_t wlFlags = wls.flags;
-    const slrhip_material& m = s.materials[s.tris[sp.tri].material];
     BSDF<N> f;
     f.kind = m.type;
     f.param = m.param;
@@ -1388,6 +1387,9 @@ BSDF<N> createBSDF(const Scene& s, const SurfPt& sp, const Wls<N>& wls) {
     }
     return f;
 }
+
+template <int N>
+inline BSDF<N> createBSDF(const Scene& s, const SurfPt& sp, const Wls<N>& wls) { return createBSDFOf<N>(s, s.materials[s.tris[sp.tri].material], wls); }
 
 inline bool isEmitting(const Scene& s, uint32_t tri) { return tri == kEnvObject || s.materials[s.tris[tri].material].emittance >= 0; }
 template <int N>
@@ -1723,6 +1725,40 @@ void addCounters(slr_oracle_counters* dst, const slr_oracle_counters& src) {
 
 } // namespace
 
+namespace {
+// Function-level known answers: the three public BSDF calls of DDF.h:231-279 on one material.
+template <int N>
+int bsdfKatT(const slr_oracle_scene* s, uint32_t material, uint32_t n, const float* in, float wlOffset, float uLambda, float* out) {
+    Wls<N> wls;
+    for (int i = 0; i < N; ++i)
+        wls.lambdas[i] = kWavelengthLowBound + (kWavelengthHighBound - kWavelengthLowBound) * (i + wlOffset) / N;
+    wls.selectedLambda = std::min(uint16_t(N * uLambda), uint16_t(N - 1));
+    wls.flags = 0;
+    BSDF<N> bsdf = createBSDFOf<N>(*s, s->materials[material], wls);
+    const int stride = 6 + 2 * N;
+    for (uint32_t i = 0; i < n; ++i) {
+        const float* q = in + 12 * (size_t)i;
+        float* o = out + stride * (size_t)i;
+        BSDFQuery<N> query;
+        query.dir_sn = V3(q[0], q[1], q[2]); query.gNormal_sn = V3(q[3], q[4], q[5]);
+        query.wlHint = (int16_t)wls.selectedLambda; query.flags = DT_All;
+        V3 dirIn(q[6], q[7], q[8]);
+        float uDir[2] = {q[10], q[11]};
+        BSDFResult r; r.dir_sn = V3(0, 0, 0); r.dirPDF = 0.0f; r.dirType = 0;
+        Spec<N> fs = bsdfSample(bsdf, query, q[9], uDir, &r);
+        for (int k = 0; k < stride; ++k) o[k] = 0.0f;
+        if (r.dirPDF != 0.0f) {
+            o[0] = r.dir_sn.x; o[1] = r.dir_sn.y; o[2] = r.dir_sn.z; o[3] = r.dirPDF; o[4] = (float)r.dirType;
+            for (int k = 0; k < N; ++k) o[5 + k] = fs[k];
+        }
+        Spec<N> fe = bsdfEvaluate(bsdf, query, dirIn);
+        for (int k = 0; k < N; ++k) o[5 + N + k] = fe[k];
+        o[5 + 2 * N] = bsdfEvaluatePDF(bsdf, query, dirIn);
+    }
+    return 0;
+}
+} // namespace
+
 extern "C" {
 
 slr_oracle_scene* slr_oracle_create(const slrhip_scene_desc* d, int mode) {
@@ -1882,6 +1918,12 @@ int slr_oracle_render(slr_oracle_scene* s, const slrhip_render_settings* st, slr
 int slr_oracle_sample(slr_oracle_scene* s, const slrhip_render_settings* st, uint32_t px, uint32_t py, uint32_t pass, float* out) {
     if (!s || !st || !out) return 1;
     return s->mode == SLRHIP_MODE_RGB ? sampleT<3>(s, st, px, py, pass, out) : sampleT<16>(s, st, px, py, pass, out);
+}
+
+int slr_oracle_bsdf_kat(slr_oracle_scene* s, uint32_t material, uint32_t n, const float* in, float wlOffset, float uLambda, float* out) {
+    if (!s || !in || !out || material >= s->materials.size()) return 1;
+    return s->mode == SLRHIP_MODE_RGB ? bsdfKatT<3>(s, material, n, in, wlOffset, uLambda, out)
+                                      : bsdfKatT<16>(s, material, n, in, wlOffset, uLambda, out);
 }
 
 int slr_oracle_render_serial(slr_oracle_scene* s, const slrhip_render_settings* st, uint32_t spp, float* fbSum,

@@ -62,7 +62,15 @@ typedef struct slr_oracle_hit {
     int P##trace(slr_oracle_scene* s, const slr_oracle_ray* rays, uint32_t n, slr_oracle_hit* hits);\
     /* xorshift128 known answers: n raw uint32 draws then n float draws from `seed`.            */ \
     void P##rng(int32_t seed, uint32_t n, uint32_t* uints, float* floats);                         \
-    int P##components(const slr_oracle_scene* s);
+    int P##components(const slr_oracle_scene* s);                                                  \
+    /* Function-level known answers: BSDF::sample / evaluate / evaluatePDF             \
+     * (DDF.h:231-279, flags = All, non-adjoint) of scene material `material` for n queries under  \
+     * WavelengthSamples::createWithEqualOffsets(wl_offset, u_lambda).                             \
+     * in[12 i ..]  = dirOut_sn[3], gNormal_sn[3], dirIn_sn[3], uComponent, uDir[2]                \
+     * out[(6+2C) i ..] = sampled dir_sn[3], dirPDF, dirType, fs(sample)[C], fs(evaluate)[C],      \
+     * evaluatePDF; the five sample fields and fs(sample) are zero when dirPDF == 0.           */ \
+    int P##bsdf_kat(slr_oracle_scene* s, uint32_t material, uint32_t n, const float* in,           \
+                    float wl_offset, float u_lambda, float* out);
 
 SLR_ORACLE_DECLARE(slr_oracle_)
 SLR_ORACLE_DECLARE(slr_ref_)

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(CSRC, "libslrhip.so")
 
 EXPORTS = ["slrhip_create", "slrhip_destroy", "slrhip_upload_scene", "slrhip_render_begin", "slrhip_render",
            "slrhip_resolve_framebuffer", "slrhip_read_framebuffer", "slrhip_synchronize", "slrhip_get_counters",
-           "slrhip_components", "slrhip_get_profile", "slrhip_trace_rays", "slrhip_sample_seed", "slrhip_tonemap_bgr8", "slrhip_save_bmp",
+           "slrhip_components", "slrhip_get_profile", "slrhip_trace_rays", "slrhip_bsdf_queries", "slrhip_sample_seed", "slrhip_tonemap_bgr8", "slrhip_save_bmp",
            "slrhip_last_error_string", "slrhip_version"]
 
 
@@ -52,6 +52,7 @@ def load_library():
     lib.slrhip_components.argtypes = [C.c_void_p]
     lib.slrhip_get_profile.argtypes = [C.c_void_p, C.POINTER(abi.Profile)]
     lib.slrhip_trace_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    lib.slrhip_bsdf_queries.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_float, C.c_float, C.c_void_p]
     lib.slrhip_sample_seed.argtypes = [C.c_int32, C.c_uint32, C.c_uint32, C.c_uint32]
     lib.slrhip_sample_seed.restype = C.c_int32
     lib.slrhip_tonemap_bgr8.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_size_t]
@@ -128,6 +129,14 @@ class Context:
         hits = np.zeros((n, 4), np.float32)
         _check(self.lib, self.lib.slrhip_trace_rays(self.handle, rays.ctypes.data, n, hits.ctypes.data), "slrhip_trace_rays")
         return hits[:, 0].copy().view(np.uint32), hits[:, 1], hits[:, 2], hits[:, 3]
+
+    def bsdf_queries(self, material, queries, wl_offset=0.5, u_lambda=0.5):
+        """Function-level BSDF queries (slrhip_bsdf_queries): queries [n][12] -> [n][6 + 2C]."""
+        q = np.ascontiguousarray(queries, dtype=np.float32).reshape(-1, 12)
+        out = np.zeros((len(q), 6 + 2 * self.components), np.float32)
+        _check(self.lib, self.lib.slrhip_bsdf_queries(self.handle, material, len(q), q.ctypes.data, wl_offset, u_lambda, out.ctypes.data),
+               "slrhip_bsdf_queries")
+        return out
 
     @property
     def mode(self):

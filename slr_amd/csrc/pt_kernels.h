@@ -118,6 +118,8 @@ void launchTraceShadow(const DevScene& sc, const PathBuffers& pb, const RenderPa
                        hipStream_t stream);
 void launchLogic(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, hipStream_t stream);
 void launchResolve(const PathBuffers& pb, const RenderParams& rp, float* dst, hipStream_t stream);
+void launchBsdfQueries(const DevScene& sc, bool spectral, uint32_t material, uint32_t n, const float* in, float wlOffset, uint32_t wl,
+                       float4* geo, float4* misc, float4* fsSample, float4* fsEval, hipStream_t stream);
 void launchTraceBatch(const DevScene& sc, const float4* org, const float4* dir, float4* out, uint32_t n, hipStream_t stream);
 int traceBlocksPerCU();
 // wave-specialised traversal (pt_trace_ws.hip): same results, ONE launch for the extension and the shadow rays of an iteration

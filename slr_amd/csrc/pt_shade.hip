@@ -863,6 +863,30 @@ __global__ void k_resolve(PathBuffers pb, RenderParams rp, float* dst) {
 }
 
 // ---- host-callable launchers -----------------------------------------------------------------------------------
+// Diagnostic (slrhip_bsdf_queries): the three BSDF entry points exactly as k_logic calls them, one query per lane.
+// geo[i] = (sampled dir_sn, dirPDF); misc[i] = (dirType, evaluatePDF, 0, 0); fsSample / fsEval in the SpecIO layout.
+template <class S>
+__global__ void __launch_bounds__(64) k_bsdf_queries(DevScene sc, uint32_t material, uint32_t n, const float* __restrict__ in, float wlOffset,
+                                                     uint32_t wl, float4* __restrict__ geo, float4* __restrict__ misc,
+                                                     float4* __restrict__ fsSample, float4* __restrict__ fsEval) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* q = in + 12 * (size_t)i;
+    const Mat<S> m = MatIO<S>::template load<false>(sc, nullptr, material, wlOffset);
+    const uint32_t type = bsdfType(m.type, 0u);
+    const V3 dirOut(q[0], q[1], q[2]), gNorm(q[3], q[4], q[5]), dirIn(q[6], q[7], q[8]);
+    BsdfSample bs;
+    bs.dir_sn = V3(0, 0, 0);
+    S fs = bsdfSample<S, true>(m, type, dirOut, gNorm, wl, q[9], q[10], q[11], &bs);
+    if (bs.dirPDF == 0.0f) { bs.dir_sn = V3(0, 0, 0); bs.dirType = 0; fs = S(); }
+    float pdf;
+    const S fe = bsdfEvaluate<S, true>(m, type, dirOut, gNorm, dirIn, wl, &pdf);
+    geo[i] = make_float4(bs.dir_sn.x, bs.dir_sn.y, bs.dir_sn.z, bs.dirPDF);
+    misc[i] = make_float4((float)bs.dirType, pdf, 0.0f, 0.0f);
+    SpecIO<S>::store(fsSample, nullptr, i, n, fs, 0.0f);
+    SpecIO<S>::store(fsEval, nullptr, i, n, fe, 0.0f);
+}
+
 void launchResetSlots(const PathBuffers& pb, const RenderParams& rp, bool clearAcc, hipStream_t stream) {
     const dim3 grid((rp.numSlots + kShadeBlock - 1) / kShadeBlock), block(kShadeBlock);
     if (rp.spectral) hipLaunchKernelGGL(k_reset_slots<Spec16>, grid, block, 0, stream, pb, rp, clearAcc ? 1u : 0u);
@@ -902,6 +926,12 @@ void launchLogic(const DevScene& sc, const PathBuffers& pb, const RenderParams& 
     else if (ldsTables) hipLaunchKernelGGL((k_logic<RGB, true, true>), grid, block, 0, stream, sc, pb, rp, parity);
     else if (!sc.hasMicrofacet) hipLaunchKernelGGL((k_logic<RGB, false, false>), grid, block, 0, stream, sc, pb, rp, parity);
     else hipLaunchKernelGGL((k_logic<RGB, false, true>), grid, block, 0, stream, sc, pb, rp, parity);
+}
+void launchBsdfQueries(const DevScene& sc, bool spectral, uint32_t material, uint32_t n, const float* in, float wlOffset, uint32_t wl,
+                       float4* geo, float4* misc, float4* fsSample, float4* fsEval, hipStream_t stream) {
+    const dim3 grid((n + 63) / 64), block(64);
+    if (spectral) hipLaunchKernelGGL(k_bsdf_queries<Spec16>, grid, block, 0, stream, sc, material, n, in, wlOffset, wl, geo, misc, fsSample, fsEval);
+    else hipLaunchKernelGGL(k_bsdf_queries<RGB>, grid, block, 0, stream, sc, material, n, in, wlOffset, wl, geo, misc, fsSample, fsEval);
 }
 void launchResolve(const PathBuffers& pb, const RenderParams& rp, float* dst, hipStream_t stream) {
     const dim3 grid((rp.numPixels + 255) / 256), block(256);

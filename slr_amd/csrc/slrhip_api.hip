@@ -817,4 +817,47 @@ int slrhip_trace_rays(slrhip_ctx* ctx, const float* rays, uint32_t n, float* hit
     return SLRHIP_OK;
 }
 
+int slrhip_bsdf_queries(slrhip_ctx* ctx, uint32_t material, uint32_t n, const float* queries, float wl_offset, float u_lambda, float* out) {
+    if (!ctx || !queries || !out) return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_bsdf_queries: null argument");
+    if (!ctx->haveScene) return fail(SLRHIP_ERR_NO_SCENE, "slrhip_bsdf_queries: no scene uploaded");
+    if (material >= ctx->scene.numMaterials) return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_bsdf_queries: material index out of range");
+    if (!(wl_offset >= 0.0f && wl_offset < 1.0f) || !(u_lambda >= 0.0f && u_lambda < 1.0f))
+        return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_bsdf_queries: wl_offset and u_lambda must be in [0, 1)");
+    if (n == 0) return SLRHIP_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const bool spectral = ctx->config.mode == SLRHIP_MODE_SPECTRAL;
+    const uint32_t C = spectral ? 16u : 3u, planes = spectral ? 4u : 1u;
+    // WavelengthSamples::createWithEqualOffsets (SpectrumTypes.h:60, RGBTypes.h:41)
+    const uint32_t wl = std::min<uint32_t>((uint16_t)(C * u_lambda), C - 1);
+    std::vector<float> in(queries, queries + (size_t)n * 12);
+    DevArray<float> dIn;
+    DevArray<float4> dGeo, dMisc, dFsS, dFsE;
+    HIP_TRY(dIn.upload(in));
+    HIP_TRY(dGeo.alloc(n));
+    HIP_TRY(dMisc.alloc(n));
+    HIP_TRY(dFsS.alloc((size_t)planes * n));
+    HIP_TRY(dFsE.alloc((size_t)planes * n));
+    launchBsdfQueries(ctx->scene, spectral, material, n, dIn.ptr, wl_offset, wl, dGeo.ptr, dMisc.ptr, dFsS.ptr, dFsE.ptr, nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    std::vector<float4> geo(n), misc(n), fsS((size_t)planes * n), fsE((size_t)planes * n);
+    HIP_TRY(hipMemcpy(geo.data(), dGeo.ptr, geo.size() * sizeof(float4), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(misc.data(), dMisc.ptr, misc.size() * sizeof(float4), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(fsS.data(), dFsS.ptr, fsS.size() * sizeof(float4), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(fsE.data(), dFsE.ptr, fsE.size() * sizeof(float4), hipMemcpyDeviceToHost));
+    const uint32_t stride = 6 + 2 * C;
+    for (uint32_t i = 0; i < n; ++i) {
+        float* o = out + (size_t)stride * i;
+        o[0] = geo[i].x; o[1] = geo[i].y; o[2] = geo[i].z; o[3] = geo[i].w; o[4] = misc[i].x;
+        for (uint32_t k = 0; k < C; ++k) {
+            const float* a = reinterpret_cast<const float*>(&fsS[(size_t)(k / 4) * n + i]);
+            const float* b = reinterpret_cast<const float*>(&fsE[(size_t)(k / 4) * n + i]);
+            o[5 + k] = a[k % 4];
+            o[5 + C + k] = b[k % 4];
+        }
+        o[5 + 2 * C] = misc[i].y;
+    }
+    return SLRHIP_OK;
+}
+
 } // extern "C"

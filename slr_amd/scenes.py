@@ -259,6 +259,67 @@ def cornell_lobes(kind, aspect=1.0, segments=16, rings=8):
     return b.build(cornell_camera(aspect), name="cornell_" + kind)
 
 
+MATERIAL_ZOO = ("lambert", "oren_nayar", "mirror", "glass", "ggx_metal_smooth", "ggx_metal_rough", "ggx_glass", "ward", "ashikhmin",
+                "ashikhmin_isotropic", "emitter_over_lambert")
+
+
+def material_zoo():
+    """One material per lobe (and parameter regime) the integrator supports, for the function-level BSDF known-answer
+    tests: a closed Cornell box (so the scene is valid for every entry point) with a small quad per material.
+    Returns (scene, {name: material index})."""
+    b = SceneBuilder()
+    cornell_walls(b)
+    one = b.spectrum_grey(1.0)
+    ti = (b.spectrum_ior("Titanium", 0, TITANIUM_ETA_RGB), b.spectrum_ior("Titanium", 1, TITANIUM_K_RGB))
+    air, bk7 = b.spectrum_ior("Air", 0, AIR_ETA_RGB), b.spectrum_ior("Glass_BK7", 0, BK7_ETA_RGB)
+    mats = {
+        "lambert": b.matte(b.spectrum_srgb_nonlinear(0.75, 0.5, 0.25)),
+        "oren_nayar": b.matte(b.spectrum_srgb_nonlinear(0.7, 0.6, 0.3), sigma=0.6),
+        "mirror": b.metal(one, b.spectrum_ior("Aluminium", 0, ALUMINIUM_ETA_RGB), b.spectrum_ior("Aluminium", 1, ALUMINIUM_K_RGB)),
+        "glass": b.glass(b.spectrum_grey(0.999), air, bk7),
+        "ggx_metal_smooth": b.microfacet_metal(ti[0], ti[1], 0.05),
+        "ggx_metal_rough": b.microfacet_metal(ti[0], ti[1], 0.5),
+        "ggx_glass": b.microfacet_glass(air, bk7, 0.2),
+        "ward": b.ward(b.spectrum_srgb_nonlinear(0.8, 0.7, 0.4), 0.15, 0.4),
+        "ashikhmin": b.ashikhmin(b.spectrum_srgb_nonlinear(0.6, 0.25, 0.2), b.spectrum_grey(0.05), 100.0, 20.0),
+        "ashikhmin_isotropic": b.ashikhmin(b.spectrum_srgb_nonlinear(0.3, 0.5, 0.2), b.spectrum_grey(0.2), 30.0, 30.0),
+        "emitter_over_lambert": b.matte(b.spectrum_srgb_nonlinear(0.9, 0.9, 0.9), emittance=b.spectrum_d65(2.0, D65_RGB)),
+    }
+    assert tuple(mats) == MATERIAL_ZOO
+    for i, m in enumerate(mats.values()):
+        x = -1.2 + 0.22 * i
+        b.add_quad([(x, 0.01, 0.0), (x + 0.2, 0.01, 0.0), (x + 0.2, 0.01, -0.2), (x, 0.01, -0.2)], (0, 1, 0), (1, 0, 0), m)
+    return b.build(cornell_camera(1.0), name="material_zoo"), mats
+
+
+def bsdf_queries(n=256, seed=2024):
+    """[n][12] query rows for slrhip_bsdf_queries / the oracle's bsdf_kat: outgoing direction, geometric normal (tilted up
+    to ~30 degrees off the shading normal) and incoming direction in the shading frame, plus the three sample numbers.
+    Both sides of the surface; the first rows are the special cases: exactly along +-z, grazing, dirIn = dirOut,
+    dirIn = mirror of dirOut, and sample numbers at 0 and just below 1."""
+    r = np.random.default_rng(seed)
+
+    def dirs(k):
+        v = r.normal(size=(k, 3))
+        return v / np.linalg.norm(v, axis=1, keepdims=True)
+    do, di = dirs(n), dirs(n)
+    gn = np.tile([0.0, 0.0, 1.0], (n, 1)) + 0.25 * r.normal(size=(n, 3))
+    gn /= np.linalg.norm(gn, axis=1, keepdims=True)
+    u = r.random(size=(n, 3))
+    do[0:4] = (0, 0, 1)
+    do[4:8] = (0, 0, -1)
+    di[8:12] = (0, 0, 1)
+    do[12:20, 2] *= 1e-3                                           # grazing outgoing directions
+    do[12:20] /= np.linalg.norm(do[12:20], axis=1, keepdims=True)
+    di[20:24] = do[20:24]                                          # retro-reflection
+    di[24:32] = do[24:32] * (-1, -1, 1)                            # the mirror direction
+    di[32:36] = -do[32:36]                                         # straight through
+    u[36:40] = 0.0
+    u[40:44] = np.float32(1.0) - np.float32(2.0 ** -24)
+    gn[44:48] = (0, 0, 1)
+    return np.concatenate([do, gn, di, u], axis=1).astype(np.float32)
+
+
 def cornell_box_boxes(aspect=1.0):
     """Config 3 of BASELINE.json, RGB variant: Cornell_Box_Boxes-shaped scene (TestScenes/Cornell_Box_Boxes.txt:7-53):
     white/red/blue walls, 0.5 x 0.5 light at y = 0.999 scaled to this box, two boxes: a GGX titanium conductor

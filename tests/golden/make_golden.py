@@ -70,6 +70,26 @@ def make(name, sc, lib, width, height, spp, serial_spp):
     print(name, "framebuffer mean", fb.mean(), "hits", int((hits["triangle"] != 0xFFFFFFFF).sum()), "/", len(hits))
 
 
+KAT_WAVELENGTHS = ((0.37, 0.61), (0.0, 0.0), (0.93, 0.9999))    # (offset, uLambda) of createWithEqualOffsets
+
+
+def make_bsdf_kat(name, lib):
+    """Function-level known answers (SURVEY 8c): BSDF::sample / evaluate / evaluatePDF of the reference's own BSDF objects,
+    one material per lobe, 192 queries (scenes.bsdf_queries) under three wavelength selections."""
+    if lib is None:
+        raise SystemExit("reference library for %s not built" % name)
+    sc, mats = scenes.material_zoo()
+    ref = lib.scene(sc)
+    q = scenes.bsdf_queries(192, 2024)
+    out = dict(scene_arrays(sc))
+    out.update(queries=q, wavelengths=np.array(KAT_WAVELENGTHS, np.float32), material_names=np.array(list(mats)),
+               material_indices=np.array(list(mats.values()), np.uint32))
+    for mname, m in mats.items():
+        out["out_" + mname] = np.stack([ref.bsdf_kat(m, q, off, ul) for off, ul in KAT_WAVELENGTHS])
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, {k: int((out["out_" + k][0][:, 3] != 0).sum()) for k in mats})
+
+
 def main():
     only = sys.argv[1:]
     if only:
@@ -99,6 +119,8 @@ def main():
         bmp = np.frombuffer(open(path, "rb").read(), dtype=np.uint8)
     np.savez_compressed(os.path.join(HERE, "tonemap_bmp.npz"), framebuffer=fb, sensitivity=np.float32(509.29581),
                         scale=np.float32(0.37), bmp=bmp)
+    if not only or "bsdf_kat_rgb" in only:
+        make_bsdf_kat("bsdf_kat_rgb", lib)
     make("rgb_tiny_box", scenes.tiny_box(1.0), lib, 32, 32, 8, 2)
     make("rgb_cornell_glass", scenes.cornell_box_spheres(4.0 / 3.0, 16, 8, "glass"), lib, 48, 36, 8, 2)
     make("rgb_oren_nayar", scenes.cornell_lobes("oren_nayar"), lib, 40, 40, 8, 2)
@@ -121,6 +143,8 @@ def main():
             bmp16 = np.frombuffer(open(path, "rb").read(), dtype=np.uint8)
         np.savez_compressed(os.path.join(HERE, "tonemap_bmp_spectral.npz"), framebuffer=fb16, sensitivity=np.float32(509.29581),
                             scale=np.float32(0.41), bmp=bmp16)
+    if not only or "bsdf_kat_spectral" in only:
+        make_bsdf_kat("bsdf_kat_spectral", spec)
     make("spectral_cornell_glass", scenes.cornell_box_spheres(1.0, 12, 6, "glass"), spec, 32, 32, 8, 2)
     make("spectral_cornell_matte", scenes.cornell_box_spheres(1.0, 12, 6, "matte"), spec, 32, 32, 8, 2)
     make("spectral_oren_nayar", scenes.cornell_lobes("oren_nayar", segments=10, rings=5), spec, 32, 32, 8, 2)

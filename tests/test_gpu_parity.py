@@ -370,3 +370,69 @@ def test_spectral_mode_rejects_rgb_only_spectra(sctx):
     b.add_uv_sphere(8, 4, b.matte(b.spectrum_rgb(0.5, 0.5, 0.5)), scenes._translate(0, 0.5, 0) @ scenes._scale(0.4))
     with pytest.raises(SlrHipError):
         sctx.upload_scene(b.build(scenes.cornell_camera(1.0)))
+
+
+# ---- function-level parity: the device BSDF functions against the reference's known answers --------------------------
+LIBM_FREE_LOBES = ("lambert", "oren_nayar", "mirror", "glass", "emitter_over_lambert")
+
+
+def _assert_lobe_close(got, want, what, exact_rows_floor, far_fraction, far_rel, worst_rel):
+    """Lobes that call float libm (GGX: acosf, tanf, atan2f, cosf, sinf; Ward: logf, atanf, expf; Ashikhmin: powf, acosf):
+    the device math library and glibc differ in the last ulp, and tan(acos(z)) amplifies that by 1 / z at grazing angles.
+    Stated tolerance: the zero / non-zero pattern (every branch taken) and the sampled lobe type agree on all but
+    `far_fraction` of the rows, at least `exact_rows_floor` of the floats are bit-equal, at most `far_fraction` of the
+    floats are further than `far_rel` relative, none further than `worst_rel`.  Measured on MI355X (tools/bsdf_kat_stats.py):
+    66-91 % bit-equal, 99th percentile 1e-5, worst 2e-3 (a direction 5e-5 off the tangent plane)."""
+    got64, want64 = got.astype(np.float64), want.astype(np.float64)
+    pattern_rows = ((got == 0) != (want == 0)).any(axis=-1)
+    assert pattern_rows.mean() <= far_fraction, (what, "branch pattern differs on", int(pattern_rows.sum()), "rows")
+    ok_rows = ~pattern_rows
+    g, w = got64[ok_rows], want64[ok_rows]
+    assert (g[..., 4] == w[..., 4]).all(), (what, "dirType")
+    exact = (got[ok_rows].view(np.uint32) == want[ok_rows].view(np.uint32)) | ((g == 0) & (w == 0))
+    rel = np.abs(g - w) / np.maximum(np.abs(w), 1e-30)
+    rel[exact] = 0
+    assert exact.mean() >= exact_rows_floor, (what, "bit-equal fraction", float(exact.mean()))
+    assert (rel > far_rel).mean() <= far_fraction, (what, "fraction beyond", far_rel, float((rel > far_rel).mean()))
+    # rows 36-43 of scenes.bsdf_queries put the sample numbers at 0 and 1 - 2^-24: microfacet slopes of +-4096, where
+    # D(m) goes with tan^-4 and one ulp of acosf moves it by tens of percent; they stay in the checks above only
+    regular = np.ones(got.shape[:-1], bool)
+    regular[..., 36:44] = False
+    rel_regular = rel[regular[ok_rows]]
+    assert rel_regular.max() <= worst_rel, (what, "worst relative difference", float(rel_regular.max()))
+
+
+@pytest.mark.parametrize("mode", ["rgb", "spectral"])
+def test_bsdf_queries_match_golden_and_oracle(mode):
+    """slrhip_bsdf_queries runs the same device functions k_logic calls.  Against the compiled reference's answers
+    (tests/golden/bsdf_kat_*.npz) and, on 4096 fresh queries per lobe, against the oracle.  Lobes without float libm
+    calls: every float bit-exact.  The others: the tolerance stated in _assert_lobe_close."""
+    g = load_golden("bsdf_kat_" + mode)
+    amode = abi.MODE_RGB if mode == "rgb" else abi.MODE_SPECTRAL
+    scene = scene_from_golden(g)
+    c = Context(device=0, mode=amode)
+    try:
+        c.upload_scene(scene)
+        o = ob.load("oracle", amode).scene(scene)
+        fresh = scenes.bsdf_queries(4096, 31)
+        for name, m in zip(g["material_names"], g["material_indices"]):
+            name, m = str(name), int(m)
+            got = np.stack([c.bsdf_queries(m, g["queries"], float(off), float(ul)) for off, ul in g["wavelengths"]])
+            got_fresh, want_fresh = c.bsdf_queries(m, fresh, 0.71, 0.33), o.bsdf_kat(m, fresh, 0.71, 0.33)
+            if name in LIBM_FREE_LOBES:
+                assert_bit_equal(got, g["out_" + name], "%s %s vs golden" % (mode, name))
+                assert_bit_equal(got_fresh, want_fresh, "%s %s vs oracle" % (mode, name))
+            else:
+                _assert_lobe_close(got, g["out_" + name], "%s %s vs golden" % (mode, name), 0.5, 0.01, 1e-4, 1e-2)
+                _assert_lobe_close(got_fresh, want_fresh, "%s %s vs oracle" % (mode, name), 0.5, 0.01, 1e-4, 5e-2)
+    finally:
+        c.close()
+
+
+def test_bsdf_queries_reject_bad_arguments(ctx):
+    ctx.upload_scene(scenes.tiny_box(1.0))
+    q = scenes.bsdf_queries(4, 1)
+    with pytest.raises(Exception, match="material index"):
+        ctx.bsdf_queries(10_000, q)
+    with pytest.raises(Exception, match="wl_offset"):
+        ctx.bsdf_queries(0, q, 1.0, 0.5)
