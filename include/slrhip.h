@@ -124,8 +124,22 @@ enum {
     SLRHIP_MATERIAL_WARD = 5,
     /* AshikhminShirleyReflection SurfaceMaterials/AshikhminShirleyReflection.cpp:14-20 -> AshikhminShirleyBRDF
      * (BSDFs/AshikhminShirleyBRDF.cpp:12-170).  spectrum = {Rs, Rd, -}, param = nu, param2 = nv.            */
-    SLRHIP_MATERIAL_ASHIKHMIN = 6
+    SLRHIP_MATERIAL_ASHIKHMIN = 6,
+    /* SummedSurfaceMaterial / MixedSurfaceMaterial (SurfaceMaterials/SummedSurfaceMaterial.cpp:13-20,
+     * MixedSurfaceMaterial.cpp:14-22) -> MultiBSDF (BSDFs/MultiBSDF.cpp:12-217) over two component BSDFs, either
+     * of which may be wrapped in InverseBSDF (InverseSurfaceMaterial basic_SurfaceMaterials.cpp:47-50,
+     * basic_BSDFs.cpp:172-203).
+     *   spectrum[0], spectrum[1] = indices of the two component MATERIALS: earlier entries of the material
+     *                              table, single-lobe types; their emittance is ignored
+     *   spectrum[2]              = SLRHIP_MULTI_INVERSE_0 | SLRHIP_MULTI_INVERSE_1 bits
+     *   param, param2            = the `scale` each component's getBSDF receives: 1, 1 for "sum";
+     *                              1 - f, f for "mix" with a constant factor f
+     * InverseBSDF is limited to the reflection-only lobes (MATTE, METAL, MICROFACET_METAL, WARD, ASHIKHMIN):
+     * the two-sided lobes read query.flags inside sampleInternal, which this path fixes at All.             */
+    SLRHIP_MATERIAL_MULTI = 7
 };
+#define SLRHIP_MULTI_INVERSE_0 1
+#define SLRHIP_MULTI_INVERSE_1 2
 typedef struct slrhip_material {
     uint32_t type;
     int32_t spectrum[3];   /* indices into slrhip_scene_desc::spectra, -1 = unused          */

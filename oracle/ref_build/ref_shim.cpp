@@ -44,6 +44,8 @@
 #include "SurfaceMaterials/IBLEmission.h"
 #include "SurfaceMaterials/AshikhminShirleyReflection.h"
 #include "SurfaceMaterials/MicrofacetSurfaceMaterial.h"
+#include "SurfaceMaterials/MixedSurfaceMaterial.h"
+#include "SurfaceMaterials/SummedSurfaceMaterial.h"
 #include "SurfaceMaterials/ModifiedWardDurReflection.h"
 #include "SurfaceMaterials/basic_SurfaceMaterials.h"
 #include "Textures/constant_textures.h"
@@ -115,6 +117,7 @@ struct slr_oracle_scene {
     std::vector<FloatTexture*> floatTextures;
     std::vector<SurfaceMaterial*> materials;
     std::vector<SurfaceMaterial*> ownedMaterials;
+    std::vector<const SurfaceMaterial*> baseMaterials;   // per scene material, without the emitter wrapper
     std::vector<EmitterSurfaceProperty*> emitters;
     std::vector<SVFresnel*> fresnels;
     std::vector<SVMicrofacetDistribution*> mfDists;
@@ -222,10 +225,32 @@ slr_oracle_scene* slr_ref_create(const slrhip_scene_desc* d, int mode) {
             base = new AshikhminShirleyReflection(tex(m.spectrum[0]), tex(m.spectrum[1]), nu, nv);      // (Rs, Rd, nu, nv)
             break;
         }
+        case SLRHIP_MATERIAL_MULTI: {
+            // the reference's own factories: InverseSurfaceMaterial, then SummedSurfaceMaterial (scales 1, 1) or
+            // MixedSurfaceMaterial with a constant factor (scales 1 - f, f)
+            const SurfaceMaterial* c[2];
+            for (int k = 0; k < 2; ++k) {
+                if (m.spectrum[k] < 0 || (uint32_t)m.spectrum[k] >= i) { delete s; return nullptr; }
+                c[k] = s->baseMaterials[m.spectrum[k]];
+                if ((m.spectrum[2] >> k) & 1) {
+                    SurfaceMaterial* inv = new InverseSurfaceMaterial(c[k]);
+                    s->ownedMaterials.push_back(inv);
+                    c[k] = inv;
+                }
+            }
+            if (m.param == 1.0f && m.param2 == 1.0f) base = new SummedSurfaceMaterial(c[0], c[1]);
+            else {
+                if (1.0f - m.param2 != m.param) { delete s; return nullptr; }
+                FloatTexture* f = new ConstantFloatTexture(m.param2); s->floatTextures.push_back(f);
+                base = new MixedSurfaceMaterial(c[0], c[1], f);
+            }
+            break;
+        }
         default:
             delete s;
             return nullptr;
         }
+        s->baseMaterials.push_back(base);
         s->ownedMaterials.push_back(base);
         if (m.emittance >= 0) {
             EmitterSurfaceProperty* e = new DiffuseEmission(tex(m.emittance));

@@ -108,6 +108,15 @@ inline float importance(const Spec<N>& s, uint16_t selectedLambda) {
     return sum * marginal + s.c[selectedLambda] * (primary - marginal);
 }
 
+// luminance(): RGBTypes.h:94-100 (double coefficients, float result) / SpectrumTypes.h:504-509 (mean of the samples)
+template <int N>
+inline float luminance(const Spec<N>& s) {
+    if (N == 3) return (float)(0.222485 * s.c[0] + 0.716905 * s.c[1] + 0.060610 * s.c[2]);
+    float sum = 0;
+    for (int i = 0; i < N; ++i) sum += s.c[i];
+    return sum / N;
+}
+
 // WavelengthSamples: RGBSamplesTemplate (RGBTypes.h:19-48) / WavelengthSamplesTemplate (SpectrumTypes.h:17-65)
 template <int N>
 struct Wls {
@@ -1164,12 +1173,9 @@ Spec<N> bsdfSample(const BSDF<N>& f, const BSDFQuery<N>& q, float uComponent, co
     return fs_sn * snCorrection;
 }
 
-// DDF.h:247-267  BSDF::evaluate
+// evaluateInternal of each lobe; `flags` = the query's flags after the caller's side test.
 template <int N>
-Spec<N> bsdfEvaluate(const BSDF<N>& f, const BSDFQuery<N>& q, V3 dir) {
-    bool reflect = dot(q.gNormal_sn, q.dir_sn) * dot(q.gNormal_sn, dir) > 0;      // sideTest DDF.h:213-216
-    uint32_t flags = q.flags & (DT_AllFreq | (reflect ? DT_Reflection : DT_Transmission));
-    if (!dtMatches(f.type, flags)) return Spec<N>();
+Spec<N> bsdfEvaluateInternal(const BSDF<N>& f, const BSDFQuery<N>& q, uint32_t flags, V3 dir) {
     Spec<N> fs_sn;
     switch (f.kind) {
     case SLRHIP_MATERIAL_MATTE:
@@ -1249,14 +1255,27 @@ Spec<N> bsdfEvaluate(const BSDF<N>& f, const BSDFQuery<N>& q, V3 dir) {
         fs_sn = Spec<N>();
         break;
     }
+    return fs_sn;
+}
+
+inline uint32_t sideTest(V3 ng, V3 d0, V3 d1) {      // DDF.h:209-212
+    bool reflect = dot(ng, d0) * dot(ng, d1) > 0;
+    return DT_AllFreq | (reflect ? DT_Reflection : DT_Transmission);
+}
+
+// DDF.h:247-267  BSDF::evaluate
+template <int N>
+Spec<N> bsdfEvaluate(const BSDF<N>& f, const BSDFQuery<N>& q, V3 dir) {
+    uint32_t flags = q.flags & sideTest(q.gNormal_sn, q.dir_sn, dir);
+    if (!dtMatches(f.type, flags)) return Spec<N>();
+    Spec<N> fs_sn = bsdfEvaluateInternal(f, q, flags, dir);
     float snCorrection = std::fabs(dir.z / dot(dir, q.gNormal_sn));
     return fs_sn * snCorrection;
 }
 
-// DDF.h:268-279  BSDF::evaluatePDF
+// evaluatePDFInternal of each lobe
 template <int N>
-float bsdfEvaluatePDF(const BSDF<N>& f, const BSDFQuery<N>& q, V3 dir) {
-    if (!dtMatches(f.type, q.flags)) return 0;
+float bsdfEvaluatePDFInternal(const BSDF<N>& f, const BSDFQuery<N>& q, V3 dir) {
     switch (f.kind) {
     case SLRHIP_MATERIAL_MATTE:
         // basic_BSDFs.cpp:41-50, OrenNayerBRDF.cpp:58-66 (identical)
@@ -1328,11 +1347,194 @@ float bsdfEvaluatePDF(const BSDF<N>& f, const BSDFQuery<N>& q, V3 dir) {
     }
 }
 
+// DDF.h:268-279  BSDF::evaluatePDF
+template <int N>
+float bsdfEvaluatePDF(const BSDF<N>& f, const BSDFQuery<N>& q, V3 dir) {
+    if (!dtMatches(f.type, q.flags)) return 0;
+    return bsdfEvaluatePDFInternal(f, q, dir);
+}
+
+// weightInternal of each lobe, and BSDF::weight (DDF.h:280-289; non-adjoint: no correction)
+template <int N>
+float bsdfWeight(const BSDF<N>& f, const BSDFQuery<N>& q) {
+    if (!dtMatches(f.type, q.flags)) return 0;
+    switch (f.kind) {
+    case SLRHIP_MATERIAL_MATTE:
+        // LambertianBRDF basic_BSDFs.cpp:51-53: importance;  OrenNayerBRDF.cpp:67-69: luminance
+        return f.param >= 0.0f ? luminance(f.a) : importance(f.a, (uint16_t)q.wlHint);
+    case SLRHIP_MATERIAL_METAL:      // basic_BSDFs.cpp:85-87
+        return importance(f.a, (uint16_t)q.wlHint) * importance(fresnelConductor(f.b, f.c, q.dir_sn.z), (uint16_t)q.wlHint);
+    case SLRHIP_MATERIAL_GLASS:      // basic_BSDFs.cpp:163-165
+        return importance(f.a, (uint16_t)q.wlHint);
+    case SLRHIP_MATERIAL_MICROFACET_METAL:
+    case SLRHIP_MATERIAL_MICROFACET_GLASS: {    // MicrofacetBSDF.cpp:102-106, 307-311
+        GGX D_ = {f.param};
+        bool entering = q.dir_sn.z >= 0.0f;
+        int32_t sign = entering ? 1 : -1;
+        return D_.evaluateSmithG1(q.dir_sn * (float)sign, V3(0, 0, 1));
+    }
+    case SLRHIP_MATERIAL_WARD:       // ModifiedWardDurBRDF.cpp:80-82
+        return importance(f.a, (uint16_t)q.wlHint);
+    case SLRHIP_MATERIAL_ASHIKHMIN: {           // AshikhminShirleyBRDF.cpp:156-165
+        float specularWeight, diffuseWeight;
+        ashikhminWeights(f, q.wlHint, std::fabs(q.dir_sn.z), &specularWeight, &diffuseWeight);
+        return specularWeight + diffuseWeight;
+    }
+    default:
+        return 0.0f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// MultiBSDF over (optionally inverted) lobes: BSDFs/MultiBSDF.cpp, InverseBSDF basic_BSDFs.cpp:172-203
+// ------------------------------------------------------------------------------------------
+template <int N>
+struct AnyBSDF {
+    uint32_t type;        // m_type: a single lobe's, or the union of the components' (MultiBSDF.cpp:16)
+    int n;                // 0: lobe[0] is the whole BSDF;  2: MultiBSDF of two components
+    BSDF<N> lobe[2];
+    bool inverse[2];      // component i is InverseBSDF(lobe[i])
+};
+inline uint32_t dtFlip(uint32_t t) { return t ^ DT_WholeSphere; }        // DDF.h:79
+
+// The component's BSDF interface as MultiBSDF sees it (m_type, weight(), the three *Internal calls).
+template <int N>
+struct Component {
+    const BSDF<N>& base;
+    bool inverse;
+    uint32_t type() const { return inverse ? dtFlip(base.type) : base.type; }                     // basic_BSDFs.h:71
+    bool matches(uint32_t flags) const { return dtMatches(type(), flags); }
+    float weight(const BSDFQuery<N>& q) const {                                                   // DDF.h:280-289
+        if (!matches(q.flags)) return 0;
+        if (!inverse) return bsdfWeight(base, q);       // matches() was checked with the same type
+        BSDFQuery<N> mq = q;                            // InverseBSDF::weightInternal :199-203
+        mq.flags = dtFlip(mq.flags);
+        return bsdfWeight(base, mq);
+    }
+    Spec<N> sampleInternal(const BSDFQuery<N>& q, float uComponent, const float uDir[2], BSDFResult* result) const {
+        if (!inverse) return bsdfSampleInternal(base, q, uComponent, uDir, result);
+        BSDFQuery<N> mq = q;                            // InverseBSDF::sampleInternal :172-181 (calls the public sample())
+        mq.flags = dtFlip(mq.flags);
+        Spec<N> ret = bsdfSample(base, mq, uComponent, uDir, result);
+        result->dirType = dtFlip(result->dirType);
+        result->dir_sn.z *= -1;
+        return ret;
+    }
+    Spec<N> evaluateInternal(const BSDFQuery<N>& q, uint32_t flags, V3 dir) const {
+        if (!inverse) return bsdfEvaluateInternal(base, q, flags, dir);
+        BSDFQuery<N> mq = q;                            // InverseBSDF::evaluateInternal :183-189 (public evaluate())
+        mq.flags = dtFlip(flags);
+        V3 mDir = dir;
+        mDir.z *= -1;
+        return bsdfEvaluate(base, mq, mDir);
+    }
+    float evaluatePDFInternal(const BSDFQuery<N>& q, V3 dir) const {
+        if (!inverse) return bsdfEvaluatePDFInternal(base, q, dir);
+        V3 mDir = dir;                                  // InverseBSDF::evaluatePDFInternal :191-197: `mQuery.flags.flip();`
+        mDir.z *= -1;                                   // discards its result, so the flags go through unflipped
+        return bsdfEvaluatePDF(base, q, mDir);
+    }
+};
+
+// Core/distributions.cpp:14-29 (compensated sums; for two items they equal the plain float sums)
+inline uint32_t sampleDiscrete(const float* importances, float* sumImportances, float* base, uint32_t n, float u) {
+    Kahan<float> sum;
+    for (uint32_t i = 0; i < n; ++i) sum.add(importances[i]);
+    *sumImportances = sum.result;
+    float su = u * sum.result;
+    Kahan<float> cum;
+    for (uint32_t i = 0; i < n; ++i) {
+        *base = cum.result;
+        cum.add(importances[i]);
+        if (su < cum.result) return i;
+    }
+    return 0;
+}
+
+// MultiBSDF::sampleInternalNoRev  MultiBSDF.cpp:20-59
+template <int N>
+Spec<N> multiSampleInternal(const AnyBSDF<N>& f, const BSDFQuery<N>& q, float uComponent, const float uDir[2], BSDFResult* result) {
+    const Component<N> c[2] = {{f.lobe[0], f.inverse[0]}, {f.lobe[1], f.inverse[1]}};
+    float weights[2];
+    for (int i = 0; i < f.n; ++i) weights[i] = c[i].weight(q);
+    float sumWeights, base;
+    uint32_t idx = sampleDiscrete(weights, &sumWeights, &base, (uint32_t)f.n, uComponent);
+    if (sumWeights == 0.0f) { result->dirPDF = 0.0f; return Spec<N>(); }
+    uComponent = (uComponent * sumWeights - base) / weights[idx];
+    result->dirPDF = 0.0f;
+    Spec<N> value = c[idx].sampleInternal(q, uComponent, uDir, result);
+    result->dirPDF *= weights[idx];
+    if (result->dirPDF == 0.0f) return Spec<N>();
+    if (!dtIsDelta(result->dirType)) {
+        for (int i = 0; i < f.n; ++i)
+            if (i != (int)idx && c[i].matches(q.flags))
+                result->dirPDF += c[i].evaluatePDFInternal(q, result->dir_sn) * weights[i];
+        uint32_t mflags = q.flags & sideTest(q.gNormal_sn, q.dir_sn, result->dir_sn);
+        value = Spec<N>();
+        for (int i = 0; i < f.n; ++i) {
+            if (!c[i].matches(mflags)) continue;
+            value = value + c[i].evaluateInternal(q, mflags, result->dir_sn);
+        }
+    }
+    result->dirPDF /= sumWeights;
+    return value;
+}
+// MultiBSDF::evaluateInternal :125-149, evaluatePDFInternalNoRev :151-169
+template <int N>
+Spec<N> multiEvaluateInternal(const AnyBSDF<N>& f, const BSDFQuery<N>& q, uint32_t flags, V3 dir) {
+    const Component<N> c[2] = {{f.lobe[0], f.inverse[0]}, {f.lobe[1], f.inverse[1]}};
+    Spec<N> ret;
+    for (int i = 0; i < f.n; ++i) {
+        if (!c[i].matches(flags)) continue;
+        ret = ret + c[i].evaluateInternal(q, flags, dir);
+    }
+    return ret;
+}
+template <int N>
+float multiEvaluatePDFInternal(const AnyBSDF<N>& f, const BSDFQuery<N>& q, V3 dir) {
+    const Component<N> c[2] = {{f.lobe[0], f.inverse[0]}, {f.lobe[1], f.inverse[1]}};
+    Kahan<float> sumWeights;
+    float weights[2];
+    for (int i = 0; i < f.n; ++i) { weights[i] = c[i].weight(q); sumWeights.add(weights[i]); }
+    if (sumWeights.result == 0.0f) return 0.0f;
+    float retPDF = 0.0f;
+    for (int i = 0; i < f.n; ++i)
+        if (weights[i] > 0) retPDF += c[i].evaluatePDFInternal(q, dir) * weights[i];
+    retPDF /= sumWeights.result;
+    return retPDF;
+}
+
+// The public BSDF interface (DDF.h:231-279) on either kind
+template <int N>
+Spec<N> bsdfSample(const AnyBSDF<N>& f, const BSDFQuery<N>& q, float uComponent, const float uDir[2], BSDFResult* result) {
+    if (f.n == 0) return bsdfSample(f.lobe[0], q, uComponent, uDir, result);
+    if (!dtMatches(f.type, q.flags)) { result->dirPDF = 0.0f; result->dirType = 0; return Spec<N>(); }
+    Spec<N> fs_sn = multiSampleInternal(f, q, uComponent, uDir, result);
+    if (result->dirPDF == 0.0f) return Spec<N>();
+    float snCorrection = std::fabs(result->dir_sn.z / dot(result->dir_sn, q.gNormal_sn));
+    return fs_sn * snCorrection;
+}
+template <int N>
+Spec<N> bsdfEvaluate(const AnyBSDF<N>& f, const BSDFQuery<N>& q, V3 dir) {
+    if (f.n == 0) return bsdfEvaluate(f.lobe[0], q, dir);
+    uint32_t flags = q.flags & sideTest(q.gNormal_sn, q.dir_sn, dir);
+    if (!dtMatches(f.type, flags)) return Spec<N>();
+    Spec<N> fs_sn = multiEvaluateInternal(f, q, flags, dir);
+    float snCorrection = std::fabs(dir.z / dot(dir, q.gNormal_sn));
+    return fs_sn * snCorrection;
+}
+template <int N>
+float bsdfEvaluatePDF(const AnyBSDF<N>& f, const BSDFQuery<N>& q, V3 dir) {
+    if (f.n == 0) return bsdfEvaluatePDF(f.lobe[0], q, dir);
+    if (!dtMatches(f.type, q.flags)) return 0;
+    return multiEvaluatePDFInternal(f, q, dir);
+}
+
 // SurfacePoint::createBSDF (geometry.cpp:56-58) -> SurfaceMaterial::getBSDF
 // (basic_SurfaceMaterials.cpp:15-43; EmitterSurfaceMaterial forwards to its base material,
 //  surface_material.h:65).  `scale * spectrum` with scale = 1.0f is an exact multiply.
 template <int N>
-BSDF<N> createBSDFOf(const Scene& s, const slrhip_material& m, const Wls<N>& wls) {
+BSDF<N> createLobe(const Scene& s, const slrhip_material& m, const Wls<N>& wls, float scale) {
     const uint16_t wlFlags = wls.flags;
     BSDF<N> f;
     f.kind = m.type;
@@ -1342,16 +1544,16 @@ BSDF<N> createBSDFOf(const Scene& s, const slrhip_material& m, const Wls<N>& wls
     switch (m.type) {
     case SLRHIP_MATERIAL_WARD:
         f.type = DT_Reflection | DT_HighFreq;                                  // ModifiedWardDurBRDF.h:29
-        f.a = 1.0f * EvalSpectrum<N>::eval(s, m.spectrum[0], wls);
+        f.a = scale * EvalSpectrum<N>::eval(s, m.spectrum[0], wls);
         break;
     case SLRHIP_MATERIAL_ASHIKHMIN:
         f.type = DT_Reflection | DT_HighFreq | DT_LowFreq;                     // AshikhminShirleyBRDF.h:29
-        f.a = 1.0f * EvalSpectrum<N>::eval(s, m.spectrum[0], wls);             // scale * Rs
-        f.b = 1.0f * EvalSpectrum<N>::eval(s, m.spectrum[1], wls);             // scale * Rd
+        f.a = scale * EvalSpectrum<N>::eval(s, m.spectrum[0], wls);             // scale * Rs
+        f.b = scale * EvalSpectrum<N>::eval(s, m.spectrum[1], wls);             // scale * Rd
         break;
     case SLRHIP_MATERIAL_MATTE:
         f.type = DT_Reflection | DT_LowFreq;                                   // basic_BSDFs.h:27, OrenNayerBRDF.h:29
-        f.a = 1.0f * EvalSpectrum<N>::eval(s, m.spectrum[0], wls);
+        f.a = scale * EvalSpectrum<N>::eval(s, m.spectrum[0], wls);
         if (m.param >= 0.0f) {                                                 // OrenNayerBRDF.h:28-30 (double literals)
             float sigma = m.param;
             f.onA = (float)(1.0f - 0.5f * sigma * sigma / (sigma * sigma + 0.33));
@@ -1370,14 +1572,14 @@ BSDF<N> createBSDFOf(const Scene& s, const slrhip_material& m, const Wls<N>& wls
         break;
     case SLRHIP_MATERIAL_METAL:
         f.type = DT_Reflection | DT_Delta0D;                                   // basic_BSDFs.h:43
-        f.a = 1.0f * EvalSpectrum<N>::eval(s, m.spectrum[0], wls);
+        f.a = scale * EvalSpectrum<N>::eval(s, m.spectrum[0], wls);
         f.b = EvalSpectrum<N>::eval(s, m.spectrum[1], wls);
         f.c = EvalSpectrum<N>::eval(s, m.spectrum[2], wls);
         break;
     case SLRHIP_MATERIAL_GLASS:
         // dispersive = !wls.lambdaSelected()  basic_SurfaceMaterials.cpp:42, basic_BSDFs.h:59-61
         f.type = DT_Reflection | DT_Transmission | DT_Delta0D | ((wlFlags & 1) ? 0u : (uint32_t)DT_Dispersive);
-        f.a = 1.0f * EvalSpectrum<N>::eval(s, m.spectrum[0], wls);
+        f.a = scale * EvalSpectrum<N>::eval(s, m.spectrum[0], wls);
         f.b = EvalSpectrum<N>::eval(s, m.spectrum[1], wls);
         f.c = EvalSpectrum<N>::eval(s, m.spectrum[2], wls);
         break;
@@ -1388,8 +1590,30 @@ BSDF<N> createBSDFOf(const Scene& s, const slrhip_material& m, const Wls<N>& wls
     return f;
 }
 
+// SummedSurfaceMaterial.cpp:13-20 / MixedSurfaceMaterial.cpp:14-22 / InverseSurfaceMaterial basic_SurfaceMaterials.cpp:47-50
 template <int N>
-inline BSDF<N> createBSDF(const Scene& s, const SurfPt& sp, const Wls<N>& wls) { return createBSDFOf<N>(s, s.materials[s.tris[sp.tri].material], wls); }
+AnyBSDF<N> createBSDFOf(const Scene& s, const slrhip_material& m, const Wls<N>& wls) {
+    AnyBSDF<N> f;
+    f.inverse[0] = f.inverse[1] = false;
+    if (m.type != SLRHIP_MATERIAL_MULTI) {
+        f.n = 0;
+        f.lobe[0] = createLobe<N>(s, m, wls, 1.0f);
+        f.lobe[1] = f.lobe[0];
+        f.type = f.lobe[0].type;
+        return f;
+    }
+    f.n = 2;
+    f.type = 0;
+    const float scales[2] = {1.0f * m.param, 1.0f * m.param2};      // `scale * (1.0f - factor)`, `scale * factor` with scale = 1
+    for (int i = 0; i < 2; ++i) {
+        f.lobe[i] = createLobe<N>(s, s.materials[m.spectrum[i]], wls, scales[i]);
+        f.inverse[i] = (m.spectrum[2] >> i) & 1;
+        f.type |= f.inverse[i] ? dtFlip(f.lobe[i].type) : f.lobe[i].type;      // MultiBSDF::add :16, InverseBSDF ctor
+    }
+    return f;
+}
+template <int N>
+inline AnyBSDF<N> createBSDF(const Scene& s, const SurfPt& sp, const Wls<N>& wls) { return createBSDFOf<N>(s, s.materials[s.tris[sp.tri].material], wls); }
 
 inline bool isEmitting(const Scene& s, uint32_t tri) { return tri == kEnvObject || s.materials[s.tris[tri].material].emittance >= 0; }
 template <int N>
@@ -1539,7 +1763,7 @@ Spec<N> contribution(const Scene& scene, const Wls<N>& initWLs, const Ray& initR
         if (pathLength >= 100) break;
         if (ctr) ++ctr->loop_iterations;
         V3 gNorm_sn = surfPt.frame.toLocal(surfPt.gNormal);
-        BSDF<N> bsdf = createBSDF(scene, surfPt, wls);
+        AnyBSDF<N> bsdf = createBSDF(scene, surfPt, wls);
         BSDFQuery<N> fsQuery;
         fsQuery.dir_sn = dirOut_sn; fsQuery.gNormal_sn = gNorm_sn; fsQuery.wlHint = (int16_t)selectedLambda; fsQuery.flags = DT_All;
 
@@ -1734,7 +1958,7 @@ int bsdfKatT(const slr_oracle_scene* s, uint32_t material, uint32_t n, const flo
         wls.lambdas[i] = kWavelengthLowBound + (kWavelengthHighBound - kWavelengthLowBound) * (i + wlOffset) / N;
     wls.selectedLambda = std::min(uint16_t(N * uLambda), uint16_t(N - 1));
     wls.flags = 0;
-    BSDF<N> bsdf = createBSDFOf<N>(*s, s->materials[material], wls);
+    AnyBSDF<N> bsdf = createBSDFOf<N>(*s, s->materials[material], wls);
     const int stride = 6 + 2 * N;
     for (uint32_t i = 0; i < n; ++i) {
         const float* q = in + 12 * (size_t)i;
@@ -1771,6 +1995,19 @@ slr_oracle_scene* slr_oracle_create(const slrhip_scene_desc* d, int mode) {
     s->materials.assign(d->materials, d->materials + d->num_materials);
     if (d->spectra) s->spectra.assign(d->spectra, d->spectra + d->num_spectra);
     if (d->spectrum_data) s->spectrumData.assign(d->spectrum_data, d->spectrum_data + d->num_spectrum_data);
+    for (uint32_t i = 0; i < d->num_materials; ++i) {          // the restrictions include/slrhip.h states for MULTI
+        const slrhip_material& m = s->materials[i];
+        if (m.type != SLRHIP_MATERIAL_MULTI) continue;
+        bool ok = (uint32_t)m.spectrum[2] <= 3u;
+        for (int k = 0; k < 2 && ok; ++k) {
+            ok = m.spectrum[k] >= 0 && (uint32_t)m.spectrum[k] < i && s->materials[m.spectrum[k]].type < SLRHIP_MATERIAL_MULTI;
+            if (ok && ((m.spectrum[2] >> k) & 1)) {
+                uint32_t ct = s->materials[m.spectrum[k]].type;
+                ok = ct != SLRHIP_MATERIAL_GLASS && ct != SLRHIP_MATERIAL_MICROFACET_GLASS;
+            }
+        }
+        if (!ok) { delete s; return nullptr; }
+    }
     s->tris.resize(d->num_triangles);
     std::vector<float> importances;
     for (uint32_t i = 0; i < d->num_triangles; ++i) {

@@ -14,7 +14,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 MODE_RGB, MODE_SPECTRAL = 0, 1
-MAT_MATTE, MAT_METAL, MAT_GLASS, MAT_MF_METAL, MAT_MF_GLASS, MAT_WARD, MAT_ASHIKHMIN = 0, 1, 2, 3, 4, 5, 6
+MAT_MATTE, MAT_METAL, MAT_GLASS, MAT_MF_METAL, MAT_MF_GLASS, MAT_WARD, MAT_ASHIKHMIN, MAT_MULTI = 0, 1, 2, 3, 4, 5, 6, 7
+MULTI_INVERSE_0, MULTI_INVERSE_1 = 1, 2
 SPEC_RGB_ONLY, SPEC_UPSAMPLED, SPEC_REGULAR, SPEC_IRREGULAR = 0, 1, 2, 3
 
 # numpy dtypes with the exact layout of the C structs (checked in tests/test_abi.py)

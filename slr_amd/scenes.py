@@ -106,6 +106,17 @@ class SceneBuilder:
         """createSurfaceMaterial("Ashikhmin", (Rd, Rs, nx, ny)) -> AshikhminShirleyBRDF(Rs, Rd, nu, nv) (API.cpp:537-552)."""
         return self.material(abi.MAT_ASHIKHMIN, (rs, rd, -1), nu, param2=nv)
 
+    def summed(self, m0, m1, inverse=(False, False), emittance=-1):
+        """createSurfaceMaterial("sum", (m0, m1)) -> MultiBSDF of the two components' BSDFs (API.cpp "sum",
+        SummedSurfaceMaterial.cpp:13-20); inverse[i] wraps component i as createSurfaceMaterial("inverse", (m_i,))."""
+        return self.material(abi.MAT_MULTI, (m0, m1, int(bool(inverse[0])) | int(bool(inverse[1])) << 1), 1.0, emittance, 1.0)
+
+    def mixed(self, m0, m1, factor, inverse=(False, False), emittance=-1):
+        """createSurfaceMaterial("mix", (m0, m1, factor)) with a constant factor (MixedSurfaceMaterial.cpp:14-22):
+        the components receive scale 1 - factor and factor."""
+        f = np.float32(factor)
+        return self.material(abi.MAT_MULTI, (m0, m1, int(bool(inverse[0])) | int(bool(inverse[1])) << 1), np.float32(1.0) - f, emittance, f)
+
     def microfacet_metal(self, eta, k, alpha):
         return self.material(abi.MAT_MF_METAL, (-1, eta, k), alpha)
 
@@ -260,7 +271,10 @@ def cornell_lobes(kind, aspect=1.0, segments=16, rings=8):
 
 
 MATERIAL_ZOO = ("lambert", "oren_nayar", "mirror", "glass", "ggx_metal_smooth", "ggx_metal_rough", "ggx_glass", "ward", "ashikhmin",
-                "ashikhmin_isotropic", "emitter_over_lambert")
+                "ashikhmin_isotropic", "emitter_over_lambert",
+                # MultiBSDF (sum / mix / inverse): RTC3.txt:13-18 shape first, then lobes of different kinds side by side
+                "sum_lambert_inverse_lambert", "sum_lambert_ward", "mix_ggx_metal_lambert", "sum_mirror_lambert", "mix_glass_ashikhmin",
+                "sum_oren_nayar_inverse_ggx_metal", "mix_ggx_glass_inverse_ward", "emitter_over_sum")
 
 
 def material_zoo():
@@ -285,10 +299,21 @@ def material_zoo():
         "ashikhmin_isotropic": b.ashikhmin(b.spectrum_srgb_nonlinear(0.3, 0.5, 0.2), b.spectrum_grey(0.2), 30.0, 30.0),
         "emitter_over_lambert": b.matte(b.spectrum_srgb_nonlinear(0.9, 0.9, 0.9), emittance=b.spectrum_d65(2.0, D65_RGB)),
     }
+    thin = b.matte(b.spectrum_srgb_nonlinear(0.2, 0.6, 0.3))
+    mats.update({
+        "sum_lambert_inverse_lambert": b.summed(mats["lambert"], thin, inverse=(False, True)),
+        "sum_lambert_ward": b.summed(mats["lambert"], mats["ward"]),
+        "mix_ggx_metal_lambert": b.mixed(mats["ggx_metal_rough"], mats["lambert"], 0.3),
+        "sum_mirror_lambert": b.summed(mats["mirror"], thin),
+        "mix_glass_ashikhmin": b.mixed(mats["glass"], mats["ashikhmin_isotropic"], 0.625),
+        "sum_oren_nayar_inverse_ggx_metal": b.summed(mats["oren_nayar"], mats["ggx_metal_rough"], inverse=(False, True)),
+        "mix_ggx_glass_inverse_ward": b.mixed(mats["ggx_glass"], mats["ward"], 0.25, inverse=(False, True)),
+        "emitter_over_sum": b.summed(thin, mats["ward"], emittance=b.spectrum_d65(2.0, D65_RGB)),
+    })
     assert tuple(mats) == MATERIAL_ZOO
     for i, m in enumerate(mats.values()):
-        x = -1.2 + 0.22 * i
-        b.add_quad([(x, 0.01, 0.0), (x + 0.2, 0.01, 0.0), (x + 0.2, 0.01, -0.2), (x, 0.01, -0.2)], (0, 1, 0), (1, 0, 0), m)
+        x, z = -1.2 + 0.22 * (i % 11), -0.3 * (i // 11)
+        b.add_quad([(x, 0.01, z), (x + 0.2, 0.01, z), (x + 0.2, 0.01, z - 0.2), (x, 0.01, z - 0.2)], (0, 1, 0), (1, 0, 0), m)
     return b.build(cornell_camera(1.0), name="material_zoo"), mats
 
 
@@ -318,6 +343,26 @@ def bsdf_queries(n=256, seed=2024):
     u[40:44] = np.float32(1.0) - np.float32(2.0 ** -24)
     gn[44:48] = (0, 0, 1)
     return np.concatenate([do, gn, di, u], axis=1).astype(np.float32)
+
+
+def cornell_multi(aspect=1.0, segments=16, rings=8):
+    """MultiBSDF materials in a Cornell box: a sphere of mix(GGX titanium, Lambert; 0.3), a sphere of
+    sum(specular aluminium, Lambert) (a delta and a non-delta component side by side), and a free-standing sheet of
+    sum(Lambert, inverse(Lambert)) — the reflect + diffuse-transmit material of TestScenes/RTC3.txt:13-18."""
+    b = SceneBuilder()
+    cornell_walls(b)
+    ti = b.microfacet_metal(b.spectrum_ior("Titanium", 0, TITANIUM_ETA_RGB), b.spectrum_ior("Titanium", 1, TITANIUM_K_RGB), 0.3)
+    orange = b.matte(b.spectrum_srgb_nonlinear(0.8, 0.45, 0.15))
+    green = b.matte(b.spectrum_srgb_nonlinear(0.2, 0.6, 0.3))
+    grey = b.matte(b.spectrum_srgb_nonlinear(0.5, 0.5, 0.5))
+    al = b.metal(b.spectrum_grey(0.6), b.spectrum_ior("Aluminium", 0, ALUMINIUM_ETA_RGB), b.spectrum_ior("Aluminium", 1, ALUMINIUM_K_RGB))
+    coated = b.mixed(ti, orange, 0.3)
+    lacquer = b.summed(al, grey)
+    leaf = b.summed(grey, green, inverse=(False, True))
+    b.add_uv_sphere(segments, rings, coated, _translate(-0.7, 0, -0.8) @ _scale(0.5) @ _translate(0, 1, 0))
+    b.add_uv_sphere(segments, rings, lacquer, _translate(0.75, 0, -0.2) @ _scale(0.45) @ _translate(0, 1, 0))
+    b.add_quad([(-0.4, 0.0, 0.9), (0.5, 0.0, 0.6), (0.5, 1.3, 0.6), (-0.4, 1.3, 0.9)], (0.316, 0, 0.949), (0.949, 0, -0.316), leaf)
+    return b.build(cornell_camera(aspect), name="cornell_multi")
 
 
 def cornell_box_boxes(aspect=1.0):
