@@ -132,7 +132,8 @@ class Scene:
             raise ValueError("triangle references a vertex out of range")
         if self.triangles["material"].max() >= nm:
             raise ValueError("triangle references a material out of range")
-        if self.materials["spectrum"].max() >= ns or self.materials["emittance"].max() >= ns:
+        single = self.materials["type"] != MAT_MULTI      # a MULTI record's spectrum[] holds component material indices (checked by the library)
+        if (single.any() and self.materials["spectrum"][single].max() >= ns) or self.materials["emittance"].max() >= ns:
             raise ValueError("material references a spectrum out of range")
 
     def upsampling_tables(self):

@@ -88,6 +88,13 @@ struct alignas(16) DevMaterial {
 };
 static_assert(sizeof(DevMaterial) == 80, "DevMaterial layout");
 
+// SLRHIP_MATERIAL_MULTI records (both modes): param / onA = the two components' scales, onB = these bits
+// (component indices into the same table, InverseBSDF flags, the components' material types).
+static const uint32_t kMultiMaxChildIndex = 1023;
+inline uint32_t packMultiBits(uint32_t child0, uint32_t child1, uint32_t inverseBits, uint32_t type0, uint32_t type1) {
+    return child0 | (child1 << 10) | (inverseBits << 20) | (type0 << 22) | (type1 << 25);
+}
+
 // Spectral mode: a material names its constant spectra; they are evaluated at the path's wavelengths per hit
 // (ConstantSpectrumTexture::evaluate, Textures/constant_textures.h:16-31), like the reference does.
 struct alignas(16) DevMaterialS {

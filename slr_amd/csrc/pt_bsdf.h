@@ -315,10 +315,8 @@ SLR_DEV uint32_t bsdfType(uint32_t matType, uint32_t wlFlags) {
 // BSDF::sample (DDF.h:231-246) over sampleInternal of LambertianBRDF / SpecularBRDF / SpecularBSDF
 // (BSDFs/basic_BSDFs.cpp:12-26, 61-71, 95-149); query.flags = All, adjoint = false.
 template <class S, bool MF>
-SLR_DEV S bsdfSample(const Mat<S>& m, uint32_t type, V3 dirOut, V3 gNorm, uint32_t wl, float uComp, float u0, float u1, BsdfSample* res) {
-    res->dirPDF = 0.0f;
-    res->dirType = 0;
-    if (!dtMatches(type, DT_All)) return S();
+SLR_DEV S bsdfSampleInternal(const Mat<S>& m, uint32_t type, V3 dirOut, V3 gNorm, uint32_t wl, float uComp, float u0, float u1, BsdfSample* res) {
+    res->dirPDF = 0.0f;       // every failure path below leaves it so
     S fs_sn;
     switch (m.type) {
     case SLRHIP_MATERIAL_MATTE: {
@@ -491,15 +489,24 @@ SLR_DEV S bsdfSample(const Mat<S>& m, uint32_t type, V3 dirOut, V3 gNorm, uint32
     default:
         return S();
     }
+    return fs_sn;
+}
+// `flags` = query.flags: All on this path, except where InverseBSDF hands a flipped query to its base (pt_bsdf_multi.h)
+template <class S, bool MF>
+SLR_DEV S bsdfSample(const Mat<S>& m, uint32_t type, V3 dirOut, V3 gNorm, uint32_t wl, float uComp, float u0, float u1, BsdfSample* res,
+                     uint32_t flags = DT_All) {
+    res->dirPDF = 0.0f;
+    res->dirType = 0;
+    if (!dtMatches(type, flags)) return S();
+    S fs_sn = bsdfSampleInternal<S, MF>(m, type, dirOut, gNorm, wl, uComp, u0, u1, res);
     if (res->dirPDF == 0.0f) return S();
     float snCorrection = fabsf(res->dir_sn.z / dot(res->dir_sn, gNorm));
     return fs_sn * snCorrection;
 }
 
-// BSDF::evaluatePDF (DDF.h:268-279; query.flags = All) of the lobes that have a non-delta component.
+// evaluatePDFInternal of the lobes that have a non-delta component (the two-sided ones as for query.flags = All).
 template <class S, bool MF>
-SLR_DEV float bsdfEvaluatePDF(const Mat<S>& m, uint32_t type, V3 dirOut, V3 dir, uint32_t wl) {
-    if (!dtMatches(type, DT_All)) return 0.0f;
+SLR_DEV float bsdfEvaluatePDFInternal(const Mat<S>& m, V3 dirOut, V3 dir, uint32_t wl) {
     switch (m.type) {
     case SLRHIP_MATERIAL_MATTE:
         // LambertianBRDF::evaluatePDFInternal basic_BSDFs.cpp:41-50 == OrenNayerBRDF.cpp:58-66
@@ -570,14 +577,21 @@ SLR_DEV float bsdfEvaluatePDF(const Mat<S>& m, uint32_t type, V3 dirOut, V3 dir,
         return 0.0f;
     }
 }
-
-// BSDF::evaluate (DDF.h:247-267) + evaluatePDF for the NEE direction.
+// BSDF::evaluatePDF (DDF.h:268-279)
 template <class S, bool MF>
-SLR_DEV S bsdfEvaluate(const Mat<S>& m, uint32_t type, V3 dirOut, V3 gNorm, V3 dir, uint32_t wl, float* pdf) {
-    *pdf = bsdfEvaluatePDF<S, MF>(m, type, dirOut, dir, wl);
-    bool reflect = dot(gNorm, dirOut) * dot(gNorm, dir) > 0;                       // sideTest DDF.h:213-216
-    uint32_t flags = DT_All & (DT_AllFreq | (reflect ? DT_Reflection : DT_Transmission));
-    if (!dtMatches(type, flags)) return S();
+SLR_DEV float bsdfEvaluatePDF(const Mat<S>& m, uint32_t type, V3 dirOut, V3 dir, uint32_t wl, uint32_t flags = DT_All) {
+    if (!dtMatches(type, flags)) return 0.0f;
+    return bsdfEvaluatePDFInternal<S, MF>(m, dirOut, dir, wl);
+}
+
+SLR_DEV uint32_t sideTest(V3 gNorm, V3 d0, V3 d1) {                                // DDF.h:209-212
+    bool reflect = dot(gNorm, d0) * dot(gNorm, d1) > 0;
+    return DT_AllFreq | (reflect ? DT_Reflection : DT_Transmission);
+}
+
+// evaluateInternal of each lobe; `flags` = the query's flags after the caller's side test.
+template <class S, bool MF>
+SLR_DEV S bsdfEvaluateInternal(const Mat<S>& m, uint32_t flags, V3 dirOut, V3 dir, uint32_t wl) {
     S fs_sn;
     switch (m.type) {
     case SLRHIP_MATERIAL_MATTE:
@@ -648,8 +662,22 @@ SLR_DEV S bsdfEvaluate(const Mat<S>& m, uint32_t type, V3 dirOut, V3 gNorm, V3 d
     default:   // SpecularBRDF / SpecularBSDF::evaluateInternal return Zero (basic_BSDFs.cpp:73-77,151-155)
         break;
     }
+    return fs_sn;
+}
+// BSDF::evaluate (DDF.h:247-267)
+template <class S, bool MF>
+SLR_DEV S bsdfEvaluateOnly(const Mat<S>& m, uint32_t type, V3 dirOut, V3 gNorm, V3 dir, uint32_t wl, uint32_t queryFlags = DT_All) {
+    uint32_t flags = queryFlags & sideTest(gNorm, dirOut, dir);
+    if (!dtMatches(type, flags)) return S();
+    S fs_sn = bsdfEvaluateInternal<S, MF>(m, flags, dirOut, dir, wl);
     float snCorrection = fabsf(dir.z / dot(dir, gNorm));
     return fs_sn * snCorrection;
+}
+// BSDF::evaluate + evaluatePDF for the NEE direction.
+template <class S, bool MF>
+SLR_DEV S bsdfEvaluate(const Mat<S>& m, uint32_t type, V3 dirOut, V3 gNorm, V3 dir, uint32_t wl, float* pdf) {
+    *pdf = bsdfEvaluatePDF<S, MF>(m, type, dirOut, dir, wl);
+    return bsdfEvaluateOnly<S, MF>(m, type, dirOut, gNorm, dir, wl);
 }
 
 } // namespace slrhip

@@ -25,6 +25,7 @@ struct DevScene {
     uint32_t numLights;
     uint32_t lightPow2;           // prevPowerOf2(numLights)
     uint32_t hasMicrofacet;       // any SLRHIP_MATERIAL_MICROFACET_* in the scene
+    uint32_t hasMulti;            // any SLRHIP_MATERIAL_MULTI: k_logic with the MultiBSDF code
     uint32_t numSpectra;
     uint32_t numSpectrumData;     // floats in spectrumPool (padded to a multiple of 4 on upload)
     // environment sphere (InfiniteSphereSurfaceObject, SurfaceObject.cpp:137-222); RGB mode

@@ -24,6 +24,7 @@
 #include <string>
 
 #include "pt_bsdf.h"
+#include "pt_bsdf_multi.h"
 #include "pt_kernels.h"
 
 namespace slrhip {
@@ -375,7 +376,7 @@ struct ShadeLds {
     float lightCDF[kLdsLights + 1];
 };
 
-template <class S, bool LDS_TABLES, bool MF>
+template <class S, bool LDS_TABLES, bool MF, bool MULTI = false>
 __global__ __launch_bounds__(kShadeBlock) void k_logic(DevScene sc, PathBuffers pb, RenderParams rp, uint32_t parity) {
     __shared__ ShadeLds<S::N != 3> lds;
     __shared__ PushLds pushLds;
@@ -531,6 +532,16 @@ __global__ __launch_bounds__(kShadeBlock) void k_logic(DevScene sc, PathBuffers 
                 else {
                     V3 gNorm_sn = surf.frame.toLocal(surf.gNormal);
                     uint32_t type = bsdfType(m.type, wlSel);
+                    // SLRHIP_MATERIAL_MULTI: a MultiBSDF whose components are fetched from the material table on demand
+                    const auto loadComponent = [&](uint32_t idx) { return MatIO<S>::template load<LDS_TABLES>(sc, lds.mats, idx, wlOffset); };
+                    const bool isMulti = MULTI && m.type == SLRHIP_MATERIAL_MULTI;
+                    MultiRec multiRec = {};
+                    if constexpr (MULTI) {
+                        if (isMulti) {
+                            multiRec = decodeMulti(m);
+                            type = multiType(multiRec, wlSel);
+                        }
+                    }
                     if (dtMatches(type, DT_WholeSphere | DT_NonDelta)) {
                         // Scene::selectLight, SurfaceObject.cpp:432-450 (+ aggregate :279-286)
                         float lightProb;
@@ -610,8 +621,17 @@ __global__ __launch_bounds__(kShadeBlock) void k_logic(DevScene sc, PathBuffers 
                         V3 shadowDir_sn = surf.frame.toLocal(shadowDir);
                         S Le = M * S(pickEnv ? (float)(1.0 / kPi) : diffuseEDF(shadowDir_l));
                         float lightPDF = lightProb * areaPDF;
-                        float pdfDir;
-                        S fs = bsdfEvaluate<S, MF>(m, type, dirOut_sn, gNorm_sn, shadowDir_sn, wl, &pdfDir);
+                        float pdfDir = 0.0f;
+                        S fs;
+                        bool evaluated = false;
+                        if constexpr (MULTI) {
+                            if (isMulti) {
+                                const MultiBSDF<S, decltype(loadComponent)> multi = {multiRec, wlSel, loadComponent};
+                                fs = multi.evaluate(type, dirOut_sn, gNorm_sn, shadowDir_sn, wl, &pdfDir);
+                                evaluated = true;
+                            }
+                        }
+                        if (!evaluated) fs = bsdfEvaluate<S, MF>(m, type, dirOut_sn, gNorm_sn, shadowDir_sn, wl, &pdfDir);
                         float cosLight = absDot(-shadowDir, lgn);
                         float bsdfPDF = pdfDir * cosLight / dist2;
                         float MISWeight = 1.0f;
@@ -625,7 +645,16 @@ __global__ __launch_bounds__(kShadeBlock) void k_logic(DevScene sc, PathBuffers 
                     float u0 = rng.nextFloat();
                     float u1 = rng.nextFloat();
                     BsdfSample bs;
-                    S fs = bsdfSample<S, MF>(m, type, dirOut_sn, gNorm_sn, wl, uComp, u0, u1, &bs);
+                    S fs;
+                    bool sampled = false;
+                    if constexpr (MULTI) {
+                        if (isMulti) {
+                            const MultiBSDF<S, decltype(loadComponent)> multi = {multiRec, wlSel, loadComponent};
+                            fs = multi.sample(type, dirOut_sn, gNorm_sn, wl, uComp, u0, u1, &bs);
+                            sampled = true;
+                        }
+                    }
+                    if (!sampled) fs = bsdfSample<S, MF>(m, type, dirOut_sn, gNorm_sn, wl, uComp, u0, u1, &bs);
                     if (fs.isZero() || bs.dirPDF == 0.0f) {
                         finish = true;                                         // :209
                     }
@@ -873,14 +902,24 @@ __global__ void __launch_bounds__(64) k_bsdf_queries(DevScene sc, uint32_t mater
     if (i >= n) return;
     const float* q = in + 12 * (size_t)i;
     const Mat<S> m = MatIO<S>::template load<false>(sc, nullptr, material, wlOffset);
-    const uint32_t type = bsdfType(m.type, 0u);
     const V3 dirOut(q[0], q[1], q[2]), gNorm(q[3], q[4], q[5]), dirIn(q[6], q[7], q[8]);
     BsdfSample bs;
     bs.dir_sn = V3(0, 0, 0);
-    S fs = bsdfSample<S, true>(m, type, dirOut, gNorm, wl, q[9], q[10], q[11], &bs);
-    if (bs.dirPDF == 0.0f) { bs.dir_sn = V3(0, 0, 0); bs.dirType = 0; fs = S(); }
+    S fs, fe;
     float pdf;
-    const S fe = bsdfEvaluate<S, true>(m, type, dirOut, gNorm, dirIn, wl, &pdf);
+    if (m.type == SLRHIP_MATERIAL_MULTI) {
+        const auto loadComponent = [&](uint32_t idx) { return MatIO<S>::template load<false>(sc, nullptr, idx, wlOffset); };
+        const MultiBSDF<S, decltype(loadComponent)> multi = {decodeMulti(m), 0u, loadComponent};
+        const uint32_t type = multiType(multi.rec, 0u);
+        fs = multi.sample(type, dirOut, gNorm, wl, q[9], q[10], q[11], &bs);
+        fe = multi.evaluate(type, dirOut, gNorm, dirIn, wl, &pdf);
+    }
+    else {
+        const uint32_t type = bsdfType(m.type, 0u);
+        fs = bsdfSample<S, true>(m, type, dirOut, gNorm, wl, q[9], q[10], q[11], &bs);
+        fe = bsdfEvaluate<S, true>(m, type, dirOut, gNorm, dirIn, wl, &pdf);
+    }
+    if (bs.dirPDF == 0.0f) { bs.dir_sn = V3(0, 0, 0); bs.dirType = 0; fs = S(); }
     geo[i] = make_float4(bs.dir_sn.x, bs.dir_sn.y, bs.dir_sn.z, bs.dirPDF);
     misc[i] = make_float4((float)bs.dirType, pdf, 0.0f, 0.0f);
     SpecIO<S>::store(fsSample, nullptr, i, n, fs, 0.0f);
@@ -903,6 +942,12 @@ void launchLogic(const DevScene& sc, const PathBuffers& pb, const RenderParams& 
     const bool ldsTables = sc.numMaterials <= (uint32_t)kLdsMaterials && sc.numLights <= (uint32_t)kLdsLights &&
                            (!rp.spectral || (sc.numSpectra <= (uint32_t)kLdsSpectra && sc.numSpectrumData <= (uint32_t)kLdsPoolFloats));
     // The microfacet (GGX) code costs ~45 VGPRs, so scenes without such lobes get kernels without it.
+    if (sc.hasMulti) {
+        // MultiBSDF scenes: one kernel per mode, tables in HBM (a component is re-read per use), all lobes compiled in
+        if (rp.spectral) hipLaunchKernelGGL((k_logic<Spec16, false, true, true>), grid, block, 0, stream, sc, pb, rp, parity);
+        else hipLaunchKernelGGL((k_logic<RGB, false, true, true>), grid, block, 0, stream, sc, pb, rp, parity);
+        return;
+    }
     if (rp.spectral) {
         // One lane per slot (Spec16) unless the context asks for four (SpecQ: SLRHIP_FLAG_SPECTRAL_QUAD or SLRHIP_SPECTRAL_LANES=4).
         // Measured on configs[2] after the LDS sample pool: 1 445 vs 1 487 us per launch — the quarter-size register footprint

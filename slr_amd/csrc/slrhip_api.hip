@@ -240,8 +240,42 @@ int slrhip_upload_scene(slrhip_ctx* ctx, const slrhip_scene_desc* d) {
         std::memset(&dm, 0, sizeof(dm));
         dm.type = m.type;
         dm.param = m.param;
-        if (m.type > SLRHIP_MATERIAL_ASHIKHMIN)
+        if (m.type > SLRHIP_MATERIAL_MULTI)
             return fail(SLRHIP_ERR_UNSUPPORTED, "slrhip_upload_scene: unknown material type");
+        if (m.type == SLRHIP_MATERIAL_MULTI) {
+            // MultiBSDF of two earlier single-lobe materials (include/slrhip.h); the record carries indices, scales, flags
+            if ((uint32_t)m.spectrum[2] > 3u)
+                return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: MULTI material with unknown inverse bits");
+            uint32_t childType[2];
+            for (int k = 0; k < 2; ++k) {
+                if (m.spectrum[k] < 0 || (uint32_t)m.spectrum[k] >= i)
+                    return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: MULTI component must be an earlier entry of the material table");
+                if ((uint32_t)m.spectrum[k] > kMultiMaxChildIndex)
+                    return fail(SLRHIP_ERR_UNSUPPORTED, "slrhip_upload_scene: MULTI component index beyond 1023");
+                childType[k] = d->materials[m.spectrum[k]].type;
+                if (childType[k] >= SLRHIP_MATERIAL_MULTI)
+                    return fail(SLRHIP_ERR_UNSUPPORTED, "slrhip_upload_scene: MULTI components must be single-lobe materials (no nesting)");
+                if (((m.spectrum[2] >> k) & 1) && (childType[k] == SLRHIP_MATERIAL_GLASS || childType[k] == SLRHIP_MATERIAL_MICROFACET_GLASS))
+                    return fail(SLRHIP_ERR_UNSUPPORTED, "slrhip_upload_scene: inverse of a two-sided lobe (glass, microfacet glass) is not supported");
+            }
+            if (m.emittance >= 0 && (uint32_t)m.emittance >= d->num_spectra)
+                return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: spectrum index out of range");
+            if (spectral && m.emittance >= 0 && d->spectra[m.emittance].kind == SLRHIP_SPECTRUM_RGB_ONLY)
+                return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: spectral mode needs a spectral descriptor for every spectrum in use");
+            dm.param = 1.0f * m.param;          // `scale * (1.0f - factor)` / `scale * factor` with scale = 1 (MixedSurfaceMaterial.cpp:16-17)
+            dm.onA = 1.0f * m.param2;
+            const uint32_t bits = packMultiBits((uint32_t)m.spectrum[0], (uint32_t)m.spectrum[1], (uint32_t)m.spectrum[2], childType[0], childType[1]);
+            std::memcpy(&dm.onB, &bits, sizeof(bits));
+            if (m.emittance >= 0)
+                for (int k = 0; k < 3; ++k) dm.emittance[k] = d->spectra[m.emittance].rgb[k];
+            emitting[i] = m.emittance >= 0;
+            mats[i] = dm;
+            DevMaterialS ds;
+            ds.type = dm.type; ds.param = dm.param; ds.onA = dm.onA; ds.onB = dm.onB;
+            ds.spec[0] = ds.spec[1] = ds.spec[2] = -1; ds.spec[3] = m.emittance;
+            matsS[i] = ds;
+            continue;
+        }
         if (m.type == SLRHIP_MATERIAL_WARD || m.type == SLRHIP_MATERIAL_ASHIKHMIN) {
             dm.onA = m.param2;          // the lobe's second scalar travels in the Oren-Nayar slot (unused by these types)
             if (!(m.param > 0.0f) || !(m.param2 > 0.0f))
@@ -472,8 +506,11 @@ int slrhip_upload_scene(slrhip_ctx* ctx, const slrhip_scene_desc* d) {
     sc.numSpectra = (uint32_t)devSpectra.size();
     sc.numLights = (uint32_t)lights.size();
     sc.hasMicrofacet = 0;
-    for (const DevMaterial& dm : mats)
+    sc.hasMulti = 0;
+    for (const DevMaterial& dm : mats) {
         if (dm.type >= SLRHIP_MATERIAL_MICROFACET_METAL) sc.hasMicrofacet = 1;     // GGX, Ward, Ashikhmin: the kernels with the glossy-lobe code
+        if (dm.type == SLRHIP_MATERIAL_MULTI) sc.hasMulti = 1;
+    }
     sc.lightPow2 = prevPowerOf2(sc.numLights);
     sc.hasEnv = d->env ? 1u : 0u;
     sc.aggImportance = lightIntegral;

@@ -12,7 +12,8 @@ values, matte / metal / glass / microfacet / Ward / Ashikhmin materials, diffuse
 setRenderSettings — i.e. the walls, lights, cameras and materials of TestScenes/Cornell_Box_*.txt.  What the image
 lacks (no assimp / OpenEXR, no asset files in the reference tree): load3DModel accepts only the two primitive models
 the test scenes use ("…/sphere.assbin", "…/box.assbin") and substitutes this package's tessellated unit sphere / cube;
-Image2D textures, setEnvironment images, "sum" / "mix" / "inverse" materials and the scan* helpers raise UnsupportedFeature.
+Image2D textures, setEnvironment images, nested "sum" / "mix" / "inverse" materials and the scan* helpers raise UnsupportedFeature
+("sum" / "mix" of two single-lobe materials, either possibly "inverse", load as SLRHIP_MATERIAL_MULTI).
 """
 import math
 import re
@@ -612,6 +613,10 @@ class Interpreter:
             "Ward": [("R", SpectrumTex, D), ("anisoX", FloatTex, D), ("anisoY", FloatTex, D)],
             "Ashikhmin": [("Rd", SpectrumTex, D), ("Rs", SpectrumTex, D), ("nx", FloatTex, D), ("ny", FloatTex, D)],
             "emitter": [("scatter", Material, D), ("emitter", Emitter, D)],
+            # API.cpp:583-636: InverseSurfaceMaterial / MixedSurfaceMaterial / SummedSurfaceMaterial -> SLRHIP_MATERIAL_MULTI
+            "inverse": [("base", Material, D)],
+            "mix": [("mat0", Material, D), ("mat1", Material, D), ("factor", FloatTex, D)],
+            "sum": [("mat0", Material, D), ("mat1", Material, D)],
         }
         kind = a["type"]
         if kind not in sigs:
@@ -665,13 +670,32 @@ class Interpreter:
                 spectrum_cache[key] = _bind_spectrum(b, sv)
             return spectrum_cache[key]
 
-        def material(m):
-            key = id(m)
+        def material(m, see_emitter=True):
+            key = (id(m), see_emitter)        # m stays alive in the node graph, so its id is stable
             if key in material_cache:
                 return material_cache[key]
             p = m.params
-            emit = spectrum(m.emitter.emittance) if m.emitter is not None else -1
+            emit = spectrum(m.emitter.emittance) if (m.emitter is not None and see_emitter) else -1
             sp = lambda name: spectrum(p[name].spectrum)
+            if m.kind == "inverse":
+                raise UnsupportedFeature('an "inverse" material on its own (only as a component of "sum" / "mix")')
+            if m.kind in ("sum", "mix"):
+                comps, inv = [], []
+                for c in (p["mat0"], p["mat1"]):
+                    flipped = c.kind == "inverse"
+                    leaf = c.params["base"] if flipped else c
+                    if leaf.kind in ("sum", "mix", "inverse"):
+                        raise UnsupportedFeature('nested "sum" / "mix" / "inverse" materials')
+                    if flipped and leaf.kind in ("glass", "microfacet glass"):
+                        raise UnsupportedFeature('"inverse" of a two-sided material (%s)' % leaf.kind)
+                    comps.append(material(leaf, see_emitter=False))      # a component's own emitter is not seen through the sum
+                    inv.append(flipped)                                  # (SurfaceMaterial::isEmitting is false for it)
+                if m.kind == "sum":
+                    idx = b.summed(comps[0], comps[1], inv, emit)
+                else:
+                    idx = b.mixed(comps[0], comps[1], p["factor"].value, inv, emit)
+                material_cache[key] = idx
+                return idx
             if m.kind == "matte":
                 idx = b.material(abi.MAT_MATTE, (sp("reflectance"), -1, -1), -1.0 if p["sigma"] is None else p["sigma"].value, emit)
             elif m.kind == "metal":

@@ -345,13 +345,17 @@ def bsdf_queries(n=256, seed=2024):
     return np.concatenate([do, gn, di, u], axis=1).astype(np.float32)
 
 
-def cornell_multi(aspect=1.0, segments=16, rings=8):
+def cornell_multi(aspect=1.0, segments=16, rings=8, libm_free=False):
     """MultiBSDF materials in a Cornell box: a sphere of mix(GGX titanium, Lambert; 0.3), a sphere of
     sum(specular aluminium, Lambert) (a delta and a non-delta component side by side), and a free-standing sheet of
-    sum(Lambert, inverse(Lambert)) — the reflect + diffuse-transmit material of TestScenes/RTC3.txt:13-18."""
+    sum(Lambert, inverse(Lambert)) — the reflect + diffuse-transmit material of TestScenes/RTC3.txt:13-18.
+    libm_free: Oren-Nayar in place of the GGX lobe, so that no float libm call is on the path (bit-exact on the GPU)."""
     b = SceneBuilder()
     cornell_walls(b)
-    ti = b.microfacet_metal(b.spectrum_ior("Titanium", 0, TITANIUM_ETA_RGB), b.spectrum_ior("Titanium", 1, TITANIUM_K_RGB), 0.3)
+    if libm_free:
+        ti = b.matte(b.spectrum_srgb_nonlinear(0.7, 0.7, 0.75), sigma=0.5)
+    else:
+        ti = b.microfacet_metal(b.spectrum_ior("Titanium", 0, TITANIUM_ETA_RGB), b.spectrum_ior("Titanium", 1, TITANIUM_K_RGB), 0.3)
     orange = b.matte(b.spectrum_srgb_nonlinear(0.8, 0.45, 0.15))
     green = b.matte(b.spectrum_srgb_nonlinear(0.2, 0.6, 0.3))
     grey = b.matte(b.spectrum_srgb_nonlinear(0.5, 0.5, 0.5))
@@ -362,7 +366,7 @@ def cornell_multi(aspect=1.0, segments=16, rings=8):
     b.add_uv_sphere(segments, rings, coated, _translate(-0.7, 0, -0.8) @ _scale(0.5) @ _translate(0, 1, 0))
     b.add_uv_sphere(segments, rings, lacquer, _translate(0.75, 0, -0.2) @ _scale(0.45) @ _translate(0, 1, 0))
     b.add_quad([(-0.4, 0.0, 0.9), (0.5, 0.0, 0.6), (0.5, 1.3, 0.6), (-0.4, 1.3, 0.9)], (0.316, 0, 0.949), (0.949, 0, -0.316), leaf)
-    return b.build(cornell_camera(aspect), name="cornell_multi")
+    return b.build(cornell_camera(aspect), name="cornell_multi" + ("_libm_free" if libm_free else ""))
 
 
 def cornell_box_boxes(aspect=1.0):

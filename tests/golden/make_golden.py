@@ -155,6 +155,11 @@ def main():
     make("spectral_ashikhmin", scenes.cornell_lobes("ashikhmin", segments=10, rings=5), spec, 32, 32, 8, 2)
     make("spectral_ibl", scenes.ibl_test_scene(1.0, (128, 64), 12, 6, area_light=True), spec, 32, 32, 8, 2)
     make("rgb_cornell_matte", scenes.cornell_box_spheres(4.0 / 3.0, 16, 8, "matte"), lib, 48, 36, 8, 2)
+    # MultiBSDF (sum / mix / inverse materials)
+    make("rgb_multi", scenes.cornell_multi(1.0, 12, 6), lib, 40, 40, 8, 2)
+    make("rgb_multi_libm_free", scenes.cornell_multi(1.0, 12, 6, libm_free=True), lib, 40, 40, 8, 2)
+    make("spectral_multi", scenes.cornell_multi(1.0, 10, 5), spec, 32, 32, 8, 2)
+    make("spectral_multi_libm_free", scenes.cornell_multi(1.0, 10, 5, libm_free=True), spec, 32, 32, 8, 2)
 
 
 if __name__ == "__main__":

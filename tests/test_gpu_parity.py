@@ -373,7 +373,7 @@ def test_spectral_mode_rejects_rgb_only_spectra(sctx):
 
 
 # ---- function-level parity: the device BSDF functions against the reference's known answers --------------------------
-LIBM_FREE_LOBES = ("lambert", "oren_nayar", "mirror", "glass", "emitter_over_lambert")
+LIBM_FREE_LOBES = ("lambert", "oren_nayar", "mirror", "glass", "emitter_over_lambert", "sum_lambert_inverse_lambert", "sum_mirror_lambert")
 
 
 def _assert_lobe_close(got, want, what, exact_rows_floor, far_fraction, far_rel, worst_rel):
@@ -436,3 +436,54 @@ def test_bsdf_queries_reject_bad_arguments(ctx):
         ctx.bsdf_queries(10_000, q)
     with pytest.raises(Exception, match="wl_offset"):
         ctx.bsdf_queries(0, q, 1.0, 0.5)
+
+
+# ---- MultiBSDF: summed / mixed / inverted materials -----------------------------------------------------
+def _render_golden(name):
+    g = load_golden(name)
+    mode = abi.MODE_SPECTRAL if name.startswith("spectral") else abi.MODE_RGB
+    c = Context(device=0, mode=mode, stripes=1)
+    try:
+        st = ob.settings(int(g["width"]), int(g["height"]), int(g["seed"]))
+        fb = c.render_image(scene_from_golden(g), st, int(g["spp"]))
+        assert c.counters().samples == int(g["width"]) * int(g["height"]) * int(g["spp"])
+    finally:
+        c.close()
+    return fb, g["framebuffer"]
+
+
+@pytest.mark.parametrize("name", ["rgb_multi_libm_free", "spectral_multi_libm_free"])
+def test_multibsdf_frame_matches_reference_golden(name):
+    """sum(mirror, Lambert), mix(Oren-Nayar, Lambert), sum(Lambert, inverse(Lambert)): component selection by weight,
+    the mixture PDF and the summed value of MultiBSDF.cpp:20-59, the InverseBSDF forwarding — no float libm on the
+    path, so the frame is expected bit-exact against the compiled reference's."""
+    fb, want = _render_golden(name)
+    s = frame_stats(fb, want)
+    assert s["exact_fraction"] >= 0.999, s
+    assert s["rmse"] <= 1e-3 * max(s["mean"], 1e-9), s
+
+
+@pytest.mark.parametrize("name", ["rgb_multi", "spectral_multi"])
+def test_multibsdf_with_ggx_component_within_tolerance(name):
+    """The same scene with a GGX component in the mix: the float-libm tolerance of the GGX tests."""
+    fb, want = _render_golden(name)
+    s = frame_stats(fb, want)
+    assert s["rmse"] <= 1e-3 * s["mean"], s
+    assert np.isclose(fb, want, rtol=1e-4, atol=1e-9).mean() >= 0.90
+    assert np.isfinite(fb).all()
+
+
+def test_multibsdf_rejects_what_it_does_not_support(ctx):
+    b = scenes.SceneBuilder()
+    scenes.cornell_walls(b)
+    glass = b.glass(b.spectrum_grey(0.999), b.spectrum_ior("Air", 0, scenes.AIR_ETA_RGB), b.spectrum_ior("Glass_BK7", 0, scenes.BK7_ETA_RGB))
+    matte = b.matte(b.spectrum_grey(0.5))
+    inner = b.summed(matte, matte)
+    for bad in (lambda: b.summed(matte, glass, inverse=(False, True)),       # inverse of a two-sided lobe
+                lambda: b.summed(inner, matte),                              # nesting
+                lambda: b.material(abi.MAT_MULTI, (matte, 10_000, 0), 1.0, -1, 1.0)):   # component index out of range
+        n = len(b.materials)
+        bad()
+        with pytest.raises(Exception, match="MULTI|inverse"):
+            ctx.upload_scene(b.build(scenes.cornell_camera(1.0)))
+        del b.materials[n:]

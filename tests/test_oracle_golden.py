@@ -8,7 +8,8 @@ from oracle import binding as ob
 from slr_amd import abi
 
 SCENES = ["rgb_tiny_box", "rgb_cornell_glass", "rgb_cornell_matte", "rgb_oren_nayar", "rgb_ggx_metal", "rgb_ggx_glass", "rgb_ward", "rgb_ashikhmin",
-          "rgb_ibl", "rgb_ibl_area"]     # environment sphere alone / next to a triangle light (Scene::selectLight)
+          "rgb_ibl", "rgb_ibl_area",
+          "rgb_multi", "rgb_multi_libm_free"]     # environment sphere alone / next to a triangle light (Scene::selectLight)
 
 
 def test_rng_known_answers(oracle_rgb):
@@ -110,7 +111,7 @@ def test_rejects_bad_scene(oracle_rgb):
 
 
 SPECTRAL_SCENES = ["spectral_cornell_glass", "spectral_cornell_matte", "spectral_oren_nayar", "spectral_ggx_metal", "spectral_ggx_glass", "spectral_ashikhmin",
-                   "spectral_ibl"]     # environment texels as (u, v, s), looked up in the Meng-15 grid at run time, + an area light
+                   "spectral_ibl", "spectral_multi", "spectral_multi_libm_free"]     # environment texels as (u, v, s), looked up in the Meng-15 grid at run time, + an area light
 
 
 @pytest.mark.parametrize("name", SPECTRAL_SCENES)

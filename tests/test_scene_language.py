@@ -139,12 +139,53 @@ def test_glossy_lobes_and_emitters_on_any_base():
 
 
 @pytest.mark.parametrize("snippet", ['x = Image2D("images/a.exr");', 'setEnvironment("images/sky.exr", 4);',
-                                     'n = load3DModel("models/teapot.assbin");',
-                                     'm = createSurfaceMaterial("sum", (createSurfaceMaterial("matte", (SpectrumTexture(Spectrum(0.5, 0.5, 0.5)),)), '
-                                     'createSurfaceMaterial("matte", (SpectrumTexture(Spectrum(0.1, 0.1, 0.1)),))));'])
+                                     'n = load3DModel("models/teapot.assbin");'])
 def test_missing_assets_and_lobes_are_refused_loudly(snippet):
     with pytest.raises(sl.UnsupportedFeature):
         sl.Interpreter().run(snippet)
+
+
+MULTI_SCRIPT = '''
+    function leaf(R, T) {
+        r = createSurfaceMaterial("matte", (SpectrumTexture(R),));
+        tBase = createSurfaceMaterial("matte", (SpectrumTexture(T),));
+        t = createSurfaceMaterial("inverse", (tBase,));
+        return createSurfaceMaterial("sum", (r, t));
+    }
+    green = leaf(Spectrum(0.5, 0.5, 0.5), Spectrum(0.2, 0.6, 0.3));
+    ti = createSurfaceMaterial("microfacet metal", (SpectrumTexture(Spectrum("ID": "Titanium", 0)), SpectrumTexture(Spectrum("ID": "Titanium", 1)), FloatTexture(0.3)));
+    coated = createSurfaceMaterial("mix", (ti, createSurfaceMaterial("matte", (SpectrumTexture(Spectrum(0.8, 0.45, 0.15)),)), FloatTexture(0.3)));
+    %s
+    q = createMesh((((0, 0, 0), (0, 1, 0), (1, 0, 0), (0, 0)), ((1, 0, 0), (0, 1, 0), (1, 0, 0), (1, 0)), ((1, 0, 1), (0, 1, 0), (1, 0, 0), (1, 1))),
+                   ((green, ((0, 1, 2),)), (%s, ((0, 2, 1),))));
+    addChild(root, q);
+    c = createNode(); addChild(c, createPerspectiveCamera()); addChild(root, c);
+'''
+
+
+def test_summed_mixed_and_inverse_materials_become_multi_records():
+    """TestScenes/RTC3.txt:13-18 builds its leaves as sum(matte, inverse(matte)): API.cpp:583-636."""
+    from slr_amd import abi
+    it = sl.Interpreter()
+    it.run(MULTI_SCRIPT % ("", "coated"))
+    sc = it.build()
+    m = sc.materials
+    assert list(m["type"]) == [abi.MAT_MATTE, abi.MAT_MATTE, abi.MAT_MULTI, abi.MAT_MF_METAL, abi.MAT_MATTE, abi.MAT_MULTI]
+    assert tuple(m["spectrum"][2]) == (0, 1, abi.MULTI_INVERSE_1) and (float(m["param"][2]), float(m["param2"][2])) == (1.0, 1.0)
+    assert tuple(m["spectrum"][5]) == (3, 4, 0)
+    assert (m["param"][5], m["param2"][5]) == (np.float32(1.0) - np.float32(0.3), np.float32(0.3))      # scale * (1.0f - factor), scale * factor
+    assert set(sc.triangles["material"]) == {2, 5}
+
+
+@pytest.mark.parametrize("extra, used", [('bad = createSurfaceMaterial("sum", (green, ti));', "bad"),                    # nesting
+                                         ('bad = createSurfaceMaterial("inverse", (ti,));', "bad"),                       # inverse on its own
+                                         ('g = createSurfaceMaterial("glass", (SpectrumTexture(Spectrum(0.9, 0.9, 0.9)), SpectrumTexture(Spectrum("ID": "Air", 0)), '
+                                          'SpectrumTexture(Spectrum("ID": "Glass_BK7", 0)))); bad = createSurfaceMaterial("sum", (ti, createSurfaceMaterial("inverse", (g,))));', "bad")])
+def test_multi_materials_outside_the_supported_subset_are_refused(extra, used):
+    it = sl.Interpreter()
+    it.run(MULTI_SCRIPT % (extra, used))
+    with pytest.raises(sl.UnsupportedFeature):
+        it.build()
 
 
 def test_syntax_errors_are_reported():
