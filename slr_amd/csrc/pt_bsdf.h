@@ -47,9 +47,6 @@ SLR_DEV DevSpectrum loadSpectrumRecord(const DevSpectrum* spectra, int32_t idx) 
 
 template <class S>
 SLR_DEV S evalSpectrum(const DevSpectrum* spectra, const float* __restrict__ pool, int32_t idx, float wlOffset) {
-#ifdef SLR_EXP_CONST_SPECTRA
-    return S(0.5f + 0.001f * (float)idx);     // timing experiment only: what the table look-ups cost
-#endif
     const DevSpectrum sp = loadSpectrumRecord(spectra, idx);
     const float* data = pool + sp.dataOffset;
     switch (sp.kind) {
