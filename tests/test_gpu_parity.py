@@ -487,3 +487,59 @@ def test_multibsdf_rejects_what_it_does_not_support(ctx):
         with pytest.raises(Exception, match="MULTI|inverse"):
             ctx.upload_scene(b.build(scenes.cornell_camera(1.0)))
         del b.materials[n:]
+
+
+# ---- table placement and size-independent properties at BASELINE size ------------------------------------------------
+def _patchwork_scene(num_materials, num_lights):
+    """Cornell walls + a floor patchwork in which every patch has its own matte material and some patches emit:
+    more materials (> 32) and lights (> 16) than the shade kernel stages in LDS, so the tables stay in HBM."""
+    b = scenes.SceneBuilder()
+    scenes.cornell_walls(b)
+    rng = np.random.default_rng(3)
+    side = int(np.ceil(np.sqrt(num_materials)))
+    for i in range(num_materials):
+        r, g, bl = rng.uniform(0.1, 0.9, 3)
+        emit = b.spectrum_d65(0.5 + 0.1 * i, scenes.D65_RGB) if i < num_lights else -1
+        m = b.matte(b.spectrum_srgb_nonlinear(float(r), float(g), float(bl)), emittance=emit)
+        x, z = -1.2 + 2.4 * (i % side) / side, -1.8 + 3.0 * (i // side) / side
+        w, y = 2.2 / side, 0.02 + 0.3 * (i % 3)
+        b.add_quad([(x, y, z + w), (x + w, y, z + w), (x + w, y, z), (x, y, z)], (0, 1, 0), (1, 0, 0), m)
+    return b.build(scenes.cornell_camera(1.0), name="patchwork")
+
+
+def test_many_materials_and_lights_use_the_tables_in_hbm(oracle_rgb, oracle_spectral):
+    sc = _patchwork_scene(45, 20)
+    assert len(sc.materials) > 32 and (sc.materials["emittance"] >= 0).sum() > 16
+    st = ob.settings(72, 56, seed=21)
+    for mode, orc in ((abi.MODE_RGB, oracle_rgb), (abi.MODE_SPECTRAL, oracle_spectral)):
+        want, _ = orc.scene(sc).render(st, 8)
+        c = Context(mode=mode, stripes=1)
+        fb = c.render_image(sc, st, 8)
+        c.close()
+        assert_bit_equal(fb, want, "patchwork mode %d" % mode)
+        assert want.sum() > 0
+
+
+def test_radiance_is_linear_in_the_emitted_power_at_full_size():
+    """A property that needs no oracle, at BASELINE's 1280x720: scaling every emitter by a power of two scales every float of
+    the frame by exactly that factor (products by 2^k are exact, and no decision on a path — BSDF sampling, Russian
+    roulette on throughput, light selection among equal importances — looks at the emitted radiance)."""
+    frames = []
+    for scale in (4.0, 16.0):
+        b = scenes.SceneBuilder()
+        red = b.matte(b.spectrum_srgb_nonlinear(0.75, 0.25, 0.25))
+        white = b.matte(b.spectrum_srgb_nonlinear(0.75, 0.75, 0.75))
+        b.add_quad([(-1.5, 0, 2.55), (-1.5, 0, -2.55), (-1.5, 2.5, -2.55), (-1.5, 2.5, 2.55)], (1, 0, 0), (0, 0, -1), red)
+        b.add_quad([(-1.5, 0, 2.55), (1.5, 0, 2.55), (1.5, 0, -2.55), (-1.5, 0, -2.55)], (0, 1, 0), (1, 0, 0), white)
+        b.add_quad([(-1.5, 0, -2.55), (1.5, 0, -2.55), (1.5, 2.5, -2.55), (-1.5, 2.5, -2.55)], (0, 0, 1), (1, 0, 0), white)
+        light = b.matte(b.spectrum_srgb_nonlinear(0.9, 0.9, 0.9), emittance=b.spectrum_d65(scale, scenes.D65_RGB))
+        b.add_quad([(-0.5, 2.499, -0.5), (0.5, 2.499, -0.5), (0.5, 2.499, 0.5), (-0.5, 2.499, 0.5)], (0, -1, 0), (1, 0, 0), light)
+        mirror = b.metal(b.spectrum_grey(1.0), b.spectrum_ior("Aluminium", 0, scenes.ALUMINIUM_ETA_RGB), b.spectrum_ior("Aluminium", 1, scenes.ALUMINIUM_K_RGB))
+        b.add_uv_sphere(32, 16, mirror, scenes._translate(0.2, 0, -0.6) @ scenes._scale(0.6) @ scenes._translate(0, 1, 0))
+        sc = b.build(scenes.cornell_camera(1280 / 720))
+        c = Context(mode=abi.MODE_RGB)
+        frames.append(c.render_image(sc, ob.settings(1280, 720), 8))
+        assert c.counters().samples == 1280 * 720 * 8
+        c.close()
+    assert frames[0].sum() > 0
+    assert_bit_equal(frames[0] * np.float32(4.0), frames[1], "16x light vs 4 * (4x light)")
