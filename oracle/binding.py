@@ -51,6 +51,7 @@ class OracleLib:
         f("rng").restype = None
         f("components").argtypes = [C.c_void_p]
         f("bsdf_kat").argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_float, C.c_float, C.c_void_p]
+        f("light_kat").argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_float, C.c_float, C.c_void_p]
         f("render_serial").argtypes = [C.c_void_p, C.POINTER(abi.RenderSettings), C.c_uint32, C.c_void_p,
                                        C.POINTER(OracleCounters)]
 
@@ -124,6 +125,16 @@ class OracleScene:
         rc = self.lib._f("bsdf_kat")(self.handle, material, len(q), q.ctypes.data, wl_offset, u_lambda, out.ctypes.data)
         if rc != 0:
             raise RuntimeError("oracle bsdf_kat failed: %d" % rc)
+        return out
+
+    def light_kat(self, u, wl_offset=0.5, u_lambda=0.5):
+        """Scene::selectLight + Light::sample; u [n][3] = light selection sample, position samples -> [n][16 + C]
+        (layout in slr_oracle.h)."""
+        q = np.ascontiguousarray(u, dtype=np.float32).reshape(-1, 3)
+        out = np.zeros((len(q), 16 + self.components), np.float32)
+        rc = self.lib._f("light_kat")(self.handle, len(q), q.ctypes.data, wl_offset, u_lambda, out.ctypes.data)
+        if rc != 0:
+            raise RuntimeError("oracle light_kat failed: %d" % rc)
         return out
 
     def render_serial(self, settings, spp):

@@ -437,6 +437,36 @@ int slr_ref_bsdf_kat(slr_oracle_scene* s, uint32_t material, uint32_t n, const f
     return 0;
 }
 
+// Scene::selectLight + Light::sample, the two calls of PathTracingRenderer.cpp:172-177, on the reference's own Scene.
+int slr_ref_light_kat(slr_oracle_scene* s, uint32_t n, const float* in, float wlOffset, float uLambda, float* out) {
+    if (!s || !in || !out) return 1;
+    float wlPDF;
+    WavelengthSamples wls = WavelengthSamples::createWithEqualOffsets(wlOffset, uLambda, &wlPDF);
+    const int stride = 16 + kComponents;
+    for (uint32_t i = 0; i < n; ++i) {
+        const float* q = in + 3 * (size_t)i;
+        float* o = out + stride * (size_t)i;
+        float lightProb;
+        Light light;
+        s->scene.selectLight(q[0], &light, &lightProb);
+        auto it = s->objIndex.find(light.top());
+        LightPosQuery lpQuery(0.0f, wls);
+        LightPosQueryResult lpResult;
+        SampledSpectrum M = light.sample(lpQuery, LightPosSample(q[1], q[2]), &lpResult);
+        const SurfacePoint& sp = lpResult.surfPt;
+        o[0] = it == s->objIndex.end() ? -1.0f : (float)it->second;
+        o[1] = lightProb;
+        o[2] = sp.p.x; o[3] = sp.p.y; o[4] = sp.p.z;
+        o[5] = sp.gNormal.x; o[6] = sp.gNormal.y; o[7] = sp.gNormal.z;
+        o[8] = sp.shadingFrame.x.x; o[9] = sp.shadingFrame.x.y; o[10] = sp.shadingFrame.x.z;
+        o[11] = sp.shadingFrame.z.x; o[12] = sp.shadingFrame.z.y; o[13] = sp.shadingFrame.z.z;
+        o[14] = lpResult.areaPDF;
+        o[15] = sp.atInfinity ? 1.0f : 0.0f;
+        for (int k = 0; k < kComponents; ++k) o[16 + k] = M[k];
+    }
+    return 0;
+}
+
 int slr_ref_trace(slr_oracle_scene* s, const slr_oracle_ray* rays, uint32_t n, slr_oracle_hit* hits) {
     if (!s || !rays || !hits) return 1;
     for (uint32_t i = 0; i < n; ++i) {

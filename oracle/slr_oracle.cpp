@@ -1950,6 +1950,40 @@ void addCounters(slr_oracle_counters* dst, const slr_oracle_counters& src) {
 } // namespace
 
 namespace {
+// Function-level known answers: Scene::selectLight + Light::sample as the integrator calls them (PathTracingRenderer.cpp:169-177).
+template <int N>
+int lightKatT(const slr_oracle_scene* s, uint32_t n, const float* in, float wlOffset, float uLambda, float* out) {
+    Wls<N> wls;
+    for (int i = 0; i < N; ++i)
+        wls.lambdas[i] = kWavelengthLowBound + (kWavelengthHighBound - kWavelengthLowBound) * (i + wlOffset) / N;
+    wls.selectedLambda = std::min(uint16_t(N * uLambda), uint16_t(N - 1));
+    wls.flags = 0;
+    const int stride = 16 + N;
+    for (uint32_t i = 0; i < n; ++i) {
+        const float* q = in + 3 * (size_t)i;
+        float* o = out + stride * (size_t)i;
+        float lightProb;
+        uint32_t lightTri = selectLight(*s, q[0], &lightProb);
+        SurfPt lp; float areaPDF;
+        Spec<N> M;
+        if (lightTri == kEnvObject) M = envSample<N>(*s, wls, q[1], q[2], &lp, &areaPDF);
+        else {
+            triSample(*s, lightTri, q[1], q[2], &lp, &areaPDF);
+            M = emittance(*s, lightTri, wls);
+        }
+        o[0] = lightTri == kEnvObject ? -1.0f : (float)lightTri;
+        o[1] = lightProb;
+        o[2] = lp.p.x; o[3] = lp.p.y; o[4] = lp.p.z;
+        o[5] = lp.gNormal.x; o[6] = lp.gNormal.y; o[7] = lp.gNormal.z;
+        o[8] = lp.frame.x.x; o[9] = lp.frame.x.y; o[10] = lp.frame.x.z;
+        o[11] = lp.frame.z.x; o[12] = lp.frame.z.y; o[13] = lp.frame.z.z;
+        o[14] = areaPDF;
+        o[15] = lp.atInfinity ? 1.0f : 0.0f;
+        for (int k = 0; k < N; ++k) o[16 + k] = M[k];
+    }
+    return 0;
+}
+
 // Function-level known answers: the three public BSDF calls of DDF.h:231-279 on one material.
 template <int N>
 int bsdfKatT(const slr_oracle_scene* s, uint32_t material, uint32_t n, const float* in, float wlOffset, float uLambda, float* out) {
@@ -2161,6 +2195,12 @@ int slr_oracle_bsdf_kat(slr_oracle_scene* s, uint32_t material, uint32_t n, cons
     if (!s || !in || !out || material >= s->materials.size()) return 1;
     return s->mode == SLRHIP_MODE_RGB ? bsdfKatT<3>(s, material, n, in, wlOffset, uLambda, out)
                                       : bsdfKatT<16>(s, material, n, in, wlOffset, uLambda, out);
+}
+
+int slr_oracle_light_kat(slr_oracle_scene* s, uint32_t n, const float* in, float wlOffset, float uLambda, float* out) {
+    if (!s || !in || !out) return 1;
+    if (s->lightTris.empty() && !s->hasEnv) return 1;
+    return s->mode == SLRHIP_MODE_RGB ? lightKatT<3>(s, n, in, wlOffset, uLambda, out) : lightKatT<16>(s, n, in, wlOffset, uLambda, out);
 }
 
 int slr_oracle_render_serial(slr_oracle_scene* s, const slrhip_render_settings* st, uint32_t spp, float* fbSum,

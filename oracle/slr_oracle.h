@@ -70,7 +70,13 @@ typedef struct slr_oracle_hit {
      * out[(6+2C) i ..] = sampled dir_sn[3], dirPDF, dirType, fs(sample)[C], fs(evaluate)[C],      \
      * evaluatePDF; the five sample fields and fs(sample) are zero when dirPDF == 0.           */ \
     int P##bsdf_kat(slr_oracle_scene* s, uint32_t material, uint32_t n, const float* in,           \
-                    float wl_offset, float u_lambda, float* out);
+                    float wl_offset, float u_lambda, float* out);                                  \
+    /* Scene::selectLight + Light::sample as the integrator calls them                             \
+     * (PathTracingRenderer.cpp:169-177).  in[3 i ..] = uLightSelection, uPos[2]                   \
+     * out[(16+C) i ..] = light (triangle index, -1 = environment sphere), lightProb, p[3],        \
+     * gNormal[3], shadingFrame.x[3], shadingFrame.z[3], areaPDF, atInfinity, M[C]              */ \
+    int P##light_kat(slr_oracle_scene* s, uint32_t n, const float* in, float wl_offset,            \
+                     float u_lambda, float* out);
 
 SLR_ORACLE_DECLARE(slr_oracle_)
 SLR_ORACLE_DECLARE(slr_ref_)

@@ -90,6 +90,34 @@ def make_bsdf_kat(name, lib):
     print(name, {k: int((out["out_" + k][0][:, 3] != 0).sum()) for k in mats})
 
 
+def light_queries(n, seed):
+    """[n][3] (light selection sample, two position samples) with the corner cases first."""
+    u = np.random.default_rng(seed).random((n, 3)).astype(np.float32)
+    one = np.float32(1.0) - np.float32(2.0 ** -24)
+    u[0] = 0.0
+    u[1] = one
+    u[2] = (0.5, 0.0, 0.0)
+    u[3] = (0.5, one, one)
+    u[4] = (one, 0.0, one)
+    return u
+
+
+def make_light_kat(name, lib):
+    """Scene::selectLight + Light::sample of the reference on a scene with an environment sphere next to triangle lights,
+    and on one with several triangle lights: 512 queries each."""
+    if lib is None:
+        raise SystemExit("reference library for %s not built" % name)
+    out = {}
+    q = light_queries(512, 77)
+    for tag, sc in (("env", scenes.ibl_test_scene(1.0, (128, 64), 12, 6, area_light=True)), ("zoo", scenes.material_zoo()[0])):
+        out.update({tag + "_" + k: v for k, v in scene_arrays(sc).items()})
+        out[tag + "_out"] = lib.scene(sc).light_kat(q, 0.3, 0.7)
+    out["queries"] = q
+    out["wavelengths"] = np.array([0.3, 0.7], np.float32)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "environment picks", int((out["env_out"][:, 0] < 0).sum()), "of", len(q))
+
+
 def main():
     only = sys.argv[1:]
     if only:
@@ -121,6 +149,8 @@ def main():
                         scale=np.float32(0.37), bmp=bmp)
     if not only or "bsdf_kat_rgb" in only:
         make_bsdf_kat("bsdf_kat_rgb", lib)
+    if not only or "light_kat_rgb" in only:
+        make_light_kat("light_kat_rgb", lib)
     make("rgb_tiny_box", scenes.tiny_box(1.0), lib, 32, 32, 8, 2)
     make("rgb_cornell_glass", scenes.cornell_box_spheres(4.0 / 3.0, 16, 8, "glass"), lib, 48, 36, 8, 2)
     make("rgb_oren_nayar", scenes.cornell_lobes("oren_nayar"), lib, 40, 40, 8, 2)
@@ -145,6 +175,8 @@ def main():
                             scale=np.float32(0.41), bmp=bmp16)
     if not only or "bsdf_kat_spectral" in only:
         make_bsdf_kat("bsdf_kat_spectral", spec)
+    if not only or "light_kat_spectral" in only:
+        make_light_kat("light_kat_spectral", spec)
     make("spectral_cornell_glass", scenes.cornell_box_spheres(1.0, 12, 6, "glass"), spec, 32, 32, 8, 2)
     make("spectral_cornell_matte", scenes.cornell_box_spheres(1.0, 12, 6, "matte"), spec, 32, 32, 8, 2)
     make("spectral_oren_nayar", scenes.cornell_lobes("oren_nayar", segments=10, rings=5), spec, 32, 32, 8, 2)

@@ -11,7 +11,19 @@ def load_golden(name):
     return np.load(os.path.join(GOLDEN, name + ".npz"))
 
 
-def scene_from_golden(g, name="golden"):
+class _Prefixed:
+    """View of an npz whose keys carry a prefix (several scenes in one fixture)."""
+    def __init__(self, g, prefix):
+        self.g, self.prefix = g, prefix
+        self.files = [k[len(prefix):] for k in g.files if k.startswith(prefix)]
+
+    def __getitem__(self, k):
+        return self.g[self.prefix + k]
+
+
+def scene_from_golden(g, name="golden", prefix=""):
+    if prefix:
+        g = _Prefixed(g, prefix)
     cam = abi.Camera()
     c = g["camera"]
     cam.local_to_world[:] = c[0:16].tolist()

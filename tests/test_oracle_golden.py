@@ -166,3 +166,20 @@ def test_bsdf_queries_match_compiled_reference(request, oracle_rgb, oracle_spect
     q = scenes.bsdf_queries(1024, 7)
     for name, m in mats.items():
         assert_bit_equal(o.bsdf_kat(m, q, 0.25, 0.8), r.bsdf_kat(m, q, 0.25, 0.8), "%s %s" % (mode, name))
+
+
+@pytest.mark.parametrize("mode", ["rgb", "spectral"])
+def test_light_sampling_known_answers(oracle_rgb, oracle_spectral, mode):
+    """Scene::selectLight + Light::sample (PathTracingRenderer.cpp:169-177) of the reference: which light, its probability,
+    the sampled point, normal, shading frame, area PDF and emittance — environment sphere (importance-map inversion, lat-long
+    mapping) next to triangle lights, and several triangle lights; sample numbers 0 and 1 - 2^-24 included."""
+    g = load_golden("light_kat_" + mode)
+    lib = oracle_rgb if mode == "rgb" else oracle_spectral
+    off, ul = [float(v) for v in g["wavelengths"]]
+    for tag in ("env", "zoo"):
+        sc = lib.scene(scene_from_golden(g, prefix=tag + "_"))
+        got = sc.light_kat(g["queries"], off, ul)
+        assert_bit_equal(got, g[tag + "_out"], "%s %s" % (mode, tag))
+    env_picks = (g["env_out"][:, 0] < 0).mean()
+    assert 0.2 < env_picks < 0.5            # 1 / (1 + number of triangle lights) of the selection samples
+    assert len(np.unique(g["zoo_out"][:, 0])) > 2

@@ -99,3 +99,19 @@ def test_spectral_cornell_frame_bit_exact(oracle_spectral, ref_spectral, right):
     fo, _ = so.render(st, 8)
     fr, _ = sr.render(st, 8)
     assert_bit_equal(fo, fr, "spectral cornell " + right)
+
+
+@pytest.mark.parametrize("mode", ["rgb", "spectral"])
+def test_light_sampling_and_multibsdf_frames_bit_exact(request, oracle_rgb, oracle_spectral, mode):
+    """Fresh inputs for the two newest pins: selectLight + Light::sample on 4096 queries, and whole frames of the
+    MultiBSDF scene at a size the goldens do not hold."""
+    orc = oracle_rgb if mode == "rgb" else oracle_spectral
+    ref = request.getfixturevalue("ref_" + mode)
+    u = np.random.default_rng(91).random((4096, 3)).astype(np.float32)
+    for sc in (scenes.ibl_test_scene(1.0, (128, 64), 12, 6, area_light=True), scenes.cornell_box_boxes(1.0)):
+        assert_bit_equal(orc.scene(sc).light_kat(u, 0.9, 0.1), ref.scene(sc).light_kat(u, 0.9, 0.1), "light_kat " + sc.name)
+    sc = scenes.cornell_multi(1.0, 14, 7)
+    st = ob.settings(56, 44, seed=17)
+    a, _ = orc.scene(sc).render(st, 6)
+    b, _ = ref.scene(sc).render(st, 6)
+    assert_bit_equal(a, b, "cornell_multi " + mode)
