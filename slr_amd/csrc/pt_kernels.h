@@ -85,11 +85,11 @@ struct PathBuffers {
     float4* accC;
     float4* nee;                  // pending next-event contribution
     float4* shadowDir;            // shadow ray direction, w = distMax
-    float* pdfPrev;               // spectral mode only: the scalars that ride in .w in RGB mode
-    float* camWeight;
-    float* wlOffset;              // spectral mode: the sample's wavelength offset (lambda_i = 360 + 470 (i + offset) / 16)
+    float* pdfPrev;               // spectral mode only: the scalar that rides in alpha.w in RGB mode
+    // per-slot sample header, written by k_regen only: x = samples of this slot finished so far, y = the current sample's
+    // camera weight (bits), z = its wavelength offset (bits; lambda_i = 360 + 470 (i + offset) / 16, spectral mode)
+    uint4* hdr;
     uint32_t* flags;
-    uint32_t* sampleIdx;
     uint32_t* visible;            // result of the shadow ray
     uint32_t* shadowQueue;        // kShards regions of shardCapacity slot indices: shadow rays of this iteration
     uint32_t* regenQueue;         // same layout: slots whose path ended (accumulate pixel, start next sample)

@@ -45,6 +45,7 @@ enum : uint32_t {
 #define F_DELTA(f) (((f) >> 13) & 1u)
 #define F_SHADOW(f) (((f) >> 14) & 1u)
 #define F_HASPATH(f) (((f) >> 15) & 1u)
+#define F_SPVALID(f) (((f) >> 10) & 1u)      // spectral mode: the path's radiance sum in HBM has been written since the path began
 #define F_MAKE(state, len, wl, wlsel, delta, shadow) \
     ((state) | ((len) << 3) | ((wl) << 16) | ((wlsel) << 12) | ((delta) << 13) | ((shadow) << 14))
 
@@ -303,64 +304,85 @@ __device__ __forceinline__ float envAreaPDF(const DevScene& sc, float phi, float
 
 // SampledSpectrumSum sp of Job::contribution (PathTracingRenderer.cpp:141): see the note at its use in k_logic.
 template <class S> struct SpAcc;
+// A path starts with sp = 0 (and alpha = 1, no previous PDF): k_regen does not write those records, the first k_logic visit
+// (state FIRST_HIT) supplies the values instead of what it loaded.  RGB keeps the pair in registers and always stores it,
+// so it is valid from then on; the spectral variants update HBM only when a contribution arrives and track that in `valid`
+// (flag bit 10), which k_regen consults before reading the sum.
 template <> struct SpAcc<RGB> {
     RGB r, c, nee;
-    float camWeight;
     __device__ __forceinline__ void begin(const PathBuffers& pb, uint32_t slot, uint32_t n) {
         float unused;
-        SpecIO<RGB>::load(pb.spR, nullptr, slot, n, r, camWeight);
+        SpecIO<RGB>::load(pb.spR, nullptr, slot, n, r, unused);
         SpecIO<RGB>::load(pb.spC, nullptr, slot, n, c, unused);
         SpecIO<RGB>::load(pb.nee, nullptr, slot, n, nee, unused);
     }
+    __device__ __forceinline__ void startPath(bool first, uint32_t) { if (first) { r = RGB(); c = RGB(); } }
+    __device__ __forceinline__ uint32_t validBits() const { return 1u << 10; }
     __device__ __forceinline__ void addPendingNee(const PathBuffers&, uint32_t, uint32_t) { kahanAdd(r, c, nee); }
     __device__ __forceinline__ void add(const PathBuffers&, uint32_t, uint32_t, const RGB& v) { kahanAdd(r, c, v); }
     __device__ __forceinline__ void end(const PathBuffers& pb, uint32_t slot, uint32_t n, bool pathContinues) {
-        SpecIO<RGB>::store(pb.spR, nullptr, slot, n, r, camWeight);
+        SpecIO<RGB>::store(pb.spR, nullptr, slot, n, r, 0.0f);
         if (pathContinues) SpecIO<RGB>::store(pb.spC, nullptr, slot, n, c, 0.0f);       // a finished path only hands over the sum
     }
 };
 template <> struct SpAcc<Spec16> {
+    bool valid;
     __device__ __forceinline__ void begin(const PathBuffers&, uint32_t, uint32_t) {}
+    __device__ __forceinline__ void startPath(bool first, uint32_t flags) { valid = !first && F_SPVALID(flags); }
+    __device__ __forceinline__ uint32_t validBits() const { return valid ? 1u << 10 : 0u; }
     __device__ __forceinline__ void add(const PathBuffers& pb, uint32_t slot, uint32_t n, const Spec16& v) {
         // plane by plane: 4 components of the Kahan pair in flight at a time
+        const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-            float4 r = pb.spR[(size_t)p * n + slot], c = pb.spC[(size_t)p * n + slot];
+            float4 r = zero, c = zero;
+            if (valid) { r = pb.spR[(size_t)p * n + slot]; c = pb.spC[(size_t)p * n + slot]; }
             kahanAdd(r.x, c.x, v.c[4 * p]); kahanAdd(r.y, c.y, v.c[4 * p + 1]);
             kahanAdd(r.z, c.z, v.c[4 * p + 2]); kahanAdd(r.w, c.w, v.c[4 * p + 3]);
             pb.spR[(size_t)p * n + slot] = r;
             pb.spC[(size_t)p * n + slot] = c;
         }
+        valid = true;
     }
     __device__ __forceinline__ void addPendingNee(const PathBuffers& pb, uint32_t slot, uint32_t n) {
+        const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const float4 v = pb.nee[(size_t)p * n + slot];
-            float4 r = pb.spR[(size_t)p * n + slot], c = pb.spC[(size_t)p * n + slot];
+            float4 r = zero, c = zero;
+            if (valid) { r = pb.spR[(size_t)p * n + slot]; c = pb.spC[(size_t)p * n + slot]; }
             kahanAdd(r.x, c.x, v.x); kahanAdd(r.y, c.y, v.y); kahanAdd(r.z, c.z, v.z); kahanAdd(r.w, c.w, v.w);
             pb.spR[(size_t)p * n + slot] = r;
             pb.spC[(size_t)p * n + slot] = c;
         }
+        valid = true;
     }
     __device__ __forceinline__ void end(const PathBuffers&, uint32_t, uint32_t, bool) {}
 };
 
 template <> struct SpAcc<SpecQ> {
+    bool valid;
     __device__ __forceinline__ void begin(const PathBuffers&, uint32_t, uint32_t) {}
+    __device__ __forceinline__ void startPath(bool first, uint32_t flags) { valid = !first && F_SPVALID(flags); }
+    __device__ __forceinline__ uint32_t validBits() const { return valid ? 1u << 10 : 0u; }
     __device__ __forceinline__ void add(const PathBuffers& pb, uint32_t slot, uint32_t n, const SpecQ& v) {
         const size_t i = (size_t)SpecQ::q() * n + slot;
-        float4 r = pb.spR[i], c = pb.spC[i];
+        float4 r = make_float4(0.0f, 0.0f, 0.0f, 0.0f), c = r;
+        if (valid) { r = pb.spR[i]; c = pb.spC[i]; }
         kahanAdd(r.x, c.x, v.c[0]); kahanAdd(r.y, c.y, v.c[1]); kahanAdd(r.z, c.z, v.c[2]); kahanAdd(r.w, c.w, v.c[3]);
         pb.spR[i] = r;
         pb.spC[i] = c;
+        valid = true;
     }
     __device__ __forceinline__ void addPendingNee(const PathBuffers& pb, uint32_t slot, uint32_t n) {
         const size_t i = (size_t)SpecQ::q() * n + slot;
         const float4 v = pb.nee[i];
-        float4 r = pb.spR[i], c = pb.spC[i];
+        float4 r = make_float4(0.0f, 0.0f, 0.0f, 0.0f), c = r;
+        if (valid) { r = pb.spR[i]; c = pb.spC[i]; }
         kahanAdd(r.x, c.x, v.x); kahanAdd(r.y, c.y, v.y); kahanAdd(r.z, c.z, v.z); kahanAdd(r.w, c.w, v.w);
         pb.spR[i] = r;
         pb.spC[i] = c;
+        valid = true;
     }
     __device__ __forceinline__ void end(const PathBuffers&, uint32_t, uint32_t, bool) {}
 };
@@ -425,10 +447,13 @@ __global__ __launch_bounds__(kShadeBlock) void k_logic(DevScene sc, PathBuffers 
         const float4 h = pb.hit[slot];
         const float4 o4 = pb.rayOrg[slot], d4 = pb.rayDir[slot];
         const uint32_t vis = pb.visible[slot];
-        const float wlOffset = S::N == 3 ? 0.0f : pb.wlOffset[slot];
+        const float wlOffset = S::N == 3 ? 0.0f : __uint_as_float(pb.hdr[slot].z);
 
         const uint32_t state = F_STATE(flags);
         if (state == ST_FIRST_HIT || state == ST_NEXT_HIT || state == ST_FINISH) {
+            // a path's first visit: throughput 1, no previous PDF, empty radiance sum (k_regen writes none of them)
+            if (state == ST_FIRST_HIT) { alpha = S(1.0f); bsdfPDFprev = 0.0f; }
+            sp.startPath(state == ST_FIRST_HIT, flags);
             Rng rng;
             rng.s0 = r4.x; rng.s1 = r4.y; rng.s2 = r4.z; rng.s3 = r4.w;
             uint32_t pathLength = F_PATHLEN(flags), wlSel = F_WLSEL(flags);
@@ -687,7 +712,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_logic(DevScene sc, PathBuffers 
             }
 
             // ---- store path state ---------------------------------------------------------------------------
-            if (leader) pb.flags[slot] = flags;
+            if (leader) pb.flags[slot] = flags | sp.validBits();
             sp.end(pb, slot, rp.numSlots, !emitRegen);
             if (!emitRegen) {
                 if (leader) pb.rng[slot] = make_uint4(rng.s0, rng.s1, rng.s2, rng.s3);
@@ -760,23 +785,27 @@ __global__ __launch_bounds__(kShadeBlock) void k_regen(DevScene sc, PathBuffers 
     if (i < n) {
         slot = pb.regenQueue[(size_t)shard * rp.shardCapacity + i];
         const uint32_t flags = pb.flags[slot];
-        uint32_t sampleIdx = pb.sampleIdx[slot];
+        const uint4 hdr = pb.hdr[slot];
+        uint32_t sampleIdx = hdr.x;
         if (F_HASPATH(flags)) {
             // sensor->add(p.x, p.y, wls, weight * C)  PathTracingRenderer.cpp:126-130
             S C, accR, accC;
-            float camW, unusedW;
-            SpecIO<S>::load(pb.spR, pb.camWeight, slot, rp.numSlots, C, camW);
-            SpecIO<S>::load(pb.accR, nullptr, slot, rp.numSlots, accR, unusedW);
-            SpecIO<S>::load(pb.accC, nullptr, slot, rp.numSlots, accC, unusedW);
+            float unusedW;
+            const float camW = __uint_as_float(hdr.y);
+            if (F_SPVALID(flags)) SpecIO<S>::load(pb.spR, nullptr, slot, rp.numSlots, C, unusedW);     // else the path gathered nothing: C = 0
+            // accR / accC interleave (pb.accC = pb.accR + 1, element stride 2): the pair is one 32-byte sector per slot
+            SpecIO<S>::load(pb.accR, nullptr, 2 * slot, 2 * rp.numSlots, accR, unusedW);
+            SpecIO<S>::load(pb.accC, nullptr, 2 * slot, 2 * rp.numSlots, accC, unusedW);
             const S weight = (S(1.0f) * S(1.0f)) * camW;
-            kahanAdd(accR, accC, storageAddend(weight * C, S::N == 3 ? 0.0f : pb.wlOffset[slot]));
-            SpecIO<S>::store(pb.accR, nullptr, slot, rp.numSlots, accR, 0.0f);
-            SpecIO<S>::store(pb.accC, nullptr, slot, rp.numSlots, accC, 0.0f);
+            kahanAdd(accR, accC, storageAddend(weight * C, S::N == 3 ? 0.0f : __uint_as_float(hdr.z)));
+            SpecIO<S>::store(pb.accR, nullptr, 2 * slot, 2 * rp.numSlots, accR, 0.0f);
+            SpecIO<S>::store(pb.accC, nullptr, 2 * slot, 2 * rp.numSlots, accC, 0.0f);
             ++sampleIdx;
         }
         const uint32_t stripe = slot / rp.numPixels;
         const uint32_t pix = slot - stripe * rp.numPixels;
         const uint32_t pass = rp.sppBegin + stripe + sampleIdx * rp.stripes;
+        uint4 newHdr = make_uint4(sampleIdx, 0u, 0u, 0u);
         if (pass >= rp.sppBegin + rp.sppCount) {
             pb.flags[slot] = F_MAKE((uint32_t)ST_IDLE, 0u, 0u, 0u, 0u, 0u);
             becameIdle = true;
@@ -821,14 +850,13 @@ __global__ __launch_bounds__(kShadeBlock) void k_regen(DevScene sc, PathBuffers 
             float camWeight = absDot(rayDir, lensN) / (sc.camera.areaPDF * dirPDF * selectWLPDF);
             pb.flags[slot] = F_MAKE((uint32_t)ST_FIRST_HIT, 0u, wl, 0u, 0u, 0u);
             pb.rng[slot] = make_uint4(rng.s0, rng.s1, rng.s2, rng.s3);
-            SpecIO<S>::store(pb.alpha, pb.pdfPrev, slot, rp.numSlots, S(1.0f), 0.0f);
-            SpecIO<S>::store(pb.spR, pb.camWeight, slot, rp.numSlots, S(), camWeight);
-            SpecIO<S>::store(pb.spC, nullptr, slot, rp.numSlots, S(), 0.0f);
-            if (S::N != 3) pb.wlOffset[slot] = wlOffset;
+            // alpha = 1, pdfPrev = 0 and sp = 0 are implied by ST_FIRST_HIT (see SpAcc): 48 B (RGB) / 196 B (spectral) not written
+            newHdr.y = __float_as_uint(camWeight);
+            newHdr.z = __float_as_uint(wlOffset);
             pb.rayOrg[slot] = make_float4(lensP.x, lensP.y, lensP.z, 0.0f);
             pb.rayDir[slot] = make_float4(rayDir.x, rayDir.y, rayDir.z, INFINITY);
         }
-        pb.sampleIdx[slot] = sampleIdx;
+        pb.hdr[slot] = newHdr;
     }
     // slots run out of samples only at the very end of a render() call, so this atomic is rare
     const uint64_t mi = __ballot(becameIdle);
@@ -842,13 +870,13 @@ __global__ void k_reset_slots(PathBuffers pb, RenderParams rp, uint32_t clearAcc
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;     // blockDim == kShadeBlock
     if (slot < rp.numSlots) {
         pb.flags[slot] = F_MAKE((uint32_t)ST_REGEN, 0u, 0u, 0u, 0u, 0u);
-        pb.sampleIdx[slot] = 0;
+        pb.hdr[slot] = make_uint4(0u, 0u, 0u, 0u);
         pb.visible[slot] = 0;
         // slot block b goes to region b % kShards at chunk b / kShards, exactly as k_logic would append it
         pb.regenQueue[(size_t)(blockIdx.x % kShards) * rp.shardCapacity + (blockIdx.x / kShards) * kShadeBlock + threadIdx.x] = slot;
         if (clearAccumulators) {
-            SpecIO<S>::store(pb.accR, nullptr, slot, rp.numSlots, S(), 0.0f);
-            SpecIO<S>::store(pb.accC, nullptr, slot, rp.numSlots, S(), 0.0f);
+            SpecIO<S>::store(pb.accR, nullptr, 2 * slot, 2 * rp.numSlots, S(), 0.0f);
+            SpecIO<S>::store(pb.accC, nullptr, 2 * slot, 2 * rp.numSlots, S(), 0.0f);
         }
     }
     if (blockIdx.x == 0) {
@@ -880,10 +908,10 @@ __global__ void k_resolve(PathBuffers pb, RenderParams rp, float* dst) {
     const uint32_t px = xy & 0xFFFFu, py = xy >> 16;
     S sum;
     float unusedW;
-    SpecIO<S>::load(pb.accR, nullptr, pix, rp.numSlots, sum, unusedW);
+    SpecIO<S>::load(pb.accR, nullptr, 2 * pix, 2 * rp.numSlots, sum, unusedW);
     for (uint32_t st = 1; st < rp.stripes; ++st) {
         S b;
-        SpecIO<S>::load(pb.accR, nullptr, st * rp.numPixels + pix, rp.numSlots, b, unusedW);
+        SpecIO<S>::load(pb.accR, nullptr, 2 * (st * rp.numPixels + pix), 2 * rp.numSlots, b, unusedW);
         sum = sum + b;
     }
     float* o = dst + ((size_t)py * rp.imageWidth + px) * S::N;

@@ -119,8 +119,9 @@ struct slrhip_ctx {
     DevArray<uint32_t> pixelXY;
     DevArray<uint4> rng;
     DevArray<float4> rayOrg, rayDir, hit, alpha, spR, spC, accR, accC, nee, shadowDir;
-    DevArray<float> pdfPrev, camWeight, wlOffset;
-    DevArray<uint32_t> flags, sampleIdx, visible, shadowQueue, regenQueue, queueCount, activeSlots;
+    DevArray<float> pdfPrev;
+    DevArray<uint4> hdr;
+    DevArray<uint32_t> flags, visible, shadowQueue, regenQueue, queueCount, activeSlots;
     DevArray<uint64_t> totals;
     DevArray<float> resolveScratch;
     PathBuffers buffers;
@@ -586,11 +587,11 @@ int slrhip_render_begin(slrhip_ctx* ctx, const slrhip_render_settings* st, slrhi
     HIP_TRY(ctx->rng.alloc(numSlots, true));
     HIP_TRY(ctx->rayOrg.alloc(numSlots, true)); HIP_TRY(ctx->rayDir.alloc(numSlots, true)); HIP_TRY(ctx->hit.alloc(numSlots, true));
     HIP_TRY(ctx->alpha.alloc(numSlots * planes, true)); HIP_TRY(ctx->spR.alloc(numSlots * planes, true)); HIP_TRY(ctx->spC.alloc(numSlots * planes, true));
-    HIP_TRY(ctx->accR.alloc(numSlots * planes, true)); HIP_TRY(ctx->accC.alloc(numSlots * planes, true)); HIP_TRY(ctx->nee.alloc(numSlots * planes, true));
+    HIP_TRY(ctx->accR.alloc(2 * numSlots * planes, true));      /* accR and accC interleaved */ HIP_TRY(ctx->nee.alloc(numSlots * planes, true));
     HIP_TRY(ctx->shadowDir.alloc(numSlots, true));
-    HIP_TRY(ctx->pdfPrev.alloc(spectral ? numSlots : 1, true)); HIP_TRY(ctx->camWeight.alloc(spectral ? numSlots : 1, true));
-    HIP_TRY(ctx->wlOffset.alloc(spectral ? numSlots : 1, true));
-    HIP_TRY(ctx->flags.alloc(numSlots, true)); HIP_TRY(ctx->sampleIdx.alloc(numSlots, true)); HIP_TRY(ctx->visible.alloc(numSlots, true));
+    HIP_TRY(ctx->pdfPrev.alloc(spectral ? numSlots : 1, true));
+    HIP_TRY(ctx->hdr.alloc(numSlots, true));
+    HIP_TRY(ctx->flags.alloc(numSlots, true)); HIP_TRY(ctx->visible.alloc(numSlots, true));
     // queue regions: slot block b appends to region b % kShards, so a region holds at most ceil(numBlocks / kShards) blocks
     const uint32_t numBlocks = (uint32_t)((numSlots + 255) / 256);
     const uint32_t shardCapacity = ((numBlocks + kShards - 1) / kShards) * 256;
@@ -604,9 +605,9 @@ int slrhip_render_begin(slrhip_ctx* ctx, const slrhip_render_settings* st, slrhi
 
     PathBuffers& pb = ctx->buffers;
     pb.rng = ctx->rng.ptr; pb.rayOrg = ctx->rayOrg.ptr; pb.rayDir = ctx->rayDir.ptr; pb.hit = ctx->hit.ptr;
-    pb.alpha = ctx->alpha.ptr; pb.spR = ctx->spR.ptr; pb.spC = ctx->spC.ptr; pb.accR = ctx->accR.ptr; pb.accC = ctx->accC.ptr;
+    pb.alpha = ctx->alpha.ptr; pb.spR = ctx->spR.ptr; pb.spC = ctx->spC.ptr; pb.accR = ctx->accR.ptr; pb.accC = ctx->accR.ptr + 1;
     pb.nee = ctx->nee.ptr;
-    pb.pdfPrev = spectral ? ctx->pdfPrev.ptr : nullptr; pb.camWeight = spectral ? ctx->camWeight.ptr : nullptr; pb.wlOffset = ctx->wlOffset.ptr; pb.shadowDir = ctx->shadowDir.ptr; pb.flags = ctx->flags.ptr; pb.sampleIdx = ctx->sampleIdx.ptr;
+    pb.pdfPrev = spectral ? ctx->pdfPrev.ptr : nullptr; pb.hdr = ctx->hdr.ptr; pb.shadowDir = ctx->shadowDir.ptr; pb.flags = ctx->flags.ptr;
     pb.visible = ctx->visible.ptr; pb.shadowQueue = ctx->shadowQueue.ptr; pb.regenQueue = ctx->regenQueue.ptr;
     pb.queueCount = ctx->queueCount.ptr; pb.activeSlots = ctx->activeSlots.ptr; pb.totals = ctx->totals.ptr;
     pb.pixelXY = ctx->pixelXY.ptr;
