@@ -1,958 +1,8 @@
-// pt_shade.hip — the shading half of the wavefront path tracer (gfx950, wave64).
-//
-// One path SLOT per (pixel, sample stripe).  A slot carries one light path at a time through the
-// reference's bounce loop (Renderers/PathTracingRenderer.cpp:137-262).  Per wavefront iteration:
-//
-//   k_regen          finished slots (compacted queue): add weight*C to the slot's pixel accumulator in
-//                    pass order — the Kahan sum of RGBStorage::add (RGBTypes.h:176-179), so the
-//                    framebuffer needs no atomics — then start the next sample of the same pixel:
-//                    Job::kernel's camera-ray half (PathTracingRenderer.cpp:100-120).
-//   k_trace_ws       every slot with a ray in flight (state flag) + the shadow-ray queue, one launch (pt_trace_ws.hip;
-//                    or the two batch kernels of pt_trace.hip)
-//   k_logic          every live slot: resolve the pending next-event estimate, shade the hit
-//                    (getSurfacePoint, emission + MIS, Russian roulette), then the next bounce: light
-//                    sampling + BSDF sampling (:161-221).  Emits the next extension ray in place, a shadow ray
-//                    (slot index into the shadow queue) and/or the slot index into the regen queue.
-//
-// Queues are slot-index lists in HBM, 16 regions (one per blockIdx % 16), filled by wave ballot + popcount prefix with ONE
-// atomic per workgroup per queue on a counter that has its own 128-byte line (per-wave atomics on one word were the
-// bottleneck of the first version).  All path state is SoA in 16-byte records so a wave's loads are 1 KiB bursts; the state
-// loads of k_logic are issued together at the top, and the material / light / spectrum tables live in LDS.
-#include <hip/hip_runtime.h>
-#include <stdlib.h>
-
-#include <string>
-
-#include "pt_bsdf.h"
-#include "pt_bsdf_multi.h"
-#include "pt_kernels.h"
+// pt_shade.hip — launchers of the shading half of the wavefront path tracer (gfx950, wave64) and the instantiations of its
+// small kernels; the kernel templates are in pt_shade_kernels.h, the k_logic instantiations in pt_shade_{rgb,spec16,specq,multi}.hip.
+#include "pt_shade_kernels.h"
 
 namespace slrhip {
-
-enum : uint32_t {
-    ST_IDLE = 0,            // no more samples for this slot
-    ST_REGEN = 1,           // in the regen queue: accumulate (if a path just ended) and start the next sample
-    ST_FIRST_HIT = 2,       // camera ray in flight        (PathTracingRenderer.cpp:147)
-    ST_NEXT_HIT = 3,        // BSDF-sampled ray in flight  (:225)
-    ST_FINISH = 4           // path ended while a shadow ray was still pending
-};
-// flags word: [2:0] state | [9:3] pathLength | [12] wlFlags.LambdaIsSelected | [13] previous direction was delta
-//             | [14] shadow ray pending | [15] a finished path awaits accumulation | [19:16] selectedLambda
-#define F_STATE(f) ((f) & 7u)
-#define F_PATHLEN(f) (((f) >> 3) & 127u)
-#define F_WL(f) (((f) >> 16) & 15u)
-#define F_WLSEL(f) (((f) >> 12) & 1u)
-#define F_DELTA(f) (((f) >> 13) & 1u)
-#define F_SHADOW(f) (((f) >> 14) & 1u)
-#define F_HASPATH(f) (((f) >> 15) & 1u)
-#define F_SPVALID(f) (((f) >> 10) & 1u)      // spectral mode: the path's radiance sum in HBM has been written since the path began
-#define F_MAKE(state, len, wl, wlsel, delta, shadow) \
-    ((state) | ((len) << 3) | ((wl) << 16) | ((wlsel) << 12) | ((delta) << 13) | ((shadow) << 14))
-
-static const int kShadeBlock = 256;
-static const int kLdsMaterials = 32;
-static const int kLdsLights = 16;
-static const int kLdsSpectra = 96;
-static const int kLdsPoolFloats = 6144;     // 24 KiB: the spectrum sample tables of a scene (spectral mode), staged per workgroup
-
-// Spectrum-valued path state in HBM.  RGB: one float4 per slot, the scalar that travels with it in .w.
-// Spectral: four float4 planes per array (plane p of slot i at [p * numSlots + i], so every plane is a coalesced
-// stream) and the scalar in an array of its own.
-template <class S> struct SpecIO;
-template <> struct SpecIO<RGB> {
-    static __device__ __forceinline__ void load(const float4* a, const float* /*scalars*/, uint32_t slot, uint32_t /*n*/, RGB& v, float& w) {
-        const float4 q = a[slot];
-        v = RGB(q.x, q.y, q.z); w = q.w;
-    }
-    static __device__ __forceinline__ void store(float4* a, float* /*scalars*/, uint32_t slot, uint32_t /*n*/, const RGB& v, float w) {
-        a[slot] = make_float4(v.r, v.g, v.b, w);
-    }
-};
-template <> struct SpecIO<Spec16> {
-    static __device__ __forceinline__ void load(const float4* a, const float* scalars, uint32_t slot, uint32_t n, Spec16& v, float& w) {
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const float4 q = a[(size_t)p * n + slot];
-            v.c[4 * p] = q.x; v.c[4 * p + 1] = q.y; v.c[4 * p + 2] = q.z; v.c[4 * p + 3] = q.w;
-        }
-        w = scalars ? scalars[slot] : 0.0f;
-    }
-    static __device__ __forceinline__ void store(float4* a, float* scalars, uint32_t slot, uint32_t n, const Spec16& v, float w) {
-#pragma unroll
-        for (int p = 0; p < 4; ++p) a[(size_t)p * n + slot] = make_float4(v.c[4 * p], v.c[4 * p + 1], v.c[4 * p + 2], v.c[4 * p + 3]);
-        if (scalars) scalars[slot] = w;
-    }
-};
-
-template <> struct SpecIO<SpecQ> {
-    // lane q of the quad moves plane q (components 4q .. 4q+3); the scalar is read by all four lanes and written by lane 0
-    static __device__ __forceinline__ void load(const float4* a, const float* scalars, uint32_t slot, uint32_t n, SpecQ& v, float& w) {
-        const float4 t = a[(size_t)SpecQ::q() * n + slot];
-        v.c[0] = t.x; v.c[1] = t.y; v.c[2] = t.z; v.c[3] = t.w;
-        w = scalars ? scalars[slot] : 0.0f;
-    }
-    static __device__ __forceinline__ void store(float4* a, float* scalars, uint32_t slot, uint32_t n, const SpecQ& v, float w) {
-        a[(size_t)SpecQ::q() * n + slot] = make_float4(v.c[0], v.c[1], v.c[2], v.c[3]);
-        if (scalars && SpecQ::q() == 0) scalars[slot] = w;
-    }
-};
-
-// Material access per mode
-template <class S> struct MatIO;
-template <> struct MatIO<RGB> {
-    template <bool LDS>
-    static __device__ __forceinline__ Mat<RGB> load(const DevScene& sc, const float4* ldsMats, uint32_t idx, float) {
-        return loadMat(LDS ? reinterpret_cast<const DevMaterial*>(ldsMats) + idx : sc.materials + idx);
-    }
-    template <bool LDS>
-    static __device__ __forceinline__ RGB emittance(const DevScene& sc, const float4* ldsMats, uint32_t idx, float) {
-        return loadEmittance(LDS ? reinterpret_cast<const DevMaterial*>(ldsMats) + idx : sc.materials + idx);
-    }
-};
-// spectral mode, LDS tables: [DevMaterialS x kLdsMaterials][DevSpectrum x kLdsSpectra][sample pool, kLdsPoolFloats floats]
-__device__ __forceinline__ const float* ldsPoolOf(const float4* ldsMats) {
-    return reinterpret_cast<const float*>(ldsMats + 2 * kLdsMaterials + 2 * kLdsSpectra);
-}
-template <class S> struct MatIOSpectral {
-    // spectral mode: the LDS table holds the DevMaterialS records (2 x float4 each) followed by the DevSpectrum records
-    template <bool LDS>
-    static __device__ __forceinline__ Mat<S> load(const DevScene& sc, const float4* ldsMats, uint32_t idx, float wlOffset) {
-        const DevMaterialS* mats = LDS ? reinterpret_cast<const DevMaterialS*>(ldsMats) : sc.materialsS;
-        const DevSpectrum* spectra = LDS ? reinterpret_cast<const DevSpectrum*>(ldsMats + 2 * kLdsMaterials) : sc.spectra;
-        return loadMatSpectral<S>(mats, idx, spectra, LDS ? ldsPoolOf(ldsMats) : sc.spectrumPool, wlOffset);
-    }
-    template <bool LDS>
-    static __device__ __forceinline__ S emittance(const DevScene& sc, const float4* ldsMats, uint32_t idx, float wlOffset) {
-        const DevMaterialS* mats = LDS ? reinterpret_cast<const DevMaterialS*>(ldsMats) : sc.materialsS;
-        const DevSpectrum* spectra = LDS ? reinterpret_cast<const DevSpectrum*>(ldsMats + 2 * kLdsMaterials) : sc.spectra;
-        return evalSpectrum<S>(spectra, LDS ? ldsPoolOf(ldsMats) : sc.spectrumPool, mats[idx].spec[3], wlOffset);
-    }
-};
-template <> struct MatIO<Spec16> : MatIOSpectral<Spec16> {};
-template <> struct MatIO<SpecQ> : MatIOSpectral<SpecQ> {};
-
-// Append `slot` to the workgroup's region of up to two queues: wave ballots + popcount prefixes, the four
-// wave counts meet in LDS, ONE atomic per queue per workgroup (on the region's own counter line).
-struct PushLds {
-    uint32_t count[Q_KINDS][4];
-    uint32_t base[Q_KINDS];
-};
-__device__ __forceinline__ void blockPush(PushLds& pl, bool emit0, bool emit1, uint32_t slot, uint32_t* queue0, uint32_t* queue1,
-                                          uint32_t* counters /* set being filled */, uint32_t shardCapacity) {
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t shard = blockIdx.x % kShards;
-    const uint64_t m0 = __ballot(emit0), m1 = __ballot(emit1);
-    if (lane == 0) { pl.count[0][wave] = (uint32_t)__popcll(m0); pl.count[1][wave] = (uint32_t)__popcll(m1); }
-    __syncthreads();
-    if (threadIdx.x < Q_KINDS) {
-        const uint32_t q = threadIdx.x;
-        const uint32_t total = pl.count[q][0] + pl.count[q][1] + pl.count[q][2] + pl.count[q][3];
-        pl.base[q] = total ? atomicAdd(&counters[(q * kShards + shard) * kCounterStride], total) : 0u;
-    }
-    __syncthreads();
-    const uint64_t below = (1ull << lane) - 1ull;
-    if (emit0) {
-        uint32_t off = pl.base[0];
-        for (uint32_t w = 0; w < wave; ++w) off += pl.count[0][w];
-        queue0[(size_t)shard * shardCapacity + off + __popcll(m0 & below)] = slot;
-    }
-    if (emit1) {
-        uint32_t off = pl.base[1];
-        for (uint32_t w = 0; w < wave; ++w) off += pl.count[1][w];
-        queue1[(size_t)shard * shardCapacity + off + __popcll(m1 & below)] = slot;
-    }
-}
-
-struct SurfPt {       // Core/geometry.h:239-258 (fields the path uses)
-    V3 p;
-    V3 gNormal;
-    Frame frame;
-    uint32_t material;
-    int32_t light;
-    float areaPDF;
-};
-
-// RegularConstantDiscrete1D::sample, Core/distributions.cpp:97-107
-__device__ __forceinline__ uint32_t selectLight(const DevScene& sc, const float* cdf, const float* pmf, float u, float* prob) {
-    int idx = (int)sc.numLights;
-    for (int d = (int)sc.lightPow2; d > 0; d >>= 1)
-        if (idx - d > 0 && cdf[idx - d] >= u) idx -= d;
-    --idx;
-    *prob = pmf[idx];
-    return (uint32_t)idx;
-}
-
-// ---- environment sphere (RGB mode) ---------------------------------------------------------------------------------------
-// RegularConstantContinuous1D::sample, Core/distributions.cpp:168-179
-__device__ __forceinline__ float sampleContinuous1D(const float* cdf, const float* pdfTable, uint32_t numValues, float u, float* pdf) {
-    int idx = (int)numValues;
-    uint32_t p2 = numValues;
-    p2 |= p2 >> 1; p2 |= p2 >> 2; p2 |= p2 >> 4; p2 |= p2 >> 8; p2 |= p2 >> 16; p2 -= p2 >> 1;       // prevPowerOf2
-    for (int d = (int)p2; d > 0; d >>= 1)
-        if (idx - d > 0 && cdf[idx - d] >= u) idx -= d;
-    --idx;
-    *pdf = pdfTable[idx];
-    float t = (u - cdf[idx]) / (cdf[idx + 1] - cdf[idx]);
-    return ((float)idx + t) / (float)numValues;
-}
-// ImageSpectrumTexture::evaluate (Textures/image_textures.cpp:13-20,57-63) + IBLEmission::emittance (IBLEmission.cpp:15-17)
-__device__ __forceinline__ RGB envEmittance(const DevScene& sc, float tcU, float tcV) {
-    float u = fmodf(tcU, 1.0f);
-    float v = fmodf(tcV, 1.0f);
-    u += u < 0 ? 1.0f : 0.0f;
-    v += v < 0 ? 1.0f : 0.0f;
-    uint32_t px = min((uint32_t)((float)sc.envWidth * u), sc.envWidth - 1);
-    uint32_t py = min((uint32_t)((float)sc.envHeight * v), sc.envHeight - 1);
-    const float* t = sc.envTexels + ((size_t)py * sc.envWidth + px) * 3;
-    return ((float)kPi * RGB(t[0], t[1], t[2])) * sc.envScale;
-}
-// UpsampledContinuousSpectrumTemplate::evaluate with its grid look-up (SpectrumTypes.h:239-339) at run time: the spectral
-// build's environment texels are (u, v, s) (image_textures.cpp:23-32).  Cell search and weights are per path (scalar), the
-// 16-wavelength interpolation goes through S::make like every other spectrum.
-template <class S>
-__device__ __forceinline__ S evaluateUpsampledRuntime(const DevScene& sc, float u, float v, float scale, float wlOffset) {
-    if (u < 0.0f || u >= (float)sc.gridWidth || v < 0.0f || v >= (float)sc.gridHeight) return S();
-    const int32_t ui = (int32_t)u, vi = (int32_t)v;
-    const uint8_t* cell = sc.gridCells + (size_t)(ui + (int32_t)sc.gridWidth * vi) * 8;
-    const uint2 cw = *reinterpret_cast<const uint2*>(cell);                      // inside, num_points, idx[0..5]
-    const uint32_t inside = cw.x & 0xFFu, numPoints = (cw.x >> 8) & 0xFFu;
-    const uint32_t idx6[6] = {(cw.x >> 16) & 0xFFu, cw.x >> 24, cw.y & 0xFFu, (cw.y >> 8) & 0xFFu, (cw.y >> 16) & 0xFFu, cw.y >> 24};
-    uint32_t used0 = 255u, used1 = 255u, used2 = 255u, used3 = 255u;
-    float w0 = 0, w1 = 0, w2 = 0, w3 = 0;
-    if (inside) {
-        const float s = u - (float)ui, t = v - (float)vi;
-        w0 = (1 - s) * (1 - t); w1 = s * (1 - t); w2 = (1 - s) * t; w3 = s * t;
-        used0 = idx6[0]; used1 = idx6[1]; used2 = idx6[2]; used3 = idx6[3];
-    }
-    else {
-        const float2* uv = reinterpret_cast<const float2*>(sc.pointUV);
-        const float2 p0 = uv[idx6[0]], p1 = uv[idx6[1]];
-        const float ex = u - p0.x, ey = v - p0.y;
-        float e0x = p1.x - p0.x, e0y = p1.y - p0.y;
-        float uu = e0x * ey - ex * e0y;
-        for (uint32_t i = 1; i < numPoints; ++i) {
-            const uint32_t k = i % (numPoints - 1) + 1;
-            // idx6[k] with a run-time k: select chain over the six bytes
-            const uint32_t idx = k == 1 ? idx6[1] : k == 2 ? idx6[2] : k == 3 ? idx6[3] : k == 4 ? idx6[4] : idx6[5];
-            const uint32_t idxI = i == 1 ? idx6[1] : i == 2 ? idx6[2] : i == 3 ? idx6[3] : i == 4 ? idx6[4] : idx6[5];
-            const float2 pk = uv[idx];
-            const float e1x = pk.x - p0.x, e1y = pk.y - p0.y;
-            const float vv = ex * e1y - e1x * ey;
-            const float area = e0x * e1y - e1x * e0y;
-            const float bu = uu / area, bv = vv / area;
-            const float bw = 1.0f - bu - bv;
-            if ((double)bu < -1e-6 || (double)bv < -1e-6 || (double)bw < -1e-6) {
-                uu = -vv;
-                e0x = e1x;
-                e0y = e1y;
-                continue;
-            }
-            w0 = bu; w1 = bv; w2 = bw;
-            used0 = idx; used1 = idxI; used2 = idx6[0];
-            break;
-        }
-    }
-    if (used0 == 255u) return S();
-    const uint32_t nw = 95;
-    const float* t0 = sc.pointSpectrum + (size_t)used0 * nw;
-    const float* t1 = sc.pointSpectrum + (size_t)used1 * nw;
-    const float* t2 = sc.pointSpectrum + (size_t)used2 * nw;
-    const float* t3 = sc.pointSpectrum + (size_t)(used3 == 255u ? used0 : used3) * nw;
-    const bool four = used3 != 255u;
-    S ret = S::make([&](int i) {
-        float p = (wavelengthOf(i, wlOffset) - 360.0f) / (830.0f - 360.0f);
-        float sBinF = p * (float)(nw - 1);
-        uint32_t sBin = (uint32_t)sBinF;
-        uint32_t sBinNext = (sBin + 1 < nw) ? (sBin + 1) : (nw - 1);
-        float t = sBinF - (float)sBin;
-        float r = 0.0f;
-        r += w0 * (t0[sBin] * (1 - t) + t0[sBinNext] * t);
-        r += w1 * (t1[sBin] * (1 - t) + t1[sBinNext] * t);
-        r += w2 * (t2[sBin] * (1 - t) + t2[sBinNext] * t);
-        if (four) r += w3 * (t3[sBin] * (1 - t) + t3[sBinNext] * t);
-        return r;
-    });
-    return ret * scale;
-}
-template <class S>
-__device__ __forceinline__ S envEmittanceSpectral(const DevScene& sc, float tcU, float tcV, float wlOffset) {
-    float u = fmodf(tcU, 1.0f);
-    float v = fmodf(tcV, 1.0f);
-    u += u < 0 ? 1.0f : 0.0f;
-    v += v < 0 ? 1.0f : 0.0f;
-    uint32_t px = min((uint32_t)((float)sc.envWidth * u), sc.envWidth - 1);
-    uint32_t py = min((uint32_t)((float)sc.envHeight * v), sc.envHeight - 1);
-    const float* t = sc.envTexels + ((size_t)py * sc.envWidth + px) * 3;
-    const float kEqualEnergyReflectance = 0.009355121400914532f;                 // Upsampling::EqualEnergyReflectance
-    const S tex = evaluateUpsampledRuntime<S>(sc, t[0], t[1], t[2] / kEqualEnergyReflectance, wlOffset);
-    return ((float)kPi * tex) * sc.envScale;                                     // IBLEmission::emittance
-}
-template <class S> __device__ __forceinline__ S envEmittanceS(const DevScene& sc, float u, float v, float wlOffset);
-template <> __device__ __forceinline__ RGB envEmittanceS<RGB>(const DevScene& sc, float u, float v, float) { return envEmittance(sc, u, v); }
-template <> __device__ __forceinline__ Spec16 envEmittanceS<Spec16>(const DevScene& sc, float u, float v, float o) { return envEmittanceSpectral<Spec16>(sc, u, v, o); }
-template <> __device__ __forceinline__ SpecQ envEmittanceS<SpecQ>(const DevScene& sc, float u, float v, float o) { return envEmittanceSpectral<SpecQ>(sc, u, v, o); }
-// InfiniteSphereSurfaceObject::evaluateAreaPDF, SurfaceObject.cpp:217-222 (RegularConstantContinuous2D::evaluatePDF :218-224)
-__device__ __forceinline__ float envAreaPDF(const DevScene& sc, float phi, float theta) {
-    float d0 = (float)((double)phi / (2 * kPi)), d1 = (float)((double)theta / kPi);
-    uint32_t idx1D = min((uint32_t)((float)sc.envMapHeight * d1), sc.envMapHeight - 1);
-    // the reference indexes with no clamp; phi / 2pi can round up to 1.0f, which would read past the table
-    uint32_t iTop = min((uint32_t)(int32_t)(d1 * (float)sc.envMapHeight), sc.envMapHeight - 1);
-    uint32_t iRow = min((uint32_t)(int32_t)(d0 * (float)sc.envMapWidth), sc.envMapWidth - 1);
-    float uvPDF = sc.envTopPDF[iTop] * sc.envRowPDF[(size_t)idx1D * sc.envMapWidth + iRow];
-    return (float)((double)uvPDF / (2 * kPi * kPi * (double)sinf(theta)));
-}
-
-// SampledSpectrumSum sp of Job::contribution (PathTracingRenderer.cpp:141): see the note at its use in k_logic.
-template <class S> struct SpAcc;
-// A path starts with sp = 0 (and alpha = 1, no previous PDF): k_regen does not write those records, the first k_logic visit
-// (state FIRST_HIT) supplies the values instead of what it loaded.  RGB keeps the pair in registers and always stores it,
-// so it is valid from then on; the spectral variants update HBM only when a contribution arrives and track that in `valid`
-// (flag bit 10), which k_regen consults before reading the sum.
-template <> struct SpAcc<RGB> {
-    RGB r, c, nee;
-    __device__ __forceinline__ void begin(const PathBuffers& pb, uint32_t slot, uint32_t n) {
-        float unused;
-        SpecIO<RGB>::load(pb.spR, nullptr, slot, n, r, unused);
-        SpecIO<RGB>::load(pb.spC, nullptr, slot, n, c, unused);
-        SpecIO<RGB>::load(pb.nee, nullptr, slot, n, nee, unused);
-    }
-    __device__ __forceinline__ void startPath(bool first, uint32_t) { if (first) { r = RGB(); c = RGB(); } }
-    __device__ __forceinline__ uint32_t validBits() const { return 1u << 10; }
-    __device__ __forceinline__ void addPendingNee(const PathBuffers&, uint32_t, uint32_t) { kahanAdd(r, c, nee); }
-    __device__ __forceinline__ void add(const PathBuffers&, uint32_t, uint32_t, const RGB& v) { kahanAdd(r, c, v); }
-    __device__ __forceinline__ void end(const PathBuffers& pb, uint32_t slot, uint32_t n, bool pathContinues) {
-        SpecIO<RGB>::store(pb.spR, nullptr, slot, n, r, 0.0f);
-        if (pathContinues) SpecIO<RGB>::store(pb.spC, nullptr, slot, n, c, 0.0f);       // a finished path only hands over the sum
-    }
-};
-template <> struct SpAcc<Spec16> {
-    bool valid;
-    __device__ __forceinline__ void begin(const PathBuffers&, uint32_t, uint32_t) {}
-    __device__ __forceinline__ void startPath(bool first, uint32_t flags) { valid = !first && F_SPVALID(flags); }
-    __device__ __forceinline__ uint32_t validBits() const { return valid ? 1u << 10 : 0u; }
-    __device__ __forceinline__ void add(const PathBuffers& pb, uint32_t slot, uint32_t n, const Spec16& v) {
-        // plane by plane: 4 components of the Kahan pair in flight at a time
-        const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            float4 r = zero, c = zero;
-            if (valid) { r = pb.spR[(size_t)p * n + slot]; c = pb.spC[(size_t)p * n + slot]; }
-            kahanAdd(r.x, c.x, v.c[4 * p]); kahanAdd(r.y, c.y, v.c[4 * p + 1]);
-            kahanAdd(r.z, c.z, v.c[4 * p + 2]); kahanAdd(r.w, c.w, v.c[4 * p + 3]);
-            pb.spR[(size_t)p * n + slot] = r;
-            pb.spC[(size_t)p * n + slot] = c;
-        }
-        valid = true;
-    }
-    __device__ __forceinline__ void addPendingNee(const PathBuffers& pb, uint32_t slot, uint32_t n) {
-        const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const float4 v = pb.nee[(size_t)p * n + slot];
-            float4 r = zero, c = zero;
-            if (valid) { r = pb.spR[(size_t)p * n + slot]; c = pb.spC[(size_t)p * n + slot]; }
-            kahanAdd(r.x, c.x, v.x); kahanAdd(r.y, c.y, v.y); kahanAdd(r.z, c.z, v.z); kahanAdd(r.w, c.w, v.w);
-            pb.spR[(size_t)p * n + slot] = r;
-            pb.spC[(size_t)p * n + slot] = c;
-        }
-        valid = true;
-    }
-    __device__ __forceinline__ void end(const PathBuffers&, uint32_t, uint32_t, bool) {}
-};
-
-template <> struct SpAcc<SpecQ> {
-    bool valid;
-    __device__ __forceinline__ void begin(const PathBuffers&, uint32_t, uint32_t) {}
-    __device__ __forceinline__ void startPath(bool first, uint32_t flags) { valid = !first && F_SPVALID(flags); }
-    __device__ __forceinline__ uint32_t validBits() const { return valid ? 1u << 10 : 0u; }
-    __device__ __forceinline__ void add(const PathBuffers& pb, uint32_t slot, uint32_t n, const SpecQ& v) {
-        const size_t i = (size_t)SpecQ::q() * n + slot;
-        float4 r = make_float4(0.0f, 0.0f, 0.0f, 0.0f), c = r;
-        if (valid) { r = pb.spR[i]; c = pb.spC[i]; }
-        kahanAdd(r.x, c.x, v.c[0]); kahanAdd(r.y, c.y, v.c[1]); kahanAdd(r.z, c.z, v.c[2]); kahanAdd(r.w, c.w, v.c[3]);
-        pb.spR[i] = r;
-        pb.spC[i] = c;
-        valid = true;
-    }
-    __device__ __forceinline__ void addPendingNee(const PathBuffers& pb, uint32_t slot, uint32_t n) {
-        const size_t i = (size_t)SpecQ::q() * n + slot;
-        const float4 v = pb.nee[i];
-        float4 r = make_float4(0.0f, 0.0f, 0.0f, 0.0f), c = r;
-        if (valid) { r = pb.spR[i]; c = pb.spC[i]; }
-        kahanAdd(r.x, c.x, v.x); kahanAdd(r.y, c.y, v.y); kahanAdd(r.z, c.z, v.z); kahanAdd(r.w, c.w, v.w);
-        pb.spR[i] = r;
-        pb.spC[i] = c;
-        valid = true;
-    }
-    __device__ __forceinline__ void end(const PathBuffers&, uint32_t, uint32_t, bool) {}
-};
-
-template <bool SPECTRAL>
-struct ShadeLds {
-    // RGB: DevMaterial = 5 x float4 each.  Spectral: DevMaterialS (2 x float4 each), DevSpectrum (2 x float4 each), then the
-    // spectrum sample pool: evaluating a spectrum is 16 x 2 scattered 16-byte reads per slot, which the vector L1 serves at
-    // one cache line per clock (measured: the look-ups were 1.0-1.6 ms of a 1.4-2.0 ms launch); LDS serves them in banks
-    float4 mats[SPECTRAL ? kLdsMaterials * 2 + kLdsSpectra * 2 + kLdsPoolFloats / 4 : kLdsMaterials * 5];
-    float4 lights[kLdsLights * 9];         // LightTri   = 9 x float4
-    float lightPMF[kLdsLights];
-    float lightCDF[kLdsLights + 1];
-};
-
-template <class S, bool LDS_TABLES, bool MF, bool MULTI = false>
-__global__ __launch_bounds__(kShadeBlock) void k_logic(DevScene sc, PathBuffers pb, RenderParams rp, uint32_t parity) {
-    __shared__ ShadeLds<S::N != 3> lds;
-    __shared__ PushLds pushLds;
-    if (LDS_TABLES) {
-        if (S::N == 3) {
-            const float4* gm = reinterpret_cast<const float4*>(sc.materials);
-            for (uint32_t i = threadIdx.x; i < sc.numMaterials * 5; i += kShadeBlock) lds.mats[i] = gm[i];
-        }
-        else {
-            const float4* gm = reinterpret_cast<const float4*>(sc.materialsS);
-            const float4* gs = reinterpret_cast<const float4*>(sc.spectra);
-            for (uint32_t i = threadIdx.x; i < sc.numMaterials * 2; i += kShadeBlock) lds.mats[i] = gm[i];
-            for (uint32_t i = threadIdx.x; i < sc.numSpectra * 2; i += kShadeBlock) lds.mats[2 * kLdsMaterials + i] = gs[i];
-            const float4* gp = reinterpret_cast<const float4*>(sc.spectrumPool);
-            for (uint32_t i = threadIdx.x; i < (sc.numSpectrumData + 3) / 4; i += kShadeBlock) lds.mats[2 * kLdsMaterials + 2 * kLdsSpectra + i] = gp[i];
-        }
-        const float4* gl = reinterpret_cast<const float4*>(sc.lightTris);
-        for (uint32_t i = threadIdx.x; i < sc.numLights * 9; i += kShadeBlock) lds.lights[i] = gl[i];
-        if (threadIdx.x < sc.numLights) lds.lightPMF[threadIdx.x] = sc.lightPMF[threadIdx.x];
-        if (threadIdx.x <= sc.numLights) lds.lightCDF[threadIdx.x] = sc.lightCDF[threadIdx.x];
-        __syncthreads();
-    }
-    const float* lightPMF = LDS_TABLES ? lds.lightPMF : sc.lightPMF;
-    const float* lightCDF = LDS_TABLES ? lds.lightCDF : sc.lightCDF;
-
-    // S::LANES adjacent lanes share one slot (SpecQ: 4, each holding a quarter of the spectrum; the per-path scalar work is
-    // replicated, identically, in all of them); the first of them ("leader") writes the scalar state and the queue entries
-    constexpr uint32_t L = S::LANES;
-    const uint32_t slot = (blockIdx.x * kShadeBlock + threadIdx.x) / L;
-    const bool leader = L == 1 || (threadIdx.x & (L - 1)) == 0;
-    bool emitExt = false, emitShadow = false, emitRegen = false;
-    uint32_t* qw = pb.queueCount + (parity ^ 1) * kQueueSetWords;
-
-    if (slot < rp.numSlots) {
-        // ---- all state loads up front: one memory round trip instead of a dependent chain -----------
-        uint32_t flags = pb.flags[slot];
-        const uint4 r4 = pb.rng[slot];
-        // The path's radiance sum (Kahan pair) and the pending light sample: RGB keeps them in registers (3 x 16 B,
-        // requested with everything else); in spectral mode they are 3 x 64 B that most visits never touch, so they
-        // stay in HBM and SpAcc updates them in place when a contribution actually arrives.
-        S alpha;
-        SpAcc<S> sp;
-        float bsdfPDFprev;
-        SpecIO<S>::load(pb.alpha, pb.pdfPrev, slot, rp.numSlots, alpha, bsdfPDFprev);
-        sp.begin(pb, slot, rp.numSlots);
-        const float4 h = pb.hit[slot];
-        const float4 o4 = pb.rayOrg[slot], d4 = pb.rayDir[slot];
-        const uint32_t vis = pb.visible[slot];
-        const float wlOffset = S::N == 3 ? 0.0f : __uint_as_float(pb.hdr[slot].z);
-
-        const uint32_t state = F_STATE(flags);
-        if (state == ST_FIRST_HIT || state == ST_NEXT_HIT || state == ST_FINISH) {
-            // a path's first visit: throughput 1, no previous PDF, empty radiance sum (k_regen writes none of them)
-            if (state == ST_FIRST_HIT) { alpha = S(1.0f); bsdfPDFprev = 0.0f; }
-            sp.startPath(state == ST_FIRST_HIT, flags);
-            Rng rng;
-            rng.s0 = r4.x; rng.s1 = r4.y; rng.s2 = r4.z; rng.s3 = r4.w;
-            uint32_t pathLength = F_PATHLEN(flags), wlSel = F_WLSEL(flags);
-            const uint32_t wl = F_WL(flags);
-            V3 rayOrg(o4.x, o4.y, o4.z), rayDir(d4.x, d4.y, d4.z);
-            float rayTmin = 0.0f;
-            SurfPt surf;
-            V3 dirOut_sn;
-            bool haveSurf = false;
-            bool finish = false;
-            const uint32_t tri = __float_as_uint(h.x);
-
-            // the hit triangle's shading record: issued before anything else is computed
-            float4 q0, q1, q2, q3, q4, q5;
-            const bool hasHit = state != ST_FINISH && tri != 0xFFFFFFFFu;
-            if (hasHit) {
-                const float4* st = reinterpret_cast<const float4*>(sc.shadeTris) + (size_t)tri * 6;
-                q0 = st[0]; q1 = st[1]; q2 = st[2]; q3 = st[3]; q4 = st[4]; q5 = st[5];
-            }
-
-            // ---- 1. resolve the pending next-event estimate (:180,202) ---------------------------------
-            if (F_SHADOW(flags) && vis) sp.addPendingNee(pb, slot, rp.numSlots);
-
-            // ---- 2. the hit that just came back ------------------------------------------------------------
-            Mat<S> m;
-            if (!hasHit) {
-                finish = true;                      // ST_FINISH, or a miss: :148 return Zero / :226 break
-                if (state != ST_FINISH && sc.hasEnv) {
-                    // the ray left the scene: Scene::intersect falls through to the environment sphere (SurfaceObject.cpp:411-414).
-                    // InfiniteSphere::intersect / getSurfacePoint (Surface/InfiniteSphere.cpp:34-59), Vector3::toPolarYUp (Vector3.h:72-75)
-                    float theta = acosf(fminf(1.0f, fmaxf(-1.0f, rayDir.y)));
-                    float phi = fmodf((float)((double)atan2f(-rayDir.x, rayDir.z) + 2 * kPi), (float)(2 * kPi));
-                    float texU = (float)((double)phi / (2 * kPi)), texV = (float)((double)theta / kPi);
-                    // emittance x IBLEDF::evaluate = 1 / pi (EDFs/IBLEDF.cpp:19-23)
-                    S Le = envEmittanceS<S>(sc, texU, texV, wlOffset) * S((float)(1.0 / kPi));
-                    if (state == ST_FIRST_HIT) {
-                        sp.add(pb, slot, rp.numSlots, alpha * Le);             // :152-157, atInfinity -> return sp
-                    }
-                    else {
-                        // implicit light sampling :232-250; the path ends at infinity before Russian roulette
-                        float sumImps = sc.aggImportance + 1.0f;
-                        float lightProb = 1.0f / sumImps;                        // Scene::evaluateProb SurfaceObject.cpp:456-457
-                        V3 gN = -rayDir;
-                        float lightPDF = lightProb * envAreaPDF(sc, phi, theta) * 1.0f / absDot(rayDir, gN);
-                        float MISWeight = 1.0f;
-                        if (!F_DELTA(flags))
-                            MISWeight = (bsdfPDFprev * bsdfPDFprev) / (lightPDF * lightPDF + bsdfPDFprev * bsdfPDFprev);
-                        sp.add(pb, slot, rp.numSlots, alpha * Le * MISWeight);
-                    }
-                }
-            }
-            else {
-                // Triangle::getSurfacePoint, Surface/TriangleMesh.cpp:180-215.  isect.p = org + dir * t (:170)
-                surf.p = rayOrg + rayDir * h.y;
-                surf.gNormal = V3(q3.w, q4.w, q5.w);
-                surf.material = __float_as_uint(q0.w);
-                surf.light = (int32_t)__float_as_uint(q1.w);
-                surf.areaPDF = q2.w;
-                m = MatIO<S>::template load<LDS_TABLES>(sc, lds.mats, surf.material, wlOffset);
-                const float b0 = h.z, b1 = h.w;
-                const float b2 = 1.0f - b0 - b1;
-                surf.frame.z = normalize(b0 * xyz(q0) + b1 * xyz(q1) + b2 * xyz(q2));
-                surf.frame.x = normalize(b0 * xyz(q3) + b1 * xyz(q4) + b2 * xyz(q5));
-                const float dotNT = dot(surf.frame.z, surf.frame.x);
-                if (fabsf(dotNT) >= 0.01f) surf.frame.x = normalize(surf.frame.x - dotNT * surf.frame.z);
-                surf.frame.y = cross(surf.frame.z, surf.frame.x);
-                haveSurf = true;
-                dirOut_sn = surf.frame.toLocal(-rayDir);
-                if (surf.light >= 0) {
-                    S Le = MatIO<S>::template emittance<LDS_TABLES>(sc, lds.mats, surf.material, wlOffset) * S(diffuseEDF(dirOut_sn));
-                    if (state == ST_FIRST_HIT) {
-                        sp.add(pb, slot, rp.numSlots, alpha * Le);             // :152-156
-                    }
-                    else {
-                        // implicit light sampling with MIS :232-249
-                        float lightProb = lightPMF[surf.light] * 1.0f;          // SurfaceObject.cpp:295-298, :78-80
-                        if (sc.hasEnv) lightProb = sc.aggImportance / (sc.aggImportance + 1.0f) * lightProb;   // Scene::evaluateProb :459
-                        float dist2 = sqLength(rayOrg - surf.p);
-                        float lightPDF = lightProb * surf.areaPDF * dist2 / absDot(rayDir, surf.gNormal);
-                        float MISWeight = 1.0f;
-                        if (!F_DELTA(flags))
-                            MISWeight = (bsdfPDFprev * bsdfPDFprev) / (lightPDF * lightPDF + bsdfPDFprev * bsdfPDFprev);
-                        sp.add(pb, slot, rp.numSlots, alpha * Le * MISWeight);
-                    }
-                }
-                if (state == ST_NEXT_HIT) {
-                    // Russian roulette :254-258 (initY = importance(One) evaluated like the reference)
-                    float initY = importance(S(1.0f), wl);
-                    float continueProb = fminf(importance(alpha, wl) / initY, 1.0f);
-                    if (rng.nextFloat() < continueProb) alpha = alpha / continueProb;
-                    else finish = true;
-                }
-            }
-
-            // ---- 3. next bounce: NEE + BSDF sampling (:161-221) ----------------------------------------------
-            if (!finish && haveSurf) {
-                ++pathLength;
-                if (pathLength >= 100) {
-                    finish = true;
-                }
-                else {
-                    V3 gNorm_sn = surf.frame.toLocal(surf.gNormal);
-                    uint32_t type = bsdfType(m.type, wlSel);
-                    // SLRHIP_MATERIAL_MULTI: a MultiBSDF whose components are fetched from the material table on demand
-                    const auto loadComponent = [&](uint32_t idx) { return MatIO<S>::template load<LDS_TABLES>(sc, lds.mats, idx, wlOffset); };
-                    const bool isMulti = MULTI && m.type == SLRHIP_MATERIAL_MULTI;
-                    MultiRec multiRec = {};
-                    if constexpr (MULTI) {
-                        if (isMulti) {
-                            multiRec = decodeMulti(m);
-                            type = multiType(multiRec, wlSel);
-                        }
-                    }
-                    if (dtMatches(type, DT_WholeSphere | DT_NonDelta)) {
-                        // Scene::selectLight, SurfaceObject.cpp:432-450 (+ aggregate :279-286)
-                        float lightProb;
-                        float uSel = rng.nextFloat();
-                        bool pickEnv = false;
-                        if (sc.hasEnv) {
-                            float sumImps = sc.aggImportance + 1.0f;
-                            float su = sumImps * uSel;
-                            if (su < sc.aggImportance) uSel = uSel / (sc.aggImportance / sumImps);
-                            else pickEnv = true;
-                        }
-                        float lu0 = rng.nextFloat();
-                        float lu1 = rng.nextFloat();
-                        V3 lp, lgn;
-                        Frame lf;
-                        float areaPDF;
-                        S M;
-                        float shadowTmax;
-                        V3 sdir;
-                        if (pickEnv) {
-                            lightProb = 1.0f * (1.0f / (sc.aggImportance + 1.0f));
-                            // InfiniteSphereSurfaceObject::sample, SurfaceObject.cpp:158-185
-                            float topPDF, rowPDF;
-                            float d1 = sampleContinuous1D(sc.envTopCDF, sc.envTopPDF, sc.envMapHeight, lu1, &topPDF);
-                            uint32_t idx1D = min((uint32_t)((float)sc.envMapHeight * d1), sc.envMapHeight - 1);
-                            float d0 = sampleContinuous1D(sc.envRowCDF + (size_t)idx1D * (sc.envMapWidth + 1), sc.envRowPDF + (size_t)idx1D * sc.envMapWidth,
-                                                          sc.envMapWidth, lu0, &rowPDF);
-                            float uvPDF = rowPDF * topPDF;
-                            float phi = (float)((double)d0 * (2 * kPi));
-                            float theta = (float)((double)d1 * kPi);
-                            lp = V3(-sinf(phi) * sinf(theta), cosf(theta), cosf(phi) * sinf(theta));
-                            lgn = -lp;
-                            lf.x = normalize(V3(-cosf(phi), 0.0f, -sinf(phi)));
-                            lf.z = lgn;
-                            lf.y = cross(lf.z, lf.x);
-                            areaPDF = (float)((double)uvPDF / (2 * kPi * kPi * (double)sinf(theta)));
-                            M = envEmittanceS<S>(sc, (float)((double)phi / (2 * kPi)), (float)((double)theta / kPi), wlOffset);
-                            sdir = normalize(lp);                              // Scene::testVisibility :421-423: [eps, FLT_MAX]
-                            shadowTmax = 3.402823466e+38f;
-                        }
-                        else {
-                            uint32_t li = selectLight(sc, lightCDF, lightPMF, uSel, &lightProb);
-                            lightProb *= 1.0f;
-                            if (sc.hasEnv) lightProb *= sc.aggImportance / (sc.aggImportance + 1.0f);
-                            // Triangle::sample TriangleMesh.cpp:224-255
-                            const float4* lt = (LDS_TABLES ? lds.lights : reinterpret_cast<const float4*>(sc.lightTris)) + (size_t)li * 9;
-                            float4 l0 = lt[0], l1 = lt[1], l2 = lt[2], l3 = lt[3], l4 = lt[4], l5 = lt[5], l6 = lt[6], l7 = lt[7], l8 = lt[8];
-                            float su1 = sqrtf(lu0);
-                            float b0 = 1.0f - su1;
-                            float b1 = lu1 * su1;
-                            float b2 = 1.0f - b0 - b1;
-                            lp = b0 * xyz(l0) + b1 * xyz(l1) + b2 * xyz(l2);
-                            lgn = V3(l3.w, l4.w, l5.w);
-                            lf.z = normalize(b0 * xyz(l3) + b1 * xyz(l4) + b2 * xyz(l5));
-                            lf.x = normalize(b0 * xyz(l6) + b1 * xyz(l7) + b2 * xyz(l8));
-                            lf.y = cross(lf.z, lf.x);
-                            areaPDF = l2.w;
-                            const uint32_t lmat = __float_as_uint(l1.w);
-                            M = MatIO<S>::template emittance<LDS_TABLES>(sc, lds.mats, lmat, wlOffset);
-                            // shadow ray of Scene::testVisibility SurfaceObject.cpp:425-426
-                            float dist = length(surf.p - lp);
-                            sdir = (lp - surf.p) / dist;
-                            shadowTmax = dist * (1 - kRayEpsilon);
-                        }
-                        if (leader) pb.shadowDir[slot] = make_float4(sdir.x, sdir.y, sdir.z, shadowTmax);
-                        emitShadow = true;
-                        // contribution if visible :181-202
-                        float dist2;
-                        V3 shadowDir;
-                        if (pickEnv) { dist2 = 1.0f; shadowDir = normalize(lp); }   // SurfacePoint::getDirectionFrom geometry.cpp:32-37
-                        else {
-                            V3 dvec = lp - surf.p;
-                            dist2 = sqLength(dvec);
-                            shadowDir = dvec / sqrtf(dist2);
-                        }
-                        V3 shadowDir_l = lf.toLocal(-shadowDir);
-                        V3 shadowDir_sn = surf.frame.toLocal(shadowDir);
-                        S Le = M * S(pickEnv ? (float)(1.0 / kPi) : diffuseEDF(shadowDir_l));
-                        float lightPDF = lightProb * areaPDF;
-                        float pdfDir = 0.0f;
-                        S fs;
-                        bool evaluated = false;
-                        if constexpr (MULTI) {
-                            if (isMulti) {
-                                const MultiBSDF<S, decltype(loadComponent)> multi = {multiRec, wlSel, loadComponent};
-                                fs = multi.evaluate(type, dirOut_sn, gNorm_sn, shadowDir_sn, wl, &pdfDir);
-                                evaluated = true;
-                            }
-                        }
-                        if (!evaluated) fs = bsdfEvaluate<S, MF>(m, type, dirOut_sn, gNorm_sn, shadowDir_sn, wl, &pdfDir);
-                        float cosLight = absDot(-shadowDir, lgn);
-                        float bsdfPDF = pdfDir * cosLight / dist2;
-                        float MISWeight = 1.0f;
-                        if (!isinf(areaPDF))
-                            MISWeight = (lightPDF * lightPDF) / (lightPDF * lightPDF + bsdfPDF * bsdfPDF);
-                        float G = absDot(shadowDir_sn, gNorm_sn) * cosLight / dist2;
-                        S contrib = alpha * Le * fs * (G * MISWeight / lightPDF);
-                        SpecIO<S>::store(pb.nee, nullptr, slot, rp.numSlots, contrib, 0.0f);
-                    }
-                    float uComp = rng.nextFloat();
-                    float u0 = rng.nextFloat();
-                    float u1 = rng.nextFloat();
-                    BsdfSample bs;
-                    S fs;
-                    bool sampled = false;
-                    if constexpr (MULTI) {
-                        if (isMulti) {
-                            const MultiBSDF<S, decltype(loadComponent)> multi = {multiRec, wlSel, loadComponent};
-                            fs = multi.sample(type, dirOut_sn, gNorm_sn, wl, uComp, u0, u1, &bs);
-                            sampled = true;
-                        }
-                    }
-                    if (!sampled) fs = bsdfSample<S, MF>(m, type, dirOut_sn, gNorm_sn, wl, uComp, u0, u1, &bs);
-                    if (fs.isZero() || bs.dirPDF == 0.0f) {
-                        finish = true;                                         // :209
-                    }
-                    else {
-                        if (bs.dirType & DT_Dispersive) {                      // :211-214
-                            bs.dirPDF /= S::N;                                 // WavelengthSamples::NumComponents
-                            wlSel = 1;
-                        }
-                        alpha = alpha * (fs * absDot(bs.dir_sn, gNorm_sn) / bs.dirPDF);     // :215
-                        rayDir = surf.frame.fromLocal(bs.dir_sn);
-                        rayOrg = surf.p;                                       // :221 Ray(p, dirIn, time, eps)
-                        rayTmin = kRayEpsilon;
-                        bsdfPDFprev = bs.dirPDF;
-                        flags = F_MAKE((uint32_t)ST_NEXT_HIT, pathLength, wl, wlSel, dtIsDelta(bs.dirType) ? 1u : 0u, emitShadow ? 1u : 0u);
-                        emitExt = true;
-                    }
-                    // the shadow ray starts at the shading point, which is also the next ray's origin
-                    if (emitShadow && !emitExt && leader) pb.rayOrg[slot] = make_float4(surf.p.x, surf.p.y, surf.p.z, kRayEpsilon);
-                }
-            }
-
-            // ---- 4. path finished ----------------------------------------------------------------------------
-            if (finish && emitShadow) {
-                // the NEE of this bounce is still in flight: finish next iteration
-                flags = F_MAKE((uint32_t)ST_FINISH, pathLength, wl, wlSel, 0u, 1u);
-            }
-            else if (finish) {
-                flags = F_MAKE((uint32_t)ST_REGEN, 0u, 0u, 0u, 0u, 0u) | (1u << 15);
-                emitRegen = true;
-            }
-
-            // ---- store path state ---------------------------------------------------------------------------
-            if (leader) pb.flags[slot] = flags | sp.validBits();
-            sp.end(pb, slot, rp.numSlots, !emitRegen);
-            if (!emitRegen) {
-                if (leader) pb.rng[slot] = make_uint4(rng.s0, rng.s1, rng.s2, rng.s3);
-                SpecIO<S>::store(pb.alpha, pb.pdfPrev, slot, rp.numSlots, alpha, bsdfPDFprev);
-            }
-            if (emitExt && leader) {
-                pb.rayOrg[slot] = make_float4(rayOrg.x, rayOrg.y, rayOrg.z, rayTmin);
-                pb.rayDir[slot] = make_float4(rayDir.x, rayDir.y, rayDir.z, INFINITY);
-            }
-        }
-    }
-
-    // ---- stream compaction of the shadow rays and of the finished slots -----------------------------------------
-    (void)emitExt;     // extension rays need no queue: the traversal kernel reads the state flag
-    blockPush(pushLds, emitShadow && leader, emitRegen && leader, slot, pb.shadowQueue, pb.regenQueue, qw, rp.shardCapacity);
-    if (rp.countSlots) {
-        const uint64_t ma = __ballot((emitExt || emitShadow || emitRegen) && leader);
-        if ((threadIdx.x & 63u) == 0 && ma)
-            atomicAdd((unsigned long long*)&pb.totals[totalIndex(T_SLOT_VISITS, blockIdx.x % kShards)], (unsigned long long)__popcll(ma));
-    }
-}
-
-// Finished (or brand-new) slots, dense: sensor->add + the camera-ray half of Job::kernel.
-// Workgroup b serves chunk b / kShards of queue region b % kShards; surplus workgroups exit at once.
-// SpectrumStorage::add.  RGB: the sample is Kahan-added to the pixel (RGBTypes.h:176-179).  Spectral: every component goes
-// to the storage bin of its wavelength scaled by the reciprocal bin width, then the 16-bin addend is Kahan-added
-// (SpectrumTypes.h:818-836).  Bin selection through compare-selects keeps the addend in registers.
-__device__ __forceinline__ RGB storageAddend(const RGB& val, float) { return val; }
-__device__ __forceinline__ Spec16 storageAddend(const Spec16& val, float wlOffset) {
-    const float recBinWidth = 16 / (830.0f - 360.0f);
-    uint32_t sBin[16];
-    float v[16];
-    bool near = true;           // every component lands in its own bin or a neighbour (it always does up to rounding: lambda_i = 360 + 470 (i + u) / 16)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        sBin[i] = min((uint32_t)((wavelengthOf(i, wlOffset) - 360.0f) / (830.0f - 360.0f) * 16), 15u);
-        v[i] = val.c[i] * recBinWidth;
-        near = near && (sBin[i] + 1u >= (uint32_t)i) && (sBin[i] <= (uint32_t)i + 1u);
-    }
-    Spec16 addend;
-    if (near) {
-        // bin b can only receive components b-1, b, b+1: three guarded adds in component order instead of sixteen
-#pragma unroll
-        for (int b = 0; b < 16; ++b) {
-            float a = 0.0f;
-            if (b > 0) a = (sBin[b - 1] == (uint32_t)b) ? a + v[b - 1] : a;
-            a = (sBin[b] == (uint32_t)b) ? a + v[b] : a;
-            if (b < 15) a = (sBin[b + 1] == (uint32_t)b) ? a + v[b + 1] : a;
-            addend.c[b] = a;
-        }
-    }
-    else {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-#pragma unroll
-            for (int b = 0; b < 16; ++b) addend.c[b] = (sBin[i] == (uint32_t)b) ? addend.c[b] + v[i] : addend.c[b];
-        }
-    }
-    return addend;
-}
-
-template <class S>
-__global__ __launch_bounds__(kShadeBlock) void k_regen(DevScene sc, PathBuffers pb, RenderParams rp, uint32_t parity) {
-    const uint32_t shard = blockIdx.x % kShards;
-    const uint32_t n = pb.queueCount[queueCounterIndex(parity, Q_REGEN, shard)];
-    const uint32_t i = (blockIdx.x / kShards) * kShadeBlock + threadIdx.x;
-    if ((blockIdx.x / kShards) * kShadeBlock >= n) return;
-    bool becameIdle = false;
-    uint32_t slot = 0;
-    if (i < n) {
-        slot = pb.regenQueue[(size_t)shard * rp.shardCapacity + i];
-        const uint32_t flags = pb.flags[slot];
-        const uint4 hdr = pb.hdr[slot];
-        uint32_t sampleIdx = hdr.x;
-        if (F_HASPATH(flags)) {
-            // sensor->add(p.x, p.y, wls, weight * C)  PathTracingRenderer.cpp:126-130
-            S C, accR, accC;
-            float unusedW;
-            const float camW = __uint_as_float(hdr.y);
-            if (F_SPVALID(flags)) SpecIO<S>::load(pb.spR, nullptr, slot, rp.numSlots, C, unusedW);     // else the path gathered nothing: C = 0
-            // accR / accC interleave (pb.accC = pb.accR + 1, element stride 2): the pair is one 32-byte sector per slot
-            SpecIO<S>::load(pb.accR, nullptr, 2 * slot, 2 * rp.numSlots, accR, unusedW);
-            SpecIO<S>::load(pb.accC, nullptr, 2 * slot, 2 * rp.numSlots, accC, unusedW);
-            const S weight = (S(1.0f) * S(1.0f)) * camW;
-            kahanAdd(accR, accC, storageAddend(weight * C, S::N == 3 ? 0.0f : __uint_as_float(hdr.z)));
-            SpecIO<S>::store(pb.accR, nullptr, 2 * slot, 2 * rp.numSlots, accR, 0.0f);
-            SpecIO<S>::store(pb.accC, nullptr, 2 * slot, 2 * rp.numSlots, accC, 0.0f);
-            ++sampleIdx;
-        }
-        const uint32_t stripe = slot / rp.numPixels;
-        const uint32_t pix = slot - stripe * rp.numPixels;
-        const uint32_t pass = rp.sppBegin + stripe + sampleIdx * rp.stripes;
-        uint4 newHdr = make_uint4(sampleIdx, 0u, 0u, 0u);
-        if (pass >= rp.sppBegin + rp.sppCount) {
-            pb.flags[slot] = F_MAKE((uint32_t)ST_IDLE, 0u, 0u, 0u, 0u, 0u);
-            becameIdle = true;
-        }
-        else {
-            // Job::kernel PathTracingRenderer.cpp:100-120, draws in source (left-to-right) order
-            const uint32_t xy = pb.pixelXY[pix];
-            const uint32_t px = xy & 0xFFFFu, py = xy >> 16;
-            Rng rng;
-            rng.seed(sampleSeed(rp.rngSeed, px, py, pass));
-            float v = rng.nextFloat();
-            float time = rp.timeStart * (1 - v) + rp.timeEnd * v;
-            (void)time;
-            float pxx = px + rng.nextFloat();
-            float pyy = py + rng.nextFloat();
-            // createWithEqualOffsets: RGBTypes.h:37-45 (offset unused, PDF 1) / SpectrumTypes.h:54-64 (PDF N / 470)
-            const float wlOffset = rng.nextFloat();
-            float uLambda = rng.nextFloat();
-            const uint32_t wl = min((uint32_t)(uint16_t)(S::N * uLambda), (uint32_t)(S::N - 1));
-            const float selectWLPDF = S::N == 3 ? 1.0f : S::N / (830.0f - 360.0f);
-            float lu0 = rng.nextFloat();
-            float lu1 = rng.nextFloat();
-            // PerspectiveCamera::sample PerspectiveCamera.cpp:33-57
-            float lx, ly;
-            concentricSampleDisk(lu0, lu1, &lx, &ly);
-            V3 orgLocal(sc.camera.lensRadius * lx, sc.camera.lensRadius * ly, 0.0f);
-            V3 lensP = mulPoint(sc.camera.mat, orgLocal);
-            V3 lensN = mulNormal(sc.camera.matInv, V3(0, 0, 1));
-            Frame lf;
-            lf.z = lensN;
-            lf.x = mulVector(sc.camera.mat, V3(1, 0, 0));
-            lf.y = cross(lf.z, lf.x);
-            // PerspectiveIDF::sample :63-74 with IDFSample(p.x / W, p.y / H)
-            float sx = pxx / (float)rp.imageWidth;
-            float sy = pyy / (float)rp.imageHeight;
-            V3 pFocus(sc.camera.opWidth * (0.5f - sx), sc.camera.opHeight * (0.5f - sy), sc.camera.objPlaneDistance);
-            V3 dirLocal = normalize(pFocus - orgLocal);
-            float dirPDF = sc.camera.imgPlaneDistance * sc.camera.imgPlaneDistance /
-                           ((dirLocal.z * dirLocal.z * dirLocal.z) * sc.camera.imgPlaneArea);
-            V3 rayDir = lf.fromLocal(dirLocal);
-            // weight :126
-            float camWeight = absDot(rayDir, lensN) / (sc.camera.areaPDF * dirPDF * selectWLPDF);
-            pb.flags[slot] = F_MAKE((uint32_t)ST_FIRST_HIT, 0u, wl, 0u, 0u, 0u);
-            pb.rng[slot] = make_uint4(rng.s0, rng.s1, rng.s2, rng.s3);
-            // alpha = 1, pdfPrev = 0 and sp = 0 are implied by ST_FIRST_HIT (see SpAcc): 48 B (RGB) / 196 B (spectral) not written
-            newHdr.y = __float_as_uint(camWeight);
-            newHdr.z = __float_as_uint(wlOffset);
-            pb.rayOrg[slot] = make_float4(lensP.x, lensP.y, lensP.z, 0.0f);
-            pb.rayDir[slot] = make_float4(rayDir.x, rayDir.y, rayDir.z, INFINITY);
-        }
-        pb.hdr[slot] = newHdr;
-    }
-    // slots run out of samples only at the very end of a render() call, so this atomic is rare
-    const uint64_t mi = __ballot(becameIdle);
-    if ((threadIdx.x & 63u) == 0 && mi) atomicAdd(&pb.activeSlots[0], (uint32_t)(0u - (uint32_t)__popcll(mi)));
-}
-
-// Start of a render() call: every slot of the shard enters the regen queue with sample counter 0
-// (accumulators are kept unless asked: render() continues the image begun by render_begin()).
-template <class S>
-__global__ void k_reset_slots(PathBuffers pb, RenderParams rp, uint32_t clearAccumulators) {
-    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;     // blockDim == kShadeBlock
-    if (slot < rp.numSlots) {
-        pb.flags[slot] = F_MAKE((uint32_t)ST_REGEN, 0u, 0u, 0u, 0u, 0u);
-        pb.hdr[slot] = make_uint4(0u, 0u, 0u, 0u);
-        pb.visible[slot] = 0;
-        // slot block b goes to region b % kShards at chunk b / kShards, exactly as k_logic would append it
-        pb.regenQueue[(size_t)(blockIdx.x % kShards) * rp.shardCapacity + (blockIdx.x / kShards) * kShadeBlock + threadIdx.x] = slot;
-        if (clearAccumulators) {
-            SpecIO<S>::store(pb.accR, nullptr, 2 * slot, 2 * rp.numSlots, S(), 0.0f);
-            SpecIO<S>::store(pb.accC, nullptr, 2 * slot, 2 * rp.numSlots, S(), 0.0f);
-        }
-    }
-    if (blockIdx.x == 0) {
-        for (uint32_t k = threadIdx.x; k < 2 * kQueueSetWords; k += blockDim.x) pb.queueCount[k] = 0;
-        __syncthreads();
-        if (threadIdx.x < kShards) {
-            // entries of region r: full blocks r, r + kShards, ... ; the last block of the grid may be partial
-            const uint32_t numBlocks = (rp.numSlots + kShadeBlock - 1) / kShadeBlock;
-            const uint32_t r = threadIdx.x;
-            uint32_t cnt = 0;
-            if (r < numBlocks) {
-                const uint32_t blocksInRegion = (numBlocks - 1 - r) / kShards + 1;
-                cnt = blocksInRegion * kShadeBlock;
-                const uint32_t lastBlock = numBlocks - 1;
-                if (lastBlock % kShards == r) cnt -= numBlocks * kShadeBlock - rp.numSlots;
-            }
-            pb.queueCount[queueCounterIndex(0, Q_REGEN, r)] = cnt;
-        }
-        if (threadIdx.x == 0) pb.activeSlots[0] = rp.numSlots;
-    }
-}
-
-// ImageSensor read-out: [H][W][N] linear sums; stripes of one pixel are added in stripe order.
-template <class S>
-__global__ void k_resolve(PathBuffers pb, RenderParams rp, float* dst) {
-    const uint32_t pix = blockIdx.x * blockDim.x + threadIdx.x;
-    if (pix >= rp.numPixels) return;
-    const uint32_t xy = pb.pixelXY[pix];
-    const uint32_t px = xy & 0xFFFFu, py = xy >> 16;
-    S sum;
-    float unusedW;
-    SpecIO<S>::load(pb.accR, nullptr, 2 * pix, 2 * rp.numSlots, sum, unusedW);
-    for (uint32_t st = 1; st < rp.stripes; ++st) {
-        S b;
-        SpecIO<S>::load(pb.accR, nullptr, 2 * (st * rp.numPixels + pix), 2 * rp.numSlots, b, unusedW);
-        sum = sum + b;
-    }
-    float* o = dst + ((size_t)py * rp.imageWidth + px) * S::N;
-#pragma unroll
-    for (int i = 0; i < S::N; ++i) o[i] = sum.comp(i);
-}
-
-// ---- host-callable launchers -----------------------------------------------------------------------------------
-// Diagnostic (slrhip_bsdf_queries): the three BSDF entry points exactly as k_logic calls them, one query per lane.
-// geo[i] = (sampled dir_sn, dirPDF); misc[i] = (dirType, evaluatePDF, 0, 0); fsSample / fsEval in the SpecIO layout.
-template <class S>
-__global__ void __launch_bounds__(64) k_bsdf_queries(DevScene sc, uint32_t material, uint32_t n, const float* __restrict__ in, float wlOffset,
-                                                     uint32_t wl, float4* __restrict__ geo, float4* __restrict__ misc,
-                                                     float4* __restrict__ fsSample, float4* __restrict__ fsEval) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float* q = in + 12 * (size_t)i;
-    const Mat<S> m = MatIO<S>::template load<false>(sc, nullptr, material, wlOffset);
-    const V3 dirOut(q[0], q[1], q[2]), gNorm(q[3], q[4], q[5]), dirIn(q[6], q[7], q[8]);
-    BsdfSample bs;
-    bs.dir_sn = V3(0, 0, 0);
-    S fs, fe;
-    float pdf;
-    if (m.type == SLRHIP_MATERIAL_MULTI) {
-        const auto loadComponent = [&](uint32_t idx) { return MatIO<S>::template load<false>(sc, nullptr, idx, wlOffset); };
-        const MultiBSDF<S, decltype(loadComponent)> multi = {decodeMulti(m), 0u, loadComponent};
-        const uint32_t type = multiType(multi.rec, 0u);
-        fs = multi.sample(type, dirOut, gNorm, wl, q[9], q[10], q[11], &bs);
-        fe = multi.evaluate(type, dirOut, gNorm, dirIn, wl, &pdf);
-    }
-    else {
-        const uint32_t type = bsdfType(m.type, 0u);
-        fs = bsdfSample<S, true>(m, type, dirOut, gNorm, wl, q[9], q[10], q[11], &bs);
-        fe = bsdfEvaluate<S, true>(m, type, dirOut, gNorm, dirIn, wl, &pdf);
-    }
-    if (bs.dirPDF == 0.0f) { bs.dir_sn = V3(0, 0, 0); bs.dirType = 0; fs = S(); }
-    geo[i] = make_float4(bs.dir_sn.x, bs.dir_sn.y, bs.dir_sn.z, bs.dirPDF);
-    misc[i] = make_float4((float)bs.dirType, pdf, 0.0f, 0.0f);
-    SpecIO<S>::store(fsSample, nullptr, i, n, fs, 0.0f);
-    SpecIO<S>::store(fsEval, nullptr, i, n, fe, 0.0f);
-}
 
 void launchResetSlots(const PathBuffers& pb, const RenderParams& rp, bool clearAcc, hipStream_t stream) {
     const dim3 grid((rp.numSlots + kShadeBlock - 1) / kShadeBlock), block(kShadeBlock);
@@ -966,14 +16,13 @@ void launchRegen(const DevScene& sc, const PathBuffers& pb, const RenderParams& 
     else hipLaunchKernelGGL(k_regen<RGB>, grid, block, 0, stream, sc, pb, rp, parity);
 }
 void launchLogic(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, hipStream_t stream) {
-    const dim3 grid((rp.numSlots + kShadeBlock - 1) / kShadeBlock), block(kShadeBlock);
     const bool ldsTables = sc.numMaterials <= (uint32_t)kLdsMaterials && sc.numLights <= (uint32_t)kLdsLights &&
                            (!rp.spectral || (sc.numSpectra <= (uint32_t)kLdsSpectra && sc.numSpectrumData <= (uint32_t)kLdsPoolFloats));
     // The microfacet (GGX) code costs ~45 VGPRs, so scenes without such lobes get kernels without it.
+    const bool glossy = sc.hasMicrofacet != 0;
     if (sc.hasMulti) {
         // MultiBSDF scenes: one kernel per mode, tables in HBM (a component is re-read per use), all lobes compiled in
-        if (rp.spectral) hipLaunchKernelGGL((k_logic<Spec16, false, true, true>), grid, block, 0, stream, sc, pb, rp, parity);
-        else hipLaunchKernelGGL((k_logic<RGB, false, true, true>), grid, block, 0, stream, sc, pb, rp, parity);
+        launchLogicMulti(sc, pb, rp, parity, stream);
         return;
     }
     if (rp.spectral) {
@@ -981,24 +30,11 @@ void launchLogic(const DevScene& sc, const PathBuffers& pb, const RenderParams& 
         // Measured on configs[2] after the LDS sample pool: 1 445 vs 1 487 us per launch — the quarter-size register footprint
         // (125 vs 187 VGPR) does not pay for replicating the scalar path work four times.
         static const bool envQuad = [] { const char* e = getenv("SLRHIP_SPECTRAL_LANES"); return e && std::string(e) == "4"; }();
-        if (!envQuad && !rp.spectralQuad) {
-            if (ldsTables && !sc.hasMicrofacet) hipLaunchKernelGGL((k_logic<Spec16, true, false>), grid, block, 0, stream, sc, pb, rp, parity);
-            else if (ldsTables) hipLaunchKernelGGL((k_logic<Spec16, true, true>), grid, block, 0, stream, sc, pb, rp, parity);
-            else if (!sc.hasMicrofacet) hipLaunchKernelGGL((k_logic<Spec16, false, false>), grid, block, 0, stream, sc, pb, rp, parity);
-            else hipLaunchKernelGGL((k_logic<Spec16, false, true>), grid, block, 0, stream, sc, pb, rp, parity);
-            return;
-        }
-        const dim3 gridQ((rp.numSlots * 4u + kShadeBlock - 1) / kShadeBlock);
-        if (ldsTables && !sc.hasMicrofacet) hipLaunchKernelGGL((k_logic<SpecQ, true, false>), gridQ, block, 0, stream, sc, pb, rp, parity);
-        else if (ldsTables) hipLaunchKernelGGL((k_logic<SpecQ, true, true>), gridQ, block, 0, stream, sc, pb, rp, parity);
-        else if (!sc.hasMicrofacet) hipLaunchKernelGGL((k_logic<SpecQ, false, false>), gridQ, block, 0, stream, sc, pb, rp, parity);
-        else hipLaunchKernelGGL((k_logic<SpecQ, false, true>), gridQ, block, 0, stream, sc, pb, rp, parity);
+        if (!envQuad && !rp.spectralQuad) launchLogicSpec16(sc, pb, rp, parity, ldsTables, glossy, stream);
+        else launchLogicSpecQ(sc, pb, rp, parity, ldsTables, glossy, stream);
         return;
     }
-    if (ldsTables && !sc.hasMicrofacet) hipLaunchKernelGGL((k_logic<RGB, true, false>), grid, block, 0, stream, sc, pb, rp, parity);
-    else if (ldsTables) hipLaunchKernelGGL((k_logic<RGB, true, true>), grid, block, 0, stream, sc, pb, rp, parity);
-    else if (!sc.hasMicrofacet) hipLaunchKernelGGL((k_logic<RGB, false, false>), grid, block, 0, stream, sc, pb, rp, parity);
-    else hipLaunchKernelGGL((k_logic<RGB, false, true>), grid, block, 0, stream, sc, pb, rp, parity);
+    launchLogicRGB(sc, pb, rp, parity, ldsTables, glossy, stream);
 }
 void launchBsdfQueries(const DevScene& sc, bool spectral, uint32_t material, uint32_t n, const float* in, float wlOffset, uint32_t wl,
                        float4* geo, float4* misc, float4* fsSample, float4* fsEval, hipStream_t stream) {

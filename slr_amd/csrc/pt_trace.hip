@@ -167,7 +167,7 @@ __device__ __forceinline__ void blockAdd(uint64_t* totals, uint32_t kind, uint32
 }
 
 // Extension rays: closest hit.  Walks ALL slots (no queue): a slot has a ray in flight iff its state is
-// FIRST_HIT or NEXT_HIT (flag values 2 and 3, pt_shade.hip).
+// FIRST_HIT or NEXT_HIT (flag values 2 and 3, pt_shade_kernels.h).
 template <bool COUNT>
 __global__ __launch_bounds__(kTraceBlock) void k_trace_closest(DevScene sc, PathBuffers pb, uint32_t numSlots, uint32_t parity) {
     __shared__ TraceLds lds;

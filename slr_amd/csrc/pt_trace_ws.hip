@@ -389,7 +389,7 @@ __device__ __forceinline__ void wsConsume(const DevScene& sc, const PathBuffers&
 // ONE launch traces both ray kinds of an iteration, so the tail of the extension rays (the last long rays of a few
 // waves) is filled by shadow rays instead of idle CUs; measured: ~70 + ~50 us of fixed cost per launch pair before.
 //   phase 1, extension rays (closest hit): the producer walks ALL slots of its share (no queue); a slot has a ray in flight
-//            iff its state is FIRST_HIT or NEXT_HIT (flag values 2 and 3, pt_shade.hip).
+//            iff its state is FIRST_HIT or NEXT_HIT (flag values 2 and 3, pt_shade_kernels.h).
 //   phase 2, shadow rays: Scene::testVisibility (SurfaceObject.cpp:418-430) = "no hit in [eps, d(1-eps)]"; workgroup b
 //            serves queue region b % kShards (gridDim is a multiple of kShards).
 template <bool COUNT, int NC, bool QUANT>
