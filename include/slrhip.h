@@ -24,7 +24,8 @@
 extern "C" {
 #endif
 
-#define SLRHIP_VERSION 2   /* 2: slrhip_material::param2, slrhip_scene_desc::upsampling, Ward / Ashikhmin lobes */
+#define SLRHIP_VERSION 3   /* 2: slrhip_material::param2, slrhip_scene_desc::upsampling, Ward / Ashikhmin lobes;
+                            * 3: SLRHIP_MATERIAL_MULTI, slrhip_bsdf_queries (additive: version-2 callers are unaffected) */
 
 /* ---- status codes -------------------------------------------------------------- */
 enum {

@@ -34,7 +34,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_version(lib):
-    assert lib.slrhip_version() == 2
+    assert lib.slrhip_version() == 3
 
 
 def test_create_fails_loudly_without_gpu(lib):
