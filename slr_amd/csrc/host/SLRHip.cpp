@@ -52,6 +52,15 @@ uint32_t Scene::addMaterial(uint32_t type, int32_t s0, int32_t s1, int32_t s2, f
     m_materials.push_back(m);
     return (uint32_t)m_materials.size() - 1;
 }
+uint32_t Scene::addSummedMaterial(uint32_t mat0, uint32_t mat1, bool inverse0, bool inverse1, int32_t emittance) {
+    const int32_t bits = (inverse0 ? SLRHIP_MULTI_INVERSE_0 : 0) | (inverse1 ? SLRHIP_MULTI_INVERSE_1 : 0);
+    return addMaterial(SLRHIP_MATERIAL_MULTI, (int32_t)mat0, (int32_t)mat1, bits, 1.0f, emittance, 1.0f);
+}
+uint32_t Scene::addMixedMaterial(uint32_t mat0, uint32_t mat1, float factor, bool inverse0, bool inverse1, int32_t emittance) {
+    const int32_t bits = (inverse0 ? SLRHIP_MULTI_INVERSE_0 : 0) | (inverse1 ? SLRHIP_MULTI_INVERSE_1 : 0);
+    // MixedSurfaceMaterial::getBSDF hands scale * (1.0f - factor) and scale * factor to the components (MixedSurfaceMaterial.cpp:16-17)
+    return addMaterial(SLRHIP_MATERIAL_MULTI, (int32_t)mat0, (int32_t)mat1, bits, 1.0f - factor, emittance, factor);
+}
 slrhip_scene_desc Scene::desc() const {
     slrhip_scene_desc d;
     std::memset(&d, 0, sizeof(d));

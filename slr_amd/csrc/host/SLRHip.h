@@ -57,6 +57,10 @@ public:
     void setEnvironment(const float* texels, uint32_t width, uint32_t height, float scale, const float* importance, uint32_t mapWidth,
                         uint32_t mapHeight);
     uint32_t addMaterial(uint32_t type, int32_t s0, int32_t s1, int32_t s2, float param, int32_t emittance, float param2 = 0.0f);
+    // SurfaceMaterial::createSummedMaterial / createMixedMaterial (constant factor) over two single-lobe materials, either of
+    // which may be wrapped as SurfaceMaterial::createInverseMaterial would (libSLR/Core/surface_material.h; API.cpp:583-636).
+    uint32_t addSummedMaterial(uint32_t mat0, uint32_t mat1, bool inverse0 = false, bool inverse1 = false, int32_t emittance = -1);
+    uint32_t addMixedMaterial(uint32_t mat0, uint32_t mat1, float factor, bool inverse0 = false, bool inverse1 = false, int32_t emittance = -1);
     void setCamera(const slrhip_camera& camera) { m_camera = camera; }
     const slrhip_camera& camera() const { return m_camera; }
     slrhip_scene_desc desc() const;
