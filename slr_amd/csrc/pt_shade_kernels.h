@@ -399,8 +399,24 @@ struct ShadeLds {
     float lightCDF[kLdsLights + 1];
 };
 
+// Occupancy floor of k_logic (waves per SIMD): the register allocator spills to scratch to stay under 512 / N registers.
+// Measured on the spectral GGX scene: the 330-register allocation (1 wave per SIMD, 63 % of its cycles waiting on memory,
+// PMC) ran at 1 393 us per launch; held to 256 registers (300 B of scratch per lane, 2 waves) it runs at 765 us.
+// A floor of 3 waves costs the same kernel 988 us (more scratch than the extra wave hides), but pays on the variant
+// without the glossy lobes (190 registers: 832 -> 768 us at <= 170).  The RGB variants allocate 116-161 registers
+// (3-4 waves) on their own; forcing 5 or 6 waves slows them (220 -> 326 / 505 us), so their floor is left below that.
+#ifndef SLR_WAVES_SPECTRAL_GLOSSY
+#define SLR_WAVES_SPECTRAL_GLOSSY 2
+#endif
+#ifndef SLR_WAVES_SPECTRAL
+#define SLR_WAVES_SPECTRAL 3
+#endif
+#ifndef SLR_WAVES_RGB
+#define SLR_WAVES_RGB 2
+#endif
 template <class S, bool LDS_TABLES, bool MF, bool MULTI = false>
-__global__ __launch_bounds__(kShadeBlock) void k_logic(DevScene sc, PathBuffers pb, RenderParams rp, uint32_t parity) {
+__global__ __launch_bounds__(kShadeBlock)
+__attribute__((amdgpu_waves_per_eu(S::N == 3 ? SLR_WAVES_RGB : (MF ? SLR_WAVES_SPECTRAL_GLOSSY : SLR_WAVES_SPECTRAL)))) void k_logic(DevScene sc, PathBuffers pb, RenderParams rp, uint32_t parity) {
     __shared__ ShadeLds<S::N != 3> lds;
     __shared__ PushLds pushLds;
     if (LDS_TABLES) {
