@@ -14,8 +14,11 @@ scene = scenes.cornell_box_spheres(W / H, 48, 24, "matte")
 st = abi.RenderSettings(W, H, 0.0, 0.0, 1.0, abi.DEFAULT_SEED)
 
 
+TIMED = "--timed" in sys.argv      # the event-timed launch loop bench.py uses (no hipGraph replay)
+
+
 def shard_time(world, stripes=0, reps=2):
-    c = Context(device=0, mode=abi.MODE_RGB, stripes=stripes)
+    c = Context(device=0, mode=abi.MODE_RGB, stripes=stripes, flags=abi.FLAG_TIME_KERNELS if TIMED else 0)
     c.upload_scene(scene)
     c.render_begin(st, (0, world)); c.render(0, 64); c.synchronize()
     best = 1e9
@@ -31,6 +34,6 @@ def shard_time(world, stripes=0, reps=2):
 t1, it1 = shard_time(1)
 print("N=1: %.1f ms, %d iterations, %.0f Msamples/s" % (t1 * 1e3, it1, W * H * SPP / t1 / 1e6), flush=True)
 for n in (2, 4, 8):
-    for stripes in (0, 8, 16, 32, 64):
+    for stripes in ((0,) if TIMED else (0, 8, 16, 32, 64)):
         t, it = shard_time(n, stripes)
         print("N=%d stripes=%2d: %.1f ms, %d iterations, efficiency %.3f (speed-up %.2fx)" % (n, stripes, t * 1e3, it, t1 / (n * t), t1 / t), flush=True)
