@@ -543,3 +543,31 @@ def test_radiance_is_linear_in_the_emitted_power_at_full_size():
         c.close()
     assert frames[0].sum() > 0
     assert_bit_equal(frames[0] * np.float32(4.0), frames[1], "16x light vs 4 * (4x light)")
+
+
+def test_eight_tile_shards_assemble_the_full_size_frame_exactly():
+    """The multi-GPU decomposition at BASELINE's image size, rehearsed on one device: the eight shards a node's ranks would
+    render (8x8 tiles, t % 8 == rank) have disjoint supports, and their sum — what the RCCL reduce computes — equals the
+    unsharded frame bit for bit (per-(pixel, sample) seeding: a pixel's samples do not depend on which rank owns it)."""
+    sc = scenes.cornell_box_spheres(1280 / 720, 24, 12, "matte")
+    st = ob.settings(1280, 720)
+    c = Context(mode=abi.MODE_RGB)
+    try:
+        c.upload_scene(sc)
+        c.render_begin(st)
+        c.render(0, 4)
+        full = c.read_framebuffer()
+        total = np.zeros_like(full)
+        covered = np.zeros(full.shape[:2], bool)
+        for rank in range(8):
+            c.render_begin(st, shard=(rank, 8))
+            c.render(0, 4)
+            part = c.read_framebuffer()
+            support = (part != 0).any(axis=2)
+            assert not (covered & support).any(), "shards overlap"
+            covered |= support
+            total += part
+            assert c.counters().samples == 4 * sum(1 for ty in range(90) for tx in range(160) if (ty * 160 + tx) % 8 == rank) * 64
+    finally:
+        c.close()
+    assert_bit_equal(total, full, "sum of 8 shards vs full frame")
