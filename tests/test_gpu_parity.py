@@ -551,23 +551,40 @@ def test_eight_tile_shards_assemble_the_full_size_frame_exactly():
     unsharded frame bit for bit (per-(pixel, sample) seeding: a pixel's samples do not depend on which rank owns it)."""
     sc = scenes.cornell_box_spheres(1280 / 720, 24, 12, "matte")
     st = ob.settings(1280, 720)
-    c = Context(mode=abi.MODE_RGB)
+    # A fixed stripe count: the per-pixel float sum is taken stripe by stripe, so bit-equality across world sizes needs the
+    # same K everywhere (the automatic K grows with the world size; the frames then agree to the last ulp or two, below).
+    c = Context(mode=abi.MODE_RGB, stripes=4)
     try:
         c.upload_scene(sc)
         c.render_begin(st)
-        c.render(0, 4)
+        c.render(0, 16)
         full = c.read_framebuffer()
         total = np.zeros_like(full)
         covered = np.zeros(full.shape[:2], bool)
         for rank in range(8):
             c.render_begin(st, shard=(rank, 8))
-            c.render(0, 4)
+            c.render(0, 16)
             part = c.read_framebuffer()
             support = (part != 0).any(axis=2)
             assert not (covered & support).any(), "shards overlap"
             covered |= support
             total += part
-            assert c.counters().samples == 4 * sum(1 for ty in range(90) for tx in range(160) if (ty * 160 + tx) % 8 == rank) * 64
+            assert c.counters().samples == 16 * sum(1 for ty in range(90) for tx in range(160) if (ty * 160 + tx) % 8 == rank) * 64
     finally:
         c.close()
     assert_bit_equal(total, full, "sum of 8 shards vs full frame")
+    # automatic stripe counts (8 for the full frame, 64 for an eighth of it): same samples, another summation order
+    a = Context(mode=abi.MODE_RGB)
+    try:
+        a.upload_scene(sc)
+        a.render_begin(st, shard=(3, 8))
+        a.render(0, 16)
+        part_auto = a.read_framebuffer()
+        a.render_begin(st)
+        a.render(0, 16)
+        full_auto = a.read_framebuffer()
+    finally:
+        a.close()
+    mask = (part_auto != 0).any(axis=2)
+    assert np.allclose(part_auto[mask], full_auto[mask], rtol=2e-6, atol=1e-9)
+    assert np.allclose(full_auto, full, rtol=2e-6, atol=1e-9)
