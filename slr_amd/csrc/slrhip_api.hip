@@ -572,7 +572,7 @@ int slrhip_render_begin(slrhip_ctx* ctx, const slrhip_render_settings* st, slrhi
     if (stripes == 0) {
         // Paths in flight: throughput keeps rising with the slot count (longer launches amortise the
         // per-wave tail of the traversal kernels: 807 / 1146 / 1267 Msamples/s at 0.9 / 3.7 / 7.4 M slots on
-        // the 1280x720 Cornell scene), at 188 B of HBM per slot.  Aim for ~7.4 M slots, at most 64 stripes.
+        // the 1280x720 Cornell scene), at ≈ 200 B of HBM per slot.  Aim for ~7.4 M slots, at most 64 stripes.
         const uint32_t target = 7372800u;
         stripes = numPixels >= target || numPixels == 0 ? 1u : (target + numPixels / 2) / numPixels;
         if (stripes < 1) stripes = 1;
