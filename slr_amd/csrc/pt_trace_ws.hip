@@ -29,6 +29,10 @@ namespace slrhip {
 static const int kWsLdsStack = 11;          // + 1 trash row = 12 rows of 64 lanes = 3 KiB per consumer wave
 static const int kWsSpill = 53;            // 11 + 53 = the reference's 64-entry stack (QBVH.h:299)
 static const int kSub = 2;                 // 64-slot sub-chunks the producer keeps in flight
+#ifndef SLR_WS_AHEAD
+#define SLR_WS_AHEAD 4
+#endif
+static const int kAhead = SLR_WS_AHEAD;               // chunks whose state flags the producer reads in one round trip (see k_trace_ws)
 static uint32_t g_refill = 20;             // idle lanes that trigger a refill (SLRHIP_WS_REFILL)
 static int g_consumers = 3;                // SLRHIP_WS_NC
 static const uint32_t kSpinLimit = 1u << 22;
@@ -410,26 +414,44 @@ __global__ __launch_bounds__(64 * (NC + 1)) __attribute__((amdgpu_waves_per_eu(8
         const uint32_t chunk = kSub * 64;
         bool ok = true;
         {
+            // The state flags of kAhead chunks are fetched in one round trip, the ray records only for chunks that have a ray:
+            // near the end of a render most slots are idle, and a producer that pays one memory round trip per 128 slots
+            // whether or not they hold a ray makes an almost empty launch last ~58 us (28 dependent round trips per workgroup).
             const uint32_t numChunks = (numSlots + chunk - 1) / chunk;
-            for (uint32_t c = blockIdx.x; ok && c < numChunks; c += gridDim.x) {
-                uint32_t fl[kSub];
-                float4 o[kSub], d[kSub];
+            for (uint32_t c0 = blockIdx.x; ok && c0 < numChunks; c0 += gridDim.x * kAhead) {
+                uint32_t fl[kAhead][kSub];
 #pragma unroll
-                for (int j = 0; j < kSub; ++j) {
-                    const uint32_t s = c * chunk + j * 64 + lane;
-                    const bool valid = s < numSlots;
-                    fl[j] = valid ? __builtin_nontemporal_load(&pb.flags[s]) : 0u;
-                    o[j] = valid ? ntLoad4(&pb.rayOrg[s]) : make_float4(0, 0, 0, 0);
-                    d[j] = valid ? ntLoad4(&pb.rayDir[s]) : make_float4(0, 0, 0, 0);
-                }
-                ok = wsWaitSpace(lds, tailLocal, chunk, &dbg.producerWaits);
-                if (!ok) break;
+                for (int a = 0; a < kAhead; ++a)
 #pragma unroll
-                for (int j = 0; j < kSub; ++j) {
-                    const uint32_t state = fl[j] & 7u;
-                    tailLocal += wsAppend(lds, tailLocal, state == 2u || state == 3u, c * chunk + j * 64 + lane, o[j], d[j]);
+                    for (int j = 0; j < kSub; ++j) {
+                        const uint64_t s = (uint64_t)(c0 + a * gridDim.x) * chunk + j * 64 + lane;
+                        fl[a][j] = s < numSlots ? __builtin_nontemporal_load(&pb.flags[s]) : 0u;
+                    }
+#pragma unroll
+                for (int a = 0; a < kAhead; ++a) {
+                    const uint32_t c = c0 + a * gridDim.x;
+                    bool live[kSub];
+                    bool any = false;
+#pragma unroll
+                    for (int j = 0; j < kSub; ++j) {
+                        const uint32_t state = fl[a][j] & 7u;
+                        live[j] = state == 2u || state == 3u;
+                        any = any || __ballot(live[j]) != 0;
+                    }
+                    if (!any) continue;       // wave-uniform (also true past the last chunk: those flags were read as 0)
+                    float4 o[kSub], d[kSub];
+#pragma unroll
+                    for (int j = 0; j < kSub; ++j) {
+                        const uint32_t s = c * chunk + j * 64 + lane;
+                        o[j] = live[j] ? ntLoad4(&pb.rayOrg[s]) : make_float4(0, 0, 0, 0);
+                        d[j] = live[j] ? ntLoad4(&pb.rayDir[s]) : make_float4(0, 0, 0, 0);
+                    }
+                    ok = wsWaitSpace(lds, tailLocal, chunk, &dbg.producerWaits);
+                    if (!ok) break;
+#pragma unroll
+                    for (int j = 0; j < kSub; ++j) tailLocal += wsAppend(lds, tailLocal, live[j], c * chunk + j * 64 + lane, o[j], d[j]);
+                    WS_STORE(&lds.tail, tailLocal, __ATOMIC_RELEASE);
                 }
-                WS_STORE(&lds.tail, tailLocal, __ATOMIC_RELEASE);
             }
             extRays = tailLocal;
         }
