@@ -90,6 +90,13 @@ struct PathBuffers {
     // camera weight (bits), z = its wavelength offset (bits; lambda_i = 360 + 470 (i + offset) / 16, spectral mode)
     uint4* hdr;
     uint32_t* flags;
+    // Per-pixel sample pool: the stripes of a pixel draw their next sample index from one counter, so that they all run
+    // out of samples at about the same iteration.  finishedMask[q][pixel] = stripes whose path ended in the iteration that
+    // filled queue set q (bit = stripe, OR-ed by k_logic: the result does not depend on arrival order); k_regen gives the
+    // finishing stripes the indices nextSample[pixel] + rank-in-mask; the pixel's stripe-0 slot advances the counter and
+    // clears the mask in the next k_logic.  Deterministic: which stripe gets which sample depends on path lengths only.
+    unsigned long long* finishedMask;
+    uint32_t* nextSample;
     uint32_t* visible;            // result of the shadow ray
     uint32_t* shadowQueue;        // kShards regions of shardCapacity slot indices: shadow rays of this iteration
     uint32_t* regenQueue;         // same layout: slots whose path ended (accumulate pixel, start next sample)

@@ -449,6 +449,17 @@ __attribute__((amdgpu_waves_per_eu(S::N == 3 ? SLR_WAVES_RGB : (MF ? SLR_WAVES_S
     bool emitExt = false, emitShadow = false, emitRegen = false;
     uint32_t* qw = pb.queueCount + (parity ^ 1) * kQueueSetWords;
 
+    // Sample pool housekeeping (PathBuffers::finishedMask): the stripe-0 slot of a pixel retires the mask k_regen has just
+    // consumed — whether or not that slot itself still has a path.
+    if (slot < rp.numPixels && leader) {
+        unsigned long long* done = pb.finishedMask + (size_t)parity * rp.numPixels + slot;
+        const unsigned long long m = *done;
+        if (m) {
+            pb.nextSample[slot] += (uint32_t)__popcll(m);
+            *done = 0ull;
+        }
+    }
+
     if (slot < rp.numSlots) {
         // ---- all state loads up front: one memory round trip instead of a dependent chain -----------
         uint32_t flags = pb.flags[slot];
@@ -730,6 +741,10 @@ __attribute__((amdgpu_waves_per_eu(S::N == 3 ? SLR_WAVES_RGB : (MF ? SLR_WAVES_S
 
             // ---- store path state ---------------------------------------------------------------------------
             if (leader) pb.flags[slot] = flags | sp.validBits();
+            if (emitRegen && leader) {
+                const uint32_t stripe = slot / rp.numPixels;
+                atomicOr(pb.finishedMask + (size_t)(parity ^ 1) * rp.numPixels + (slot - stripe * rp.numPixels), 1ull << stripe);
+            }
             sp.end(pb, slot, rp.numSlots, !emitRegen);
             if (!emitRegen) {
                 if (leader) pb.rng[slot] = make_uint4(rng.s0, rng.s1, rng.s2, rng.s3);
@@ -821,7 +836,12 @@ __global__ __launch_bounds__(kShadeBlock) void k_regen(DevScene sc, PathBuffers 
         }
         const uint32_t stripe = slot / rp.numPixels;
         const uint32_t pix = slot - stripe * rp.numPixels;
-        const uint32_t pass = rp.sppBegin + stripe + sampleIdx * rp.stripes;
+        // the first sample of a stripe is its own index; later ones come from the pixel's pool in stripe order
+        uint32_t pass = rp.sppBegin + stripe;
+        if (F_HASPATH(flags)) {
+            const unsigned long long m = pb.finishedMask[(size_t)parity * rp.numPixels + pix];
+            pass = rp.sppBegin + pb.nextSample[pix] + (uint32_t)__popcll(m & ((1ull << stripe) - 1ull));
+        }
         uint4 newHdr = make_uint4(sampleIdx, 0u, 0u, 0u);
         if (pass >= rp.sppBegin + rp.sppCount) {
             pb.flags[slot] = F_MAKE((uint32_t)ST_IDLE, 0u, 0u, 0u, 0u, 0u);
@@ -888,6 +908,11 @@ __global__ void k_reset_slots(PathBuffers pb, RenderParams rp, uint32_t clearAcc
     if (slot < rp.numSlots) {
         pb.flags[slot] = F_MAKE((uint32_t)ST_REGEN, 0u, 0u, 0u, 0u, 0u);
         pb.hdr[slot] = make_uint4(0u, 0u, 0u, 0u);
+        if (slot < rp.numPixels) {
+            pb.nextSample[slot] = rp.stripes;
+            pb.finishedMask[slot] = 0ull;
+            pb.finishedMask[(size_t)rp.numPixels + slot] = 0ull;
+        }
         pb.visible[slot] = 0;
         // slot block b goes to region b % kShards at chunk b / kShards, exactly as k_logic would append it
         pb.regenQueue[(size_t)(blockIdx.x % kShards) * rp.shardCapacity + (blockIdx.x / kShards) * kShadeBlock + threadIdx.x] = slot;

@@ -121,6 +121,8 @@ struct slrhip_ctx {
     DevArray<float4> rayOrg, rayDir, hit, alpha, spR, spC, accR, accC, nee, shadowDir;
     DevArray<float> pdfPrev;
     DevArray<uint4> hdr;
+    DevArray<unsigned long long> finishedMask;
+    DevArray<uint32_t> nextSample;
     DevArray<uint32_t> flags, visible, shadowQueue, regenQueue, queueCount, activeSlots;
     DevArray<uint64_t> totals;
     DevArray<float> resolveScratch;
@@ -591,6 +593,7 @@ int slrhip_render_begin(slrhip_ctx* ctx, const slrhip_render_settings* st, slrhi
     HIP_TRY(ctx->shadowDir.alloc(numSlots, true));
     HIP_TRY(ctx->pdfPrev.alloc(spectral ? numSlots : 1, true));
     HIP_TRY(ctx->hdr.alloc(numSlots, true));
+    HIP_TRY(ctx->finishedMask.alloc(2 * (size_t)numPixels + 2, true)); HIP_TRY(ctx->nextSample.alloc((size_t)numPixels + 1, true));
     HIP_TRY(ctx->flags.alloc(numSlots, true)); HIP_TRY(ctx->visible.alloc(numSlots, true));
     // queue regions: slot block b appends to region b % kShards, so a region holds at most ceil(numBlocks / kShards) blocks
     const uint32_t numBlocks = (uint32_t)((numSlots + 255) / 256);
@@ -607,7 +610,7 @@ int slrhip_render_begin(slrhip_ctx* ctx, const slrhip_render_settings* st, slrhi
     pb.rng = ctx->rng.ptr; pb.rayOrg = ctx->rayOrg.ptr; pb.rayDir = ctx->rayDir.ptr; pb.hit = ctx->hit.ptr;
     pb.alpha = ctx->alpha.ptr; pb.spR = ctx->spR.ptr; pb.spC = ctx->spC.ptr; pb.accR = ctx->accR.ptr; pb.accC = ctx->accR.ptr + 1;
     pb.nee = ctx->nee.ptr;
-    pb.pdfPrev = spectral ? ctx->pdfPrev.ptr : nullptr; pb.hdr = ctx->hdr.ptr; pb.shadowDir = ctx->shadowDir.ptr; pb.flags = ctx->flags.ptr;
+    pb.pdfPrev = spectral ? ctx->pdfPrev.ptr : nullptr; pb.hdr = ctx->hdr.ptr; pb.finishedMask = ctx->finishedMask.ptr; pb.nextSample = ctx->nextSample.ptr; pb.shadowDir = ctx->shadowDir.ptr; pb.flags = ctx->flags.ptr;
     pb.visible = ctx->visible.ptr; pb.shadowQueue = ctx->shadowQueue.ptr; pb.regenQueue = ctx->regenQueue.ptr;
     pb.queueCount = ctx->queueCount.ptr; pb.activeSlots = ctx->activeSlots.ptr; pb.totals = ctx->totals.ptr;
     pb.pixelXY = ctx->pixelXY.ptr;
