@@ -574,8 +574,14 @@ int slrhip_render_begin(slrhip_ctx* ctx, const slrhip_render_settings* st, slrhi
     if (stripes == 0) {
         // Paths in flight: throughput keeps rising with the slot count (longer launches amortise the
         // per-wave tail of the traversal kernels: 807 / 1146 / 1267 Msamples/s at 0.9 / 3.7 / 7.4 M slots on
-        // the 1280x720 Cornell scene), at ≈ 200 B of HBM per slot.  Aim for ~7.4 M slots, at most 64 stripes.
-        const uint32_t target = 7372800u;
+        // the 1280x720 Cornell scene), at ≈ 200 B of HBM per slot.  With the per-pixel sample pool (finishedMask) the
+        // stripes of a pixel finish together, and fewer, fuller iterations keep paying: 1 988 / 2 079 / 2 098 / 2 073
+        // Msamples/s at 8 / 16 / 24 / 32 stripes (environment light: 3 850 / 4 172 / 4 323 / 4 415).  RGB: ~22 M slots
+        // (24 stripes at 1280x720, 4.4 GB).  Spectral (492 B per slot; its shade kernel is latency-bound, not
+        // launch-bound): ~7.4 M.  At most 64 stripes: the width of the pool's mask, and the best count measured for the
+        // eighth of the image a rank owns at N = 8 (61.5 / 62.5 / 65.4 / 68.0 ms at 64 / 96 / 128 / 192 with a wider mask:
+        // below ~16 samples per slot the first, statically assigned sample of every stripe weighs too much).
+        const uint32_t target = ctx->config.mode == SLRHIP_MODE_SPECTRAL ? 7372800u : 22118400u;
         stripes = numPixels >= target || numPixels == 0 ? 1u : (target + numPixels / 2) / numPixels;
         if (stripes < 1) stripes = 1;
         if (stripes > 64) stripes = 64;
