@@ -24,8 +24,9 @@
 extern "C" {
 #endif
 
-#define SLRHIP_VERSION 3   /* 2: slrhip_material::param2, slrhip_scene_desc::upsampling, Ward / Ashikhmin lobes;
-                            * 3: SLRHIP_MATERIAL_MULTI, slrhip_bsdf_queries (additive: version-2 callers are unaffected) */
+#define SLRHIP_VERSION 4   /* 2: slrhip_material::param2, slrhip_scene_desc::upsampling, Ward / Ashikhmin lobes;
+                            * 3: SLRHIP_MATERIAL_MULTI, slrhip_bsdf_queries (additive: version-2 callers are unaffected);
+                            * 4: stripes > 64 rejected, device error word, samples counted on the device (additive) */
 
 /* ---- status codes -------------------------------------------------------------- */
 enum {
@@ -242,16 +243,20 @@ typedef struct slrhip_shard {
 } slrhip_shard;
 
 /* ---- context configuration -------------------------------------------------------- */
+#define SLRHIP_MAX_STRIPES 64u
 typedef struct slrhip_config {
     int32_t device;            /* HIP device ordinal                                         */
     int32_t mode;              /* SLRHIP_MODE_*                                              */
-    uint32_t stripes;          /* sample stripes per pixel kept in flight (0 = auto)         */
+    uint32_t stripes;          /* sample stripes per pixel kept in flight: 0 = auto, else 1 .. SLRHIP_MAX_STRIPES
+                                * (the per-pixel sample pool tracks stripes in a 64-bit mask); larger values are
+                                * rejected by slrhip_create with SLRHIP_ERR_INVALID_ARGUMENT                      */
     uint32_t flags;            /* SLRHIP_FLAG_*                                              */
 } slrhip_config;
 
 /* ---- counters --------------------------------------------------------------------- */
 typedef struct slrhip_counters {
-    uint64_t samples;            /* finished (pixel, sample) pairs                           */
+    uint64_t samples;            /* finished (pixel, sample) pairs accumulated into pixels since slrhip_render_begin,
+                                  * counted on the device (sum of the per-slot sample counters)              */
     uint64_t extension_rays;     /* Scene::intersect calls         PathTracingRenderer.cpp:147,225 */
     uint64_t shadow_rays;        /* Scene::testVisibility calls    PathTracingRenderer.cpp:180     */
     uint64_t iterations;         /* wavefront iterations launched                            */
@@ -279,6 +284,8 @@ typedef struct slrhip_profile {
 } slrhip_profile;
 
 /* config.flags */
+#define SLRHIP_FLAG_TEST_DEVICE_ERROR 16u /* test hook: the next slrhip_render raises the device-side error word, so that the
+                                         * error path (SLRHIP_ERR_HIP + message) can be exercised; renders nothing useful */
 #define SLRHIP_FLAG_TIME_KERNELS   1u   /* bracket every launch with HIP events (a few us per launch)        */
 #define SLRHIP_FLAG_COUNT_TRAVERSAL 2u  /* count nodes / triangles per ray (instrumented kernels, slower)    */
 #define SLRHIP_FLAG_SPECTRAL_QUAD  8u   /* spectral shade kernel with the 16 samples spread over four lanes per path (a quarter of
@@ -304,8 +311,12 @@ int slrhip_render_begin(slrhip_ctx* ctx, const slrhip_render_settings* settings,
 /* Replaces: the pass loop PathTracingRenderer.cpp:72-81 for passes
  * [spp_begin, spp_begin+spp_count).  Sample s of pixel (x,y) draws from the xorshift128
  * stream seeded with slrhip_sample_seed(rng_seed, x, y, s), so the image does not depend
- * on the shard layout or on scheduling.  Asynchronous on `stream` (a hipStream_t, or NULL
- * for the default stream).                                                                */
+ * on the shard layout or on scheduling.  The work is ORDERED on `stream` (a hipStream_t, or
+ * NULL for the default stream): it starts after what the caller queued there before.  The
+ * call itself BLOCKS the host until the passes are done — the number of wavefront iterations
+ * is data dependent, so the host polls a device-side "live slots" word between blocks of
+ * iterations — and returns SLRHIP_ERR_HIP if a kernel raised the device error word (a
+ * bounded spin that gave up, a dropped stack push: never expected, never silent).         */
 int slrhip_render(slrhip_ctx* ctx, uint32_t spp_begin, uint32_t spp_count, void* stream);
 
 /* Resolve the accumulated radiance into a linear float framebuffer

@@ -67,7 +67,10 @@ enum { T_EXT_RAYS = 0, T_SHADOW_RAYS = 1, T_NODES_CLOSEST = 2, T_TRIS_CLOSEST = 
        // schedule diagnostics of the wave-specialised closest-hit kernel (counting builds only; SLRHIP_DEBUG_WS prints them)
        T_WS_STEPS = 7, T_WS_IDLE_SPINS = 8, T_WS_CYCLES = 9, T_WS_IDLE_CYCLES = 10, T_WS_REFILLS = 11, T_WS_PRODUCER_WAITS = 12,
        T_WS_NODE_BLOCKS = 13, T_WS_TRI_BLOCKS = 14, T_WS_ACTIVE_LANES = 15,
-       T_KINDS = 16 };
+       T_SAMPLES = 16,          // finished samples accumulated into pixels, summed from the slots' headers at the end of a render call
+       T_KINDS = 17 };
+// device error word bits (PathBuffers::errorWord): set by any kernel path that gives up or drops work
+enum : uint32_t { ERR_RING_SPACE = 1u, ERR_RING_RELEASE = 2u, ERR_CONSUMER_IDLE = 4u, ERR_STACK_OVERFLOW = 8u, ERR_QUEUE_OVERFLOW = 16u };
 static const uint32_t kTotalStride = 16;                   // 64-bit words: one 128-byte line
 __host__ __device__ inline uint32_t totalIndex(uint32_t kind, uint32_t shard) { return (kind * kShards + shard) * kTotalStride; }
 
@@ -102,6 +105,7 @@ struct PathBuffers {
     uint32_t* regenQueue;         // same layout: slots whose path ended (accumulate pixel, start next sample)
     uint32_t* queueCount;         // [parity][kind][shard], see queueCounterIndex
     uint32_t* activeSlots;        // slots that still have samples to do
+    uint32_t* errorWord;          // ERR_* bits, sticky until the next slrhip_render call; read back with activeSlots
     uint64_t* totals;             // [kind][shard], see totalIndex
     const uint32_t* pixelXY;      // pixel-of-shard -> x | y << 16
 };
@@ -116,6 +120,7 @@ struct RenderParams {
     uint32_t shardCapacity;       // entries per queue region = ceil(numBlocks / kShards) * 256
     uint32_t spectral;            // 0 = RGB (3 components), 1 = 16 wavelength samples
     uint32_t spectralQuad;        // spectral shade kernel with four lanes per slot (SLRHIP_FLAG_SPECTRAL_QUAD)
+    uint32_t injectError;         // SLRHIP_FLAG_TEST_DEVICE_ERROR: the reset kernel raises the device error word
 };
 
 void launchResetSlots(const PathBuffers& pb, const RenderParams& rp, bool clearAccumulators, hipStream_t stream);
@@ -125,6 +130,7 @@ void launchTraceClosest(const DevScene& sc, const PathBuffers& pb, const RenderP
 void launchTraceShadow(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, uint32_t blocks, bool count,
                        hipStream_t stream);
 void launchLogic(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, hipStream_t stream);
+void launchCountSamples(const PathBuffers& pb, const RenderParams& rp, hipStream_t stream);
 void launchResolve(const PathBuffers& pb, const RenderParams& rp, float* dst, hipStream_t stream);
 void launchBsdfQueries(const DevScene& sc, bool spectral, uint32_t material, uint32_t n, const float* in, float wlOffset, uint32_t wl,
                        float4* geo, float4* misc, float4* fsSample, float4* fsEval, hipStream_t stream);

@@ -1,5 +1,7 @@
 // pt_shade.hip — launchers of the shading half of the wavefront path tracer (gfx950, wave64) and the instantiations of its
 // small kernels; the kernel templates are in pt_shade_kernels.h, the k_logic instantiations in pt_shade_{rgb,spec16,specq,multi}.hip.
+#include <algorithm>
+
 #include "pt_shade_kernels.h"
 
 namespace slrhip {
@@ -41,6 +43,28 @@ void launchBsdfQueries(const DevScene& sc, bool spectral, uint32_t material, uin
     const dim3 grid((n + 63) / 64), block(64);
     if (spectral) hipLaunchKernelGGL(k_bsdf_queries<Spec16>, grid, block, 0, stream, sc, material, n, in, wlOffset, wl, geo, misc, fsSample, fsEval);
     else hipLaunchKernelGGL(k_bsdf_queries<RGB>, grid, block, 0, stream, sc, material, n, in, wlOffset, wl, geo, misc, fsSample, fsEval);
+}
+// Samples accumulated into pixels by the render call that just ended = sum over the slots of the per-slot count k_regen keeps
+// in the sample header (hdr.x, restarted by k_reset_slots).  This is the device's own account of the work done: the host's
+// numPixels x spp would be a tautology.  One atomic per workgroup on the sharded totals.
+__global__ __launch_bounds__(kShadeBlock) void k_count_samples(PathBuffers pb, RenderParams rp) {
+    __shared__ uint32_t red[kShadeBlock / 64];
+    uint32_t n = 0;
+    for (uint32_t slot = blockIdx.x * kShadeBlock + threadIdx.x; slot < rp.numSlots; slot += gridDim.x * kShadeBlock) n += pb.hdr[slot].x;
+    for (int off = 32; off > 0; off >>= 1) n += __shfl_down(n, off);
+    if ((threadIdx.x & 63u) == 0) red[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int w = 0; w < kShadeBlock / 64; ++w) t += red[w];
+        if (t) atomicAdd((unsigned long long*)&pb.totals[totalIndex(T_SAMPLES, blockIdx.x % kShards)], (unsigned long long)t);
+    }
+}
+
+void launchCountSamples(const PathBuffers& pb, const RenderParams& rp, hipStream_t stream) {
+    if (rp.numSlots == 0) return;
+    const uint32_t blocks = std::min<uint32_t>((rp.numSlots + kShadeBlock - 1) / kShadeBlock, 2048u);
+    hipLaunchKernelGGL(k_count_samples, dim3(blocks), dim3(kShadeBlock), 0, stream, pb, rp);
 }
 void launchResolve(const PathBuffers& pb, const RenderParams& rp, float* dst, hipStream_t stream) {
     const dim3 grid((rp.numPixels + 255) / 256), block(256);

@@ -139,7 +139,7 @@ struct PushLds {
     uint32_t base[Q_KINDS];
 };
 __device__ __forceinline__ void blockPush(PushLds& pl, bool emit0, bool emit1, uint32_t slot, uint32_t* queue0, uint32_t* queue1,
-                                          uint32_t* counters /* set being filled */, uint32_t shardCapacity) {
+                                          uint32_t* counters /* set being filled */, uint32_t shardCapacity, uint32_t* errorWord) {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t shard = blockIdx.x % kShards;
     const uint64_t m0 = __ballot(emit0), m1 = __ballot(emit1);
@@ -149,6 +149,7 @@ __device__ __forceinline__ void blockPush(PushLds& pl, bool emit0, bool emit1, u
         const uint32_t q = threadIdx.x;
         const uint32_t total = pl.count[q][0] + pl.count[q][1] + pl.count[q][2] + pl.count[q][3];
         pl.base[q] = total ? atomicAdd(&counters[(q * kShards + shard) * kCounterStride], total) : 0u;
+        if (pl.base[q] + total > shardCapacity) atomicOr(errorWord, ERR_QUEUE_OVERFLOW);     // cannot happen: a region holds every slot of its blocks
     }
     __syncthreads();
     const uint64_t below = (1ull << lane) - 1ull;
@@ -759,7 +760,7 @@ __attribute__((amdgpu_waves_per_eu(S::N == 3 ? SLR_WAVES_RGB : (MF ? SLR_WAVES_S
 
     // ---- stream compaction of the shadow rays and of the finished slots -----------------------------------------
     (void)emitExt;     // extension rays need no queue: the traversal kernel reads the state flag
-    blockPush(pushLds, emitShadow && leader, emitRegen && leader, slot, pb.shadowQueue, pb.regenQueue, qw, rp.shardCapacity);
+    blockPush(pushLds, emitShadow && leader, emitRegen && leader, slot, pb.shadowQueue, pb.regenQueue, qw, rp.shardCapacity, pb.errorWord);
     if (rp.countSlots) {
         const uint64_t ma = __ballot((emitExt || emitShadow || emitRegen) && leader);
         if ((threadIdx.x & 63u) == 0 && ma)
@@ -937,7 +938,7 @@ __global__ void k_reset_slots(PathBuffers pb, RenderParams rp, uint32_t clearAcc
             }
             pb.queueCount[queueCounterIndex(0, Q_REGEN, r)] = cnt;
         }
-        if (threadIdx.x == 0) pb.activeSlots[0] = rp.numSlots;
+        if (threadIdx.x == 0) { pb.activeSlots[0] = rp.numSlots; pb.errorWord[0] = rp.injectError ? ERR_QUEUE_OVERFLOW : 0u; }
     }
 }
 

@@ -38,7 +38,8 @@ struct TravCount {
 template <bool ANY_HIT, bool COUNT>
 __device__ __forceinline__ bool traverse(const float4* __restrict__ nodes4, const float4* __restrict__ tris4, const float4* topNodes,
                                          uint32_t numTop, V3 org, V3 dir, float tmin, float tmax, HitRec* hit,
-                                         uint32_t* ldsStack /* [kLdsStack][blockDim], this lane's column */, TravCount* cnt) {
+                                         uint32_t* ldsStack /* [kLdsStack][blockDim], this lane's column */, TravCount* cnt,
+                                         uint32_t* errorWord = nullptr) {
     const float idx = 1.0f / dir.x, idy = 1.0f / dir.y, idz = 1.0f / dir.z;      // Vector3.h:60 reciprocal()
     // float4 index inside a node: 0..2 = min xyz, 3..5 = max xyz, 6 = children
     const int nx = idx > 0.0f ? 0 : 3, fx = 3 - nx;
@@ -126,6 +127,7 @@ __device__ __forceinline__ bool traverse(const float4* __restrict__ nodes4, cons
         if ((cond) && (ref) != next) {                                                   \
             if (sp < kLdsStack) ldsStack[sp * kTraceBlock] = (ref);                      \
             else if (sp < kLdsStack + kSpillStack) spill[sp - kLdsStack] = (ref);        \
+            else { if (errorWord) atomicOr(errorWord, ERR_STACK_OVERFLOW); --sp; }       \
             ++sp;                                                                        \
         }
         SLR_PUSH(h0, c0)
@@ -187,7 +189,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace_closest(DevScene sc, Path
             const float4 d = pb.rayDir[slot];
             HitRec hit;
             traverse<false, COUNT>(sc.nodes, sc.leafTris, lds.top, numTop, V3(o.x, o.y, o.z), V3(d.x, d.y, d.z), o.w, d.w, &hit,
-                                   lds.stack + threadIdx.x, &cnt);
+                                   lds.stack + threadIdx.x, &cnt, pb.errorWord);
             pb.hit[slot] = make_float4(__uint_as_float(hit.tri), hit.t, hit.b0, hit.b1);
             ++rays;
         }
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace_shadow(DevScene sc, PathB
         const float4 d = pb.shadowDir[slot];
         HitRec hit;
         const bool occluded = traverse<true, COUNT>(sc.nodes, sc.leafTris, lds.top, numTop, V3(o.x, o.y, o.z), V3(d.x, d.y, d.z),
-                                                    kRayEpsilon, d.w, &hit, lds.stack + threadIdx.x, &cnt);
+                                                    kRayEpsilon, d.w, &hit, lds.stack + threadIdx.x, &cnt, pb.errorWord);
         pb.visible[slot] = occluded ? 0u : 1u;
         ++rays;
     }

@@ -200,15 +200,17 @@ __device__ __forceinline__ void wsConsume(const DevScene& sc, const PathBuffers&
                 // cycles at most: the earlier wave is between its compare-and-swap and the end of its own ring reads.
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");           // the ring reads above are complete
                 if (lane == 0) {
-                    for (uint32_t spin = 0; spin < kSpinLimit && WS_LOAD(&lds.released, __ATOMIC_ACQUIRE) != start; ++spin)
+                    uint32_t spin = 0;
+                    for (; spin < kSpinLimit && WS_LOAD(&lds.released, __ATOMIC_ACQUIRE) != start; ++spin)
                         __builtin_amdgcn_s_sleep(1);
+                    if (spin == kSpinLimit) atomicOr(pb.errorWord, ERR_RING_RELEASE);     // never expected; the render fails loudly
                     WS_STORE(&lds.released, start + take, __ATOMIC_RELEASE);
                 }
             }
             else if (nIdle == 64) {
                 // nothing in flight and nothing to take: finished, or the producer is behind
                 if (WS_LOAD(&lds.done, __ATOMIC_ACQUIRE) && WS_LOAD(&lds.tail, __ATOMIC_ACQUIRE) == WS_LOAD(&lds.reserved, __ATOMIC_RELAXED)) break;
-                if (++idleSpins > kSpinLimit) break;
+                if (++idleSpins > kSpinLimit) { if (lane == 0) atomicOr(pb.errorWord, ERR_CONSUMER_IDLE); break; }
                 if (COUNT) {
                     const uint64_t t0 = __builtin_readcyclecounter();
                     __builtin_amdgcn_s_sleep(4);
@@ -311,6 +313,7 @@ __device__ __forceinline__ void wsConsume(const DevScene& sc, const PathBuffers&
                     if (cond) {                                                         \
                         if (sp < kWsLdsStack) { stack[sp * 64] = (ref); ++sp; }         \
                         else if (!kNoSpill && sp < kWsLdsStack + kWsSpill) { spill[sp - kWsLdsStack] = (ref); ++sp; } \
+                        else atomicOr(pb.errorWord, ERR_STACK_OVERFLOW);      /* the host rejects trees that could get here */ \
                     }
                     WS_PUSH(v0, c0)
                     WS_PUSH(v1, c1)
@@ -447,7 +450,7 @@ __global__ __launch_bounds__(64 * (NC + 1)) __attribute__((amdgpu_waves_per_eu(8
                         d[j] = live[j] ? ntLoad4(&pb.rayDir[s]) : make_float4(0, 0, 0, 0);
                     }
                     ok = wsWaitSpace(lds, tailLocal, chunk, &dbg.producerWaits);
-                    if (!ok) break;
+                    if (!ok) { if (lane == 0) atomicOr(pb.errorWord, ERR_RING_SPACE); break; }
 #pragma unroll
                     for (int j = 0; j < kSub; ++j) tailLocal += wsAppend(lds, tailLocal, live[j], c * chunk + j * 64 + lane, o[j], d[j]);
                     WS_STORE(&lds.tail, tailLocal, __ATOMIC_RELEASE);
@@ -475,7 +478,7 @@ __global__ __launch_bounds__(64 * (NC + 1)) __attribute__((amdgpu_waves_per_eu(8
                     d[j] = valid ? ntLoad4(&pb.shadowDir[sl[j]]) : make_float4(0, 0, 0, 0);
                     o[j].w = kRayEpsilon;
                 }
-                if (!wsWaitSpace(lds, tailLocal, chunk, &dbg.producerWaits)) break;
+                if (!wsWaitSpace(lds, tailLocal, chunk, &dbg.producerWaits)) { if (lane == 0) atomicOr(pb.errorWord, ERR_RING_SPACE); break; }
 #pragma unroll
                 for (int j = 0; j < kSub; ++j) tailLocal += wsAppend(lds, tailLocal, sl[j] != kIdle, sl[j] | kShadowBit, o[j], d[j]);
                 WS_STORE(&lds.tail, tailLocal, __ATOMIC_RELEASE);

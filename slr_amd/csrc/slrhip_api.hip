@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -31,6 +32,18 @@ int fail(int code, const std::string& msg) {
     return code;
 }
 
+// Device-side error word (PathBuffers::errorWord): every bounded spin that gives up and every dropped stack push sets a bit, so a
+// logic error in a kernel fails the render instead of returning a wrong image with status 0.
+int deviceError(uint32_t bits) {
+    std::string what = "slrhip_render: device-side error word set:";
+    if (bits & ERR_RING_SPACE) what += " [producer gave up waiting for ray-ring space]";
+    if (bits & ERR_RING_RELEASE) what += " [consumer gave up waiting for the ring's release watermark]";
+    if (bits & ERR_CONSUMER_IDLE) what += " [consumer wave gave up waiting for rays]";
+    if (bits & ERR_STACK_OVERFLOW) what += " [traversal stack overflow: a push was dropped]";
+    if (bits & ERR_QUEUE_OVERFLOW) what += " [queue region overflow]";
+    return fail(SLRHIP_ERR_HIP, what);
+}
+
 #define HIP_TRY(expr)                                                                                   \
     do {                                                                                                \
         hipError_t e_ = (expr);                                                                         \
@@ -42,7 +55,7 @@ int fail(int code, const std::string& msg) {
 // the HBM channel interleave in every per-slot array, and a wave that loads its ten state records back to
 // back would queue all of them on one channel ("partition camping").  Each array therefore starts at its
 // own skew: a distinct odd multiple of 256 B plus a few KiB.
-static size_t g_skewCounter = 0;
+static std::atomic<size_t> g_skewCounter{0};     // shared by every context of the process; contexts may be set up from several threads
 
 template <typename T>
 struct DevArray {
@@ -128,7 +141,6 @@ struct slrhip_ctx {
     DevArray<float> resolveScratch;
     PathBuffers buffers;
     uint64_t iterations = 0;
-    uint64_t samplesDone = 0;
     bool firstRenderCall = true;
 
     // SLRHIP_FLAG_TIME_KERNELS: 4 events per iteration (before closest, after closest, after shadow, after shade)
@@ -176,6 +188,9 @@ int slrhip_create(const slrhip_config* config, slrhip_ctx** out) {
     *out = nullptr;
     if (config->mode != SLRHIP_MODE_RGB && config->mode != SLRHIP_MODE_SPECTRAL)
         return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_create: unknown mode");
+    // the per-pixel sample pool tracks the stripes of a pixel in a 64-bit mask (PathBuffers::finishedMask)
+    if (config->stripes > SLRHIP_MAX_STRIPES)
+        return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_create: at most 64 sample stripes per pixel (slrhip_config::stripes)");
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0)
@@ -605,11 +620,16 @@ int slrhip_render_begin(slrhip_ctx* ctx, const slrhip_render_settings* st, slrhi
     const uint32_t numBlocks = (uint32_t)((numSlots + 255) / 256);
     const uint32_t shardCapacity = ((numBlocks + kShards - 1) / kShards) * 256;
     HIP_TRY(ctx->shadowQueue.alloc((size_t)shardCapacity * kShards, true)); HIP_TRY(ctx->regenQueue.alloc((size_t)shardCapacity * kShards, true));
-    HIP_TRY(ctx->queueCount.alloc(2 * kQueueSetWords)); HIP_TRY(ctx->activeSlots.alloc(1));
+    HIP_TRY(ctx->queueCount.alloc(2 * kQueueSetWords)); HIP_TRY(ctx->activeSlots.alloc(2));      // [0] live slots, [1] device error word
     HIP_TRY(ctx->totals.alloc((size_t)T_KINDS * kShards * kTotalStride));
-    HIP_TRY(hipMemset(ctx->totals.ptr, 0, ctx->totals.count * sizeof(uint64_t)));
-    HIP_TRY(hipMemset(ctx->queueCount.ptr, 0, 2 * kQueueSetWords * sizeof(uint32_t)));
-    // hipMemset on device memory is only ordered on the null stream; slrhip_render may be given a non-blocking stream
+    // The statistics restart here.  A memset of device memory is only ordered on the null stream, and slrhip_render may be
+    // given a NON-BLOCKING stream, which the null stream does not wait for and which does not wait for it: the memset has to
+    // be complete before this call returns.  (Round 1, gpurun_out/overlap.log: this function also cleared queueCount with a
+    // second null-stream memset and did not wait; on a non-blocking stream k_reset_slots — which writes the initial regen
+    // counts into queueCount — could run BEFORE that memset landed, the counts were wiped, no slot ever started a sample and
+    // slrhip_render ran into its iteration bound.  queueCount is now written by k_reset_slots alone, in stream order.)
+    HIP_TRY(hipMemsetAsync(ctx->totals.ptr, 0, ctx->totals.count * sizeof(uint64_t), nullptr));
+    HIP_TRY(hipMemsetAsync(ctx->activeSlots.ptr, 0, 2 * sizeof(uint32_t), nullptr));
     HIP_TRY(hipStreamSynchronize(nullptr));
 
     PathBuffers& pb = ctx->buffers;
@@ -618,7 +638,7 @@ int slrhip_render_begin(slrhip_ctx* ctx, const slrhip_render_settings* st, slrhi
     pb.nee = ctx->nee.ptr;
     pb.pdfPrev = spectral ? ctx->pdfPrev.ptr : nullptr; pb.hdr = ctx->hdr.ptr; pb.finishedMask = ctx->finishedMask.ptr; pb.nextSample = ctx->nextSample.ptr; pb.shadowDir = ctx->shadowDir.ptr; pb.flags = ctx->flags.ptr;
     pb.visible = ctx->visible.ptr; pb.shadowQueue = ctx->shadowQueue.ptr; pb.regenQueue = ctx->regenQueue.ptr;
-    pb.queueCount = ctx->queueCount.ptr; pb.activeSlots = ctx->activeSlots.ptr; pb.totals = ctx->totals.ptr;
+    pb.queueCount = ctx->queueCount.ptr; pb.activeSlots = ctx->activeSlots.ptr; pb.errorWord = ctx->activeSlots.ptr + 1; pb.totals = ctx->totals.ptr;
     pb.pixelXY = ctx->pixelXY.ptr;
 
     RenderParams& rp = ctx->params;
@@ -630,7 +650,7 @@ int slrhip_render_begin(slrhip_ctx* ctx, const slrhip_render_settings* st, slrhi
     rp.shardCapacity = shardCapacity;
     rp.spectral = spectral ? 1u : 0u;
     rp.spectralQuad = (ctx->config.flags & SLRHIP_FLAG_SPECTRAL_QUAD) ? 1u : 0u;
-    ctx->samplesDone = 0;
+    rp.injectError = (ctx->config.flags & SLRHIP_FLAG_TEST_DEVICE_ERROR) ? 1u : 0u;
     ctx->settings = *st;
     ctx->shard = shard;
     ctx->iterations = 0;
@@ -663,6 +683,7 @@ int slrhip_render(slrhip_ctx* ctx, uint32_t sppBegin, uint32_t sppCount, void* s
 
     uint32_t parity = 0;
     uint32_t active = rp.numSlots;
+    uint32_t status[2] = {rp.numSlots, 0u};       // device words: live slots, error bits (PathBuffers::activeSlots / errorWord)
     // Each check costs one small copy + stream sync; 16 iterations between checks keeps it < 1 %.
     const int kCheckEvery = 16;
     const int kEv = 5;    // events per iteration: before regen, after regen, after closest, after shadow, after logic
@@ -710,21 +731,29 @@ int slrhip_render(slrhip_ctx* ctx, uint32_t sppBegin, uint32_t sppCount, void* s
         int rc = SLRHIP_OK;
         while (active > 0 && rc == SLRHIP_OK) {
             hipError_t e = hipGraphLaunch(exec, ws);
-            if (e == hipSuccess) e = hipMemcpyAsync(&active, ctx->activeSlots.ptr, sizeof(uint32_t), hipMemcpyDeviceToHost, ws);
+            if (e == hipSuccess) e = hipMemcpyAsync(status, ctx->activeSlots.ptr, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, ws);
             if (e == hipSuccess) e = hipStreamSynchronize(ws);
             if (e != hipSuccess) rc = fail(SLRHIP_ERR_HIP, std::string("slrhip_render: ") + hipGetErrorString(e));
+            active = status[0];
             it += kCheckEvery;
+            if (rc == SLRHIP_OK && status[1]) rc = deviceError(status[1]);
             if (rc == SLRHIP_OK && it > maxIterations) rc = fail(SLRHIP_ERR_HIP, "slrhip_render: iteration bound exceeded (internal error)");
         }
         (void)hipGraphExecDestroy(exec);
         (void)hipGraphDestroy(graph);
         if (rc != SLRHIP_OK) return rc;
         ctx->iterations += it;
-        ctx->samplesDone += (uint64_t)rp.numPixels * sppCount;
+        launchCountSamples(ctx->buffers, rp, ws);      // samples accumulated by this call, counted on the device (T_SAMPLES)
         HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(ws));
         return SLRHIP_OK;
     }
 
+    // SLRHIP_ITER_LOG=path (with SLRHIP_FLAG_TIME_KERNELS): per-iteration kernel times of this call, one line per iteration
+    // "iteration regen_ms trace_ms logic_ms live_slots_at_block_end" — how the drain of a render's last paths was measured
+    static const char* iterLog = getenv("SLRHIP_ITER_LOG");
+    std::vector<float> iterMs;
+    std::vector<uint32_t> iterActive;
     while (active > 0) {
         for (int k = 0; k < kCheckEvery; ++k) {
             hipEvent_t* ev = timeKernels ? &ctx->events[(size_t)k * kEv] : nullptr;
@@ -747,8 +776,11 @@ int slrhip_render(slrhip_ctx* ctx, uint32_t sppBegin, uint32_t sppCount, void* s
             parity ^= 1;
             ++it;
         }
-        HIP_TRY(hipMemcpyAsync(&active, ctx->activeSlots.ptr, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipGetLastError());                  // a failed launch surfaces here, not at the end of the render
+        HIP_TRY(hipMemcpyAsync(status, ctx->activeSlots.ptr, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
+        active = status[0];
+        if (status[1]) return deviceError(status[1]);
         if (timeKernels) {
             static const int cls[4] = {SLRHIP_KERNEL_REGEN, SLRHIP_KERNEL_TRACE_CLOSEST, SLRHIP_KERNEL_TRACE_SHADOW, SLRHIP_KERNEL_SHADE};
             for (int k = 0; k < kCheckEvery; ++k) {
@@ -759,14 +791,28 @@ int slrhip_render(slrhip_ctx* ctx, uint32_t sppBegin, uint32_t sppCount, void* s
                     HIP_TRY(hipEventElapsedTime(&ms, ev[j], ev[j + 1]));
                     ctx->profMs[cls[j]] += ms;
                     ++ctx->profLaunches[cls[j]];
+                    if (iterLog) iterMs.push_back(ms);
                 }
+                if (iterLog) iterActive.push_back(active);
             }
         }
         if (it > maxIterations) return fail(SLRHIP_ERR_HIP, "slrhip_render: iteration bound exceeded (internal error)");
     }
     ctx->iterations += it;
-    ctx->samplesDone += (uint64_t)rp.numPixels * sppCount;      // every slot ran out of passes: all samples are accumulated
+    launchCountSamples(ctx->buffers, rp, stream);       // samples accumulated by this call, counted on the device (T_SAMPLES)
     HIP_TRY(hipGetLastError());
+    if (iterLog && timeKernels && !iterActive.empty()) {
+        if (FILE* f = fopen(iterLog, "a")) {
+            const size_t per = iterMs.size() / iterActive.size();
+            fprintf(f, "# render: %u slots, %u passes from %u\n", rp.numSlots, sppCount, sppBegin);
+            for (size_t i = 0; i < iterActive.size(); ++i) {
+                fprintf(f, "%zu", i);
+                for (size_t j = 0; j < per; ++j) fprintf(f, " %.4f", iterMs[i * per + j]);
+                fprintf(f, " %u\n", iterActive[i]);
+            }
+            fclose(f);
+        }
+    }
     return SLRHIP_OK;
 }
 
@@ -819,7 +865,7 @@ int slrhip_get_counters(slrhip_ctx* ctx, slrhip_counters* out) {
         if (rc != SLRHIP_OK) return rc;
         out->extension_rays = t[T_EXT_RAYS];
         out->shadow_rays = t[T_SHADOW_RAYS];
-        out->samples = ctx->samplesDone;
+        out->samples = t[T_SAMPLES];          // counted on the device from the slots' sample headers (k_count_samples)
     }
     return SLRHIP_OK;
 }

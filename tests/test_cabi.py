@@ -34,7 +34,8 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_version(lib):
-    assert lib.slrhip_version() == 3
+    text = open(os.path.join(ROOT, "include", "slrhip.h")).read()
+    assert lib.slrhip_version() == int(re.search(r"#define SLRHIP_VERSION (\d+)", text).group(1)) == 4
 
 
 def test_create_fails_loudly_without_gpu(lib):
@@ -82,6 +83,4 @@ def test_tonemap_and_bmp_match_reference_saveimage(lib, name):
     assert mine.size == ref.size
     assert (mine[:54] == ref[:54]).all()                          # headers
     a, b = mine[54:].reshape(h, byte_width)[:, :3 * w], ref[54:].reshape(h, byte_width)[:, :3 * w]
-    diff = np.abs(a.astype(int) - b.astype(int))
-    # float vs double evaluation order in sRGB_gamma can move a value across an integer boundary
-    assert diff.max() <= 1 and (diff != 0).mean() < 0.01
+    assert (a == b).all(), "%d of %d pixel bytes differ" % ((a != b).sum(), a.size)

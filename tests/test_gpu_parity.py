@@ -213,6 +213,137 @@ def test_quantized_nodes_give_the_same_hits():
     assert_bit_equal(frames[1], frames[0], "quantized wave-specialised vs float batch")
 
 
+def test_quantized_grid_against_oracle_and_reference_golden(oracle_rgb):
+    """BASELINE configs[4]'s shape: the displaced grid (320 002 triangles -> >= 64 Ki four-wide nodes, so the DEFAULT
+    wave-specialised kernel traverses the 64-byte quantized nodes), thin lens r = 0.025.  Against the ORACLE at matched
+    seeds: frame and both ray counts.  Against the compiled reference's golden (tests/golden/rgb_grid400.npz; SBVH.h:417-442,
+    TriangleMesh.cpp:131-178): the 2 048 closest hits bit-equal, the frame equal except at equal-distance hits (see
+    test_oracle_golden.test_displaced_grid_matches_reference)."""
+    from test_oracle_golden import procedural_scene
+    g = load_golden("rgb_grid400")
+    sc = procedural_scene(g)
+    assert sc.camera.lens_radius == np.float32(0.025)
+    c = Context(stripes=1)
+    try:
+        st = ob.settings(int(g["width"]), int(g["height"]), int(g["seed"]))
+        fb = c.render_image(sc, st, int(g["spp"]))
+        k = c.counters()
+        assert k.bvh_nodes >= 65536
+        tri, dist, b0, b1 = c.trace_rays(g["rays"]["org"], g["rays"]["dir"], g["rays"]["dist_min"], g["rays"]["dist_max"])
+        want = g["hits"]
+        assert (tri == want["triangle"]).all()
+        hit = want["triangle"] != 0xFFFFFFFF
+        assert_bit_equal(dist[hit], want["dist"][hit], "dist")
+        assert_bit_equal(b0[hit], want["b0"][hit], "b0")
+        assert_bit_equal(b1[hit], want["b1"][hit], "b1")
+        s = frame_stats(fb, g["framebuffer"])
+        assert s["exact_fraction"] >= 0.9995 and s["rmse"] <= 1e-3 * s["mean"], s
+        # a larger frame against the oracle, default stripes (the timed configuration), ray counts included
+        st2 = ob.settings(320, 180, seed=9)
+        worc, ctr = oracle_rgb.scene(sc).render(st2, 16)
+        c.upload_scene(sc)
+        c.render_begin(st2)
+        c.render(0, 16)
+        fb2, k2 = c.read_framebuffer(), c.counters()
+        assert_bit_equal(fb2, worc, "grid, stripes = 1, vs oracle")
+        assert int(k2.samples) == int(ctr.samples) == 320 * 180 * 16
+        assert int(k2.extension_rays) == int(ctr.extension_rays) and int(k2.shadow_rays) == int(ctr.shadow_rays)
+    finally:
+        c.close()
+    a = Context()          # automatic stripe count + sample pool: the summation order of a pixel's stripes changes, nothing else
+    try:
+        fb3 = a.render_image(sc, st2, 16)
+        k3 = a.counters()
+        assert int(k3.extension_rays) == int(ctr.extension_rays) and int(k3.shadow_rays) == int(ctr.shadow_rays)
+        assert np.allclose(fb3, worc, rtol=2e-6, atol=1e-9)
+    finally:
+        a.close()
+
+
+def test_spectral_boxes_against_oracle_and_reference_golden(sctx, oracle_spectral):
+    """BASELINE configs[2] exactly: scenes.cornell_box_boxes() (GGX titanium box, alpha_g 0.1, + matte box) in SPECTRAL mode.
+    Against the compiled spectral reference's golden (MicrofacetBSDF.cpp:11-110 on its own BSDF objects) and, at 128x128x16 spp,
+    against the oracle: the float-libm tolerance of the GGX tests (device acosf / tanf / atan2f differ from glibc in the last
+    ulp): RMSE <= 1e-3 x mean, >= 90 % of floats within 1e-4 relative; ray counts within 1e-3."""
+    g = load_golden("spectral_boxes")
+    st = ob.settings(int(g["width"]), int(g["height"]), int(g["seed"]))
+    fb = sctx.render_image(scene_from_golden(g), st, int(g["spp"]))
+    want = g["framebuffer"]
+    assert fb.shape == want.shape and fb.shape[2] == 16
+    s = frame_stats(fb, want)
+    assert s["rmse"] <= 1e-3 * s["mean"], s
+    assert np.isclose(fb, want, rtol=1e-4, atol=1e-9).mean() >= 0.90
+    assert np.isfinite(fb).all()
+    sc = scenes.cornell_box_boxes()
+    st = ob.settings(128, 128, seed=3)
+    want, ctr = oracle_spectral.scene(sc).render(st, 16)
+    fb = sctx.render_image(sc, st, 16)
+    s = frame_stats(fb, want)
+    assert s["rmse"] <= 1e-3 * s["mean"], s
+    assert np.isclose(fb, want, rtol=1e-4, atol=1e-9).mean() >= 0.90
+    k = sctx.counters()
+    assert int(k.samples) == int(ctr.samples) == 128 * 128 * 16
+    assert abs(int(k.extension_rays) - int(ctr.extension_rays)) <= ctr.extension_rays * 1e-3
+    assert abs(int(k.shadow_rays) - int(ctr.shadow_rays)) <= ctr.shadow_rays * 1e-3
+
+
+def test_first_render_call_may_start_at_a_later_pass(ctx, oracle_rgb):
+    """slrhip_render(ctx, spp_begin, ...) is an ABI promise (include/slrhip.h): the FIRST call after render_begin may start at
+    pass k > 0 (a second device rendering the later half of the passes).  Against oracle.render(sppBegin = k)."""
+    sc = scenes.cornell_box_spheres(1.0, 16, 8, "glass")
+    st = ob.settings(72, 48, seed=17)
+    want, ctr = oracle_rgb.scene(sc).render(st, 9, spp_begin=23)
+    ctx.upload_scene(sc)
+    ctx.render_begin(st)
+    ctx.render(23, 9)
+    assert_bit_equal(ctx.read_framebuffer(), want, "passes 23..31, stripes = 1")
+    k = ctx.counters()
+    assert int(k.samples) == int(ctr.samples) and int(k.extension_rays) == int(ctr.extension_rays)
+    a = Context(stripes=8)
+    try:
+        a.upload_scene(sc)
+        a.render_begin(st)
+        a.render(23, 9)
+        assert np.allclose(a.read_framebuffer(), want, rtol=2e-6, atol=1e-9)
+        assert int(a.counters().samples) == 72 * 48 * 9
+    finally:
+        a.close()
+
+
+def test_two_contexts_on_non_blocking_streams_from_two_threads(oracle_rgb):
+    """Regression for round 1's `iteration bound exceeded` (gpurun_out/overlap.log): two contexts on ONE device, each driven by
+    its own host thread on its own NON-BLOCKING stream, the first render call of one of them starting at pass k > 0.  The
+    cause was render_begin's null-stream memset of the queue counters racing k_reset_slots on the non-blocking stream
+    (DESIGN.md); each half is checked against the oracle, and their Kahan-free sum against the full render."""
+    import threading
+    import torch
+    sc = scenes.cornell_box_spheres(1.0, 24, 12, "matte")
+    st = ob.settings(256, 192, seed=5)
+    SPP = 32
+    o = oracle_rgb.scene(sc)
+    halves = [o.render(st, SPP // 2, spp_begin=i * SPP // 2)[0].copy() for i in range(2)]
+    for attempt in range(3):
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        ctxs = [Context(stripes=4), Context(stripes=4)]
+        got, errors = [None, None], []
+
+        def work(i):
+            try:
+                ctxs[i].upload_scene(sc)
+                ctxs[i].render_begin(st)
+                ctxs[i].render(i * SPP // 2, SPP // 2, streams[i].cuda_stream)
+                got[i] = ctxs[i].read_framebuffer()
+            except Exception as e:
+                errors.append(e)
+        th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        [c.close() for c in ctxs]
+        assert not errors, errors
+        for i in range(2):
+            assert np.allclose(got[i], halves[i], rtol=2e-6, atol=1e-9), "context %d, attempt %d" % (i, attempt)
+
+
 def test_errors_are_loud(ctx):
     import ctypes as C
     from slr_amd.binding import SlrHipError
@@ -220,6 +351,17 @@ def test_errors_are_loud(ctx):
     with pytest.raises(SlrHipError):
         c2.render_begin(ob.settings(8, 8))          # no scene uploaded
     c2.close()
+    with pytest.raises(SlrHipError, match="64 sample stripes"):
+        Context(stripes=65)                         # the sample pool's mask is 64 bits wide
+    # a kernel that gives up (bounded spin, dropped push) raises the device error word: the render must fail, not return rc 0
+    c3 = Context(flags=abi.FLAG_TEST_DEVICE_ERROR)
+    try:
+        c3.upload_scene(scenes.tiny_box(1.0))
+        c3.render_begin(ob.settings(16, 16))
+        with pytest.raises(SlrHipError, match="device-side error word"):
+            c3.render(0, 2)
+    finally:
+        c3.close()
 
 
 @pytest.mark.parametrize("name", ["rgb_oren_nayar"])

@@ -27,12 +27,18 @@ for stripes in (8, 4):
 for stripes in (4, 8):
     streams = [torch.cuda.Stream(), torch.cuda.Stream()]
     ctxs = [one(stripes, SPP, s.cuda_stream) for s in streams]
+    errors = []
     def work(i):
-        ctxs[i].render_begin(st)
-        ctxs[i].render(i * SPP // 2, SPP // 2, streams[i].cuda_stream)
+        try:
+            ctxs[i].render_begin(st)
+            ctxs[i].render(i * SPP // 2, SPP // 2, streams[i].cuda_stream)
+        except Exception as e:      # a worker's failure must fail the probe, not vanish with the thread
+            errors.append(e)
     t = time.perf_counter()
     th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
     [x.start() for x in th]; [x.join() for x in th]
+    if errors:
+        raise errors[0]
     torch.cuda.synchronize()
     dt = time.perf_counter() - t
     print("two contexts x stripes=%d on two streams: %.1f Msamples/s" % (stripes, W * H * SPP / dt / 1e6), flush=True)

@@ -27,7 +27,7 @@ def shard_time(world, stripes):
 
 
 for rnd in range(2):
-    for world, ks in ((1, (8, 16, 24, 32)), (4, (32, 64, 96, 128)), (8, (64, 96, 128, 192, 256))):
+    for world, ks in ((1, (8, 16, 24, 32)), (4, (16, 32, 48, 64)), (8, (16, 32, 48, 64))):
         for k in ks:
             t, it = shard_time(world, k)
             print("N=%d stripes=%3d: %.1f ms, %d iterations" % (world, k, t * 1e3, it), flush=True)
