@@ -359,6 +359,18 @@ int slrhip_bsdf_queries(slrhip_ctx* ctx, uint32_t material, uint32_t n, const fl
 /* The per-(pixel, sample) seeding contract (pure function, also used by the oracle).      */
 int32_t slrhip_sample_seed(int32_t rng_seed, uint32_t pixel_x, uint32_t pixel_y, uint32_t pass);
 
+/* ---- host-side construction of spectral-mode spectra ------------------------------------------------------------------ */
+/* SpectrumType / ColorSpace of the reference (BasicTypes/Spectrum.h:17-35), as the scene language's Spectrum(...) passes them. */
+enum { SLRHIP_SPECTRUMTYPE_REFLECTANCE = 0, SLRHIP_SPECTRUMTYPE_ILLUMINANT = 1, SLRHIP_SPECTRUMTYPE_IOR = 2 };
+enum { SLRHIP_COLORSPACE_SRGB = 0, SLRHIP_COLORSPACE_SRGB_NONLINEAR = 1, SLRHIP_COLORSPACE_XYY = 2, SLRHIP_COLORSPACE_XYZ = 3 };
+#define SLRHIP_UPSAMPLING_SAMPLES 95u    /* samples per data-point spectrum, 360-830 nm (Spectrum.h:197) */
+/* Replaces: the UpsampledContinuousSpectrum(spType, space, e0, e1, e2) constructor (BasicTypes/SpectrumTypes.h:180-237), which
+ * `Spectrum(r, g, b)` of the scene language calls (libSLRSceneGraph/API.cpp:286-441, :1139-1147): writes (u, v, scale).        */
+int slrhip_upsample(int32_t spectrum_type, int32_t color_space, float e0, float e1, float e2, float uvs[3]);
+/* Replaces: the (u, v)-only half of UpsampledContinuousSpectrum::evaluate (SpectrumTypes.h:241-312).  Writes the number of data
+ * points (0, 3 or 4 -> slrhip_spectrum::reserved) and the 4 + 4 * SLRHIP_UPSAMPLING_SAMPLES floats of the UPSAMPLED payload. */
+int slrhip_resolve_upsampled(const slrhip_upsampling_tables* tables, float u, float v, uint32_t* num_points, float* payload);
+
 /* Host-side helpers on the float framebuffer.
  * slrhip_tonemap_bgr8: ImageSensor::saveImage (ImageSensor.cpp:138-186) pixel pipeline:
  * scale*sensitivity -> (spectral: XYZ->sRGB) -> 1-exp(-Y) tone map -> sRGB gamma -> 8-bit BGR,

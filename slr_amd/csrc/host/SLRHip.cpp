@@ -9,7 +9,81 @@
 
 namespace SLRHip {
 
-Scene::Scene() { std::memset(&m_camera, 0, sizeof(m_camera)); }
+Scene::Scene() { std::memset(&m_camera, 0, sizeof(m_camera)); std::memset(&m_tables, 0, sizeof(m_tables)); }
+
+bool Scene::loadSpectralTables(const std::string& path) {
+    FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) { std::fprintf(stderr, "SLRHip: cannot open %s\n", path.c_str()); return false; }
+    char magic[8];
+    uint32_t hdr[4];
+    bool ok = std::fread(magic, 1, 8, f) == 8 && std::memcmp(magic, "SLRUPS01", 8) == 0 && std::fread(hdr, 4, 4, f) == 4;
+    if (ok) ok = hdr[0] > 0 && hdr[1] > 0 && hdr[0] * hdr[1] <= 65536 && hdr[2] > 0 && hdr[2] <= 255 && hdr[3] >= 2 && hdr[3] <= 65536;
+    if (ok) {
+        m_gridCells.resize((size_t)hdr[0] * hdr[1] * 8);
+        m_pointUV.resize((size_t)hdr[2] * 2);
+        m_pointSpectrum.resize((size_t)hdr[2] * SLRHIP_UPSAMPLING_SAMPLES);
+        m_d65.resize(hdr[3]);
+        ok = std::fread(m_gridCells.data(), 1, m_gridCells.size(), f) == m_gridCells.size() &&
+             std::fread(m_pointUV.data(), 4, m_pointUV.size(), f) == m_pointUV.size() &&
+             std::fread(m_pointSpectrum.data(), 4, m_pointSpectrum.size(), f) == m_pointSpectrum.size() &&
+             std::fread(m_d65.data(), 4, m_d65.size(), f) == m_d65.size();
+    }
+    std::fclose(f);
+    if (!ok) { std::fprintf(stderr, "SLRHip: %s is not a spectral table file\n", path.c_str()); return false; }
+    m_tables.grid_width = hdr[0]; m_tables.grid_height = hdr[1]; m_tables.num_points = hdr[2];
+    m_tables.cells = m_gridCells.data(); m_tables.point_uv = m_pointUV.data(); m_tables.point_spectrum = m_pointSpectrum.data();
+    m_hasTables = true;
+    return true;
+}
+
+static float degammaSRGB(float v) { return v <= 0.04045 ? (float)(v / 12.92) : (float)std::pow((v + 0.055) / 1.055, 2.4); }     // Spectrum.cpp:24-30
+
+uint32_t Scene::addUpsampledSpectrum(int32_t spectrumType, int32_t colorSpace, float e0, float e1, float e2) {
+    if (!m_hasTables) { std::fprintf(stderr, "SLRHip: addUpsampledSpectrum needs loadSpectralTables()\n"); std::exit(-1); }
+    slrhip_spectrum s;
+    std::memset(&s, 0, sizeof(s));
+    s.kind = SLRHIP_SPECTRUM_UPSAMPLED;
+    // RGB build: Spectrum::create keeps linear sRGB (API.cpp:1281-1369); a non-linear triple is de-gamma'd first
+    const bool nonLinear = colorSpace == SLRHIP_COLORSPACE_SRGB_NONLINEAR;
+    s.rgb[0] = nonLinear ? degammaSRGB(e0) : e0; s.rgb[1] = nonLinear ? degammaSRGB(e1) : e1; s.rgb[2] = nonLinear ? degammaSRGB(e2) : e2;
+    float uvs[3];
+    std::vector<float> payload(4 + 4 * SLRHIP_UPSAMPLING_SAMPLES);
+    uint32_t numPoints = 0;
+    if (slrhip_upsample(spectrumType, colorSpace, e0, e1, e2, uvs) != SLRHIP_OK ||
+        slrhip_resolve_upsampled(&m_tables, uvs[0], uvs[1], &numPoints, payload.data()) != SLRHIP_OK) {
+        std::fprintf(stderr, "SLRHip: cannot upsample (%g, %g, %g)\n", e0, e1, e2);
+        std::exit(-1);
+    }
+    s.u = uvs[0]; s.v = uvs[1]; s.scale = uvs[2];
+    s.num_samples = SLRHIP_UPSAMPLING_SAMPLES;
+    s.reserved = numPoints;
+    return addSpectrum(s, payload.data(), (uint32_t)payload.size());
+}
+uint32_t Scene::addRegularSpectrum(float lambdaMin, float lambdaMax, const float* values, uint32_t numSamples, const float rgb[3]) {
+    slrhip_spectrum s;
+    std::memset(&s, 0, sizeof(s));
+    s.kind = SLRHIP_SPECTRUM_REGULAR;
+    s.lambda_min = lambdaMin; s.lambda_max = lambdaMax; s.num_samples = numSamples;
+    for (int i = 0; i < 3; ++i) s.rgb[i] = rgb[i];
+    return addSpectrum(s, values, numSamples);
+}
+uint32_t Scene::addIrregularSpectrum(const float* lambdas, const float* values, uint32_t numSamples, const float rgb[3]) {
+    slrhip_spectrum s;
+    std::memset(&s, 0, sizeof(s));
+    s.kind = SLRHIP_SPECTRUM_IRREGULAR;
+    s.num_samples = numSamples;
+    for (int i = 0; i < 3; ++i) s.rgb[i] = rgb[i];
+    std::vector<float> payload(lambdas, lambdas + numSamples);
+    payload.insert(payload.end(), values, values + numSamples);
+    return addSpectrum(s, payload.data(), (uint32_t)payload.size());
+}
+uint32_t Scene::addD65Spectrum(float scale, const float rgb[3]) {
+    if (!m_hasTables) { std::fprintf(stderr, "SLRHip: addD65Spectrum needs loadSpectralTables()\n"); std::exit(-1); }
+    std::vector<float> v(m_d65);
+    for (float& x : v) x = scale * x;                  // RegularContinuousSpectrum::createScaled, SpectrumTypes.h:112-118
+    const float scaled[3] = {scale * rgb[0], scale * rgb[1], scale * rgb[2]};
+    return addRegularSpectrum(300.0f, 830.0f, v.data(), (uint32_t)v.size(), scaled);
+}
 
 uint32_t Scene::addVertex(const float position[3], const float normal[3], const float tangent[3], const float texcoord[2]) {
     slrhip_vertex v;
@@ -71,6 +145,7 @@ slrhip_scene_desc Scene::desc() const {
     d.spectrum_data = m_spectrumData.data(); d.num_spectrum_data = (uint32_t)m_spectrumData.size();
     d.camera = m_camera;
     d.env = nullptr;
+    d.upsampling = m_hasTables ? &m_tables : nullptr;
     if (m_hasEnv) {
         // the descriptor points into this object: valid as long as the Scene is
         const_cast<Scene*>(this)->m_env.texels = m_envTexels.data();

@@ -44,8 +44,26 @@ class Scene {
     std::vector<float> m_envTexels, m_envImportance;
     slrhip_envmap m_env;
     bool m_hasEnv = false;
+    // the Meng-15 upsampling grid and the D65 table (slr_amd/data/upsampling_tables.bin), needed to build spectral-mode spectra
+    std::vector<uint8_t> m_gridCells;
+    std::vector<float> m_pointUV, m_pointSpectrum, m_d65;
+    slrhip_upsampling_tables m_tables;
+    bool m_hasTables = false;
 public:
     Scene();
+    // Loads the tables the spectral build of the reference compiles in (BasicTypes/Spectrum.h:197-575, common_spectra.h:49-55).
+    // Returns false (and prints to stderr) if the file is missing or malformed.
+    bool loadSpectralTables(const std::string& path);
+    // `Spectrum(spType, space, e0, e1, e2)` of the scene language (libSLRSceneGraph/API.cpp:286-441): in the spectral build an
+    // UpsampledContinuousSpectrum (SpectrumTypes.h:180-237; its (u, v) cell look-up resolved here, slrhip_resolve_upsampled), in
+    // the RGB build the (de-gamma'd) triple.  One record serves both modes.  Needs loadSpectralTables().
+    uint32_t addUpsampledSpectrum(int32_t spectrumType, int32_t colorSpace, float e0, float e1, float e2);
+    // `Spectrum("ID": "D65") * scale` (API.cpp:405-406,443-462): RegularContinuousSpectrum 300-830 nm, 531 samples; `rgb` = its
+    // RGB-build value (the caller's conversion: API.cpp:1149-1214).  Needs loadSpectralTables().
+    uint32_t addD65Spectrum(float scale, const float rgb[3]);
+    // RegularContinuousSpectrum / IrregularContinuousSpectrum from the caller's samples (refractive-index tables, API.cpp:420-441)
+    uint32_t addRegularSpectrum(float lambdaMin, float lambdaMax, const float* values, uint32_t numSamples, const float rgb[3]);
+    uint32_t addIrregularSpectrum(const float* lambdas, const float* values, uint32_t numSamples, const float rgb[3]);
     uint32_t addVertex(const float position[3], const float normal[3], const float tangent[3], const float texcoord[2]);
     uint32_t addTriangle(uint32_t v0, uint32_t v1, uint32_t v2, uint32_t material);
     uint32_t addSpectrumRGB(float r, float g, float b);

@@ -1,11 +1,14 @@
 // cornell_main.cpp — a libSLR-style host program (cf. HostProgram/main.cpp:20-62) on the HIP renderer:
 // builds the Cornell-box walls + light of TestScenes/Cornell_Box_Spheres.txt:8-107 in C++, fills RenderSettings
 // like main.cpp:51-57 and calls renderer->render(scene, settings).
-//   usage: cornell_main [spp] [width] [height] [outdir]
+//   usage: cornell_main [spp] [width] [height] [outdir] [rgb|spectral] [tables.bin]
+// In "spectral" mode the same scene is built from the scene language's spectra — Spectrum(r, g, b) = an upsampled reflectance,
+// Spectrum("ID": "D65") * 4 = a regular spectrum — entirely in C++ (SLRHip::Scene::addUpsampledSpectrum / addD65Spectrum).
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <memory>
+#include <string>
 
 #include "SLRHip.h"
 
@@ -25,13 +28,20 @@ int main(int argc, char** argv) {
     const uint32_t spp = argc > 1 ? (uint32_t)std::atoi(argv[1]) : 16;
     const int width = argc > 2 ? std::atoi(argv[2]) : 256, height = argc > 3 ? std::atoi(argv[3]) : 192;
     const char* outdir = argc > 4 ? argv[4] : ".";
+    const bool spectral = argc > 5 && std::string(argv[5]) == "spectral";
     Scene scene;
+    if (spectral && !scene.loadSpectralTables(argc > 6 ? argv[6] : "slr_amd/data/upsampling_tables.bin")) return -1;
+    auto reflectance = [&](float r, float g, float b) {
+        return spectral ? scene.addUpsampledSpectrum(SLRHIP_SPECTRUMTYPE_REFLECTANCE, SLRHIP_COLORSPACE_SRGB_NONLINEAR, r, g, b)
+                        : scene.addSpectrumRGB(degamma(r), degamma(g), degamma(b));
+    };
     auto matte = [&](float r, float g, float b) {
-        return scene.addMaterial(SLRHIP_MATERIAL_MATTE, (int32_t)scene.addSpectrumRGB(degamma(r), degamma(g), degamma(b)), -1, -1, -1.0f, -1);
+        return scene.addMaterial(SLRHIP_MATERIAL_MATTE, (int32_t)reflectance(r, g, b), -1, -1, -1.0f, -1);
     };
     const uint32_t red = matte(0.75f, 0.25f, 0.25f), blue = matte(0.25f, 0.25f, 0.75f), white = matte(0.75f, 0.75f, 0.75f);
-    const uint32_t light = scene.addMaterial(SLRHIP_MATERIAL_MATTE, (int32_t)scene.addSpectrumRGB(degamma(0.9f), degamma(0.9f), degamma(0.9f)),
-                                             -1, -1, -1.0f, (int32_t)scene.addSpectrumRGB(400.0f, 400.0f, 400.0f));
+    const float d65rgb[3] = {100.0f, 100.0f, 100.0f};
+    const uint32_t emit = spectral ? scene.addD65Spectrum(4.0f, d65rgb) : scene.addSpectrumRGB(400.0f, 400.0f, 400.0f);
+    const uint32_t light = scene.addMaterial(SLRHIP_MATERIAL_MATTE, (int32_t)reflectance(0.9f, 0.9f, 0.9f), -1, -1, -1.0f, (int32_t)emit);
     const float L[4][3] = {{-1.5f, 0, 2.55f}, {-1.5f, 0, -2.55f}, {-1.5f, 2.5f, -2.55f}, {-1.5f, 2.5f, 2.55f}};
     const float R[4][3] = {{1.5f, 0, -2.55f}, {1.5f, 0, 2.55f}, {1.5f, 2.5f, 2.55f}, {1.5f, 2.5f, -2.55f}};
     const float F[4][3] = {{-1.5f, 0, 2.55f}, {1.5f, 0, 2.55f}, {1.5f, 0, -2.55f}, {-1.5f, 0, -2.55f}};
@@ -69,7 +79,7 @@ int main(int argc, char** argv) {
     settings.addItem(RenderSettingItem::Brightness, 1.0f);
     settings.addItem(RenderSettingItem::RNGSeed, (int32_t)1509761209);
 
-    std::unique_ptr<Renderer> renderer(new PathTracingRenderer(spp, 0, outdir));
+    std::unique_ptr<Renderer> renderer(new PathTracingRenderer(spp, 0, outdir, spectral ? SLRHIP_MODE_SPECTRAL : SLRHIP_MODE_RGB));
     renderer->render(scene, settings);
     return 0;
 }

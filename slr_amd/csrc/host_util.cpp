@@ -19,9 +19,116 @@ inline float sRGBGamma(float value) {
     return (float)(1.055 * std::pow((double)value, 1.0 / 2.4) - 0.055);
 }
 
+// sRGB_degamma, BasicTypes/Spectrum.cpp:24-30 (float instantiation; literals are double)
+inline float sRGBDegamma(float value) {
+    if (value <= 0.04045) return (float)(value / 12.92);
+    return (float)std::pow((value + 0.055) / 1.055, 2.4);
+}
+
 } // namespace
 
 extern "C" {
+
+// UpsampledContinuousSpectrumTemplate<float, N> constructor (BasicTypes/SpectrumTypes.h:180-237): the colour-space cascade
+// (non-linear sRGB -> sRGB -> XYZ -> xy + brightness), then Upsampling::xy_to_uv (Spectrum.h:136-139).  Double literals in
+// float expressions are evaluated in double and stored as float, as the reference's template instantiation does.
+int slrhip_upsample(int32_t spectrumType, int32_t colorSpace, float e0, float e1, float e2, float uvs[3]) {
+    if (!uvs) return SLRHIP_ERR_INVALID_ARGUMENT;
+    float x = 0.0f, y = 0.0f, brightness = 0.0f;
+    switch (colorSpace) {
+    case SLRHIP_COLORSPACE_SRGB_NONLINEAR:
+        e0 = sRGBDegamma(e0); e1 = sRGBDegamma(e1); e2 = sRGBDegamma(e2);
+        /* fall through */
+    case SLRHIP_COLORSPACE_SRGB: {
+        float X, Y, Z;
+        if (spectrumType == SLRHIP_SPECTRUMTYPE_REFLECTANCE) {            // sRGB_E_to_XYZ, Spectrum.h:66-71
+            X = (float)(0.4969 * e0 + 0.3391 * e1 + 0.1640 * e2);
+            Y = (float)(0.2562 * e0 + 0.6782 * e1 + 0.0656 * e2);
+            Z = (float)(0.0233 * e0 + 0.1130 * e1 + 0.8637 * e2);
+        }
+        else if (spectrumType == SLRHIP_SPECTRUMTYPE_ILLUMINANT) {        // sRGB_to_XYZ, Spectrum.h:53-57
+            X = (float)(0.4124564 * e0 + 0.3575761 * e1 + 0.1804375 * e2);
+            Y = (float)(0.2126729 * e0 + 0.7151522 * e1 + 0.0721750 * e2);
+            Z = (float)(0.0193339 * e0 + 0.1191920 * e1 + 0.9503041 * e2);
+        }
+        else return SLRHIP_ERR_INVALID_ARGUMENT;                            // SLRAssert(false, "Invalid Spectrum Type")
+        e0 = X; e1 = Y; e2 = Z;
+    }   /* fall through */
+    case SLRHIP_COLORSPACE_XYZ:
+        brightness = e0 + e1 + e2;
+        if (brightness == 0) { uvs[0] = 6; uvs[1] = 4; uvs[2] = 0; return SLRHIP_OK; }
+        x = e0 / brightness;
+        y = e1 / brightness;
+        break;
+    case SLRHIP_COLORSPACE_XYY:
+        x = e0; y = e1;
+        brightness = e2 / e1;
+        break;
+    default:
+        return SLRHIP_ERR_INVALID_ARGUMENT;
+    }
+    uvs[2] = brightness / 0.009355121400914532f;                            // Upsampling::EqualEnergyReflectance
+    uvs[0] = (float)(16.730260708356887 * x + 7.7801960340706 * y - 2.170152247475828);
+    uvs[1] = (float)(-7.530081094743006 * x + 16.192422314095225 * y + 1.1125529268825947);
+    return SLRHIP_OK;
+}
+
+// The part of UpsampledContinuousSpectrumTemplate::evaluate that depends on (u, v) only (SpectrumTypes.h:241-312): the grid
+// cell, the 3 or 4 data points it interpolates and their weights.  Writes the payload slrhip_spectrum (kind UPSAMPLED)
+// carries: 4 weights, then SLRHIP_UPSAMPLING_SAMPLES records of 4 floats = the data points' spectra interleaved per bin.
+int slrhip_resolve_upsampled(const slrhip_upsampling_tables* t, float u, float v, uint32_t* numPointsOut, float* payload) {
+    if (!t || !t->cells || !t->point_uv || !t->point_spectrum || !numPointsOut || !payload || t->grid_width == 0 || t->grid_height == 0)
+        return SLRHIP_ERR_INVALID_ARGUMENT;
+    const uint32_t nw = SLRHIP_UPSAMPLING_SAMPLES;
+    std::memset(payload, 0, sizeof(float) * (4 + 4 * nw));
+    *numPointsOut = 0;
+    if (u < 0.0f || u >= (float)t->grid_width || v < 0.0f || v >= (float)t->grid_height) return SLRHIP_OK;    // evaluates to zero
+    const int32_t ui = (int32_t)u, vi = (int32_t)v;
+    const uint8_t* cell = t->cells + (size_t)(ui + (int32_t)t->grid_width * vi) * 8;
+    const uint32_t inside = cell[0], numPoints = cell[1];
+    const uint8_t* idx = cell + 2;
+    if (numPoints > 6) return SLRHIP_ERR_INVALID_ARGUMENT;
+    for (uint32_t k = 0; k < (inside ? 4u : numPoints); ++k)
+        if (idx[k] >= t->num_points) return SLRHIP_ERR_INVALID_ARGUMENT;
+    uint32_t used[4] = {0, 0, 0, 0};
+    uint32_t n = 0;
+    float* w = payload;
+    if (inside) {
+        const float s = u - (float)ui, tt = v - (float)vi;
+        w[0] = (1 - s) * (1 - tt); w[1] = s * (1 - tt); w[2] = (1 - s) * tt; w[3] = s * tt;
+        for (int k = 0; k < 4; ++k) used[k] = idx[k];
+        n = 4;
+    }
+    else if (numPoints >= 2) {
+        const float* uv = t->point_uv;
+        const float p0x = uv[2 * idx[0]], p0y = uv[2 * idx[0] + 1];
+        const float ex = u - p0x, ey = v - p0y;
+        float e0x = uv[2 * idx[1]] - p0x, e0y = uv[2 * idx[1] + 1] - p0y;
+        float uu = e0x * ey - ex * e0y;
+        for (uint32_t i = 1; i < numPoints; ++i) {
+            const uint32_t j = idx[i % (numPoints - 1) + 1];
+            const float e1x = uv[2 * j] - p0x, e1y = uv[2 * j + 1] - p0y;
+            const float vv = ex * e1y - e1x * ey;
+            const float area = e0x * e1y - e1x * e0y;
+            const float bu = uu / area, bv = vv / area;
+            const float bw = 1.0f - bu - bv;
+            if ((double)bu < -1e-6 || (double)bv < -1e-6 || (double)bw < -1e-6) {
+                uu = -vv;
+                e0x = e1x;
+                e0y = e1y;
+                continue;
+            }
+            w[0] = bu; w[1] = bv; w[2] = bw;
+            used[0] = j; used[1] = idx[i]; used[2] = idx[0];
+            n = 3;
+            break;
+        }
+    }
+    *numPointsOut = n;
+    for (uint32_t k = 0; k < n; ++k)
+        for (uint32_t b = 0; b < nw; ++b) payload[4 + 4 * b + k] = t->point_spectrum[(size_t)used[k] * nw + b];
+    return SLRHIP_OK;
+}
 
 // One xorshift128 stream per (pixel, sample): the reference has one stream per worker thread
 // (PathTracingRenderer.cpp:33-38), which is neither reproducible nor parallel; this hash is the

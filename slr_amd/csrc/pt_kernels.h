@@ -105,6 +105,10 @@ struct PathBuffers {
     uint32_t* regenQueue;         // same layout: slots whose path ended (accumulate pixel, start next sample)
     uint32_t* queueCount;         // [parity][kind][shard], see queueCounterIndex
     uint32_t* activeSlots;        // slots that still have samples to do
+    // one word per block of 256 consecutive slots: set by k_logic once every slot of the block has run out of passes (a slot
+    // never leaves ST_IDLE within a render call), cleared by k_reset_slots; the scanning kernels skip such blocks without
+    // touching their state — the last iterations of a render, in which a few long paths are left, then cost launch overhead
+    uint32_t* blockDead;
     uint32_t* errorWord;          // ERR_* bits, sticky until the next slrhip_render call; read back with activeSlots
     uint64_t* totals;             // [kind][shard], see totalIndex
     const uint32_t* pixelXY;      // pixel-of-shard -> x | y << 16

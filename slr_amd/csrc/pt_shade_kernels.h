@@ -420,6 +420,30 @@ __global__ __launch_bounds__(kShadeBlock)
 __attribute__((amdgpu_waves_per_eu(S::N == 3 ? SLR_WAVES_RGB : (MF ? SLR_WAVES_SPECTRAL_GLOSSY : SLR_WAVES_SPECTRAL)))) void k_logic(DevScene sc, PathBuffers pb, RenderParams rp, uint32_t parity) {
     __shared__ ShadeLds<S::N != 3> lds;
     __shared__ PushLds pushLds;
+    // S::LANES adjacent lanes share one slot (SpecQ: 4, each holding a quarter of the spectrum; the per-path scalar work is
+    // replicated, identically, in all of them); the first of them ("leader") writes the scalar state and the queue entries
+    constexpr uint32_t L = S::LANES;
+    const uint32_t slot = (blockIdx.x * kShadeBlock + threadIdx.x) / L;
+    const bool leader = L == 1 || (threadIdx.x & (L - 1)) == 0;
+
+    // ---- the end of a render: nothing left anywhere / nothing left in this block ------------------------------------------
+    if (pb.activeSlots[0] == 0) return;                                   // every slot is out of passes (uniform)
+    const uint32_t deadIdx = (blockIdx.x * kShadeBlock / L) / kShadeBlock;   // 256-slot block of this workgroup's first slot
+    if (pb.blockDead[deadIdx]) return;
+    uint32_t flags = slot < rp.numSlots ? pb.flags[slot] : (uint32_t)ST_IDLE;
+    {
+        const uint32_t st = F_STATE(flags);
+        // the stripe-0 slots of a pixel retire the pixel's sample-pool mask whether or not they have a path themselves
+        const bool poolDuty = blockIdx.x * kShadeBlock / L < rp.numPixels;
+        const int anyPath = __syncthreads_or(st == ST_FIRST_HIT || st == ST_NEXT_HIT || st == ST_FINISH);
+        if (!anyPath && !poolDuty) {
+            // no path to advance here (slots waiting in the regen queue are not this kernel's).  If all of them are idle the
+            // block is finished for the rest of this render call: say so, and the scanning kernels stop reading its state.
+            const int anyBusy = __syncthreads_or(st != ST_IDLE);
+            if (L == 1 && !anyBusy && threadIdx.x == 0) pb.blockDead[deadIdx] = 1u;
+            return;
+        }
+    }
     if (LDS_TABLES) {
         if (S::N == 3) {
             const float4* gm = reinterpret_cast<const float4*>(sc.materials);
@@ -442,11 +466,6 @@ __attribute__((amdgpu_waves_per_eu(S::N == 3 ? SLR_WAVES_RGB : (MF ? SLR_WAVES_S
     const float* lightPMF = LDS_TABLES ? lds.lightPMF : sc.lightPMF;
     const float* lightCDF = LDS_TABLES ? lds.lightCDF : sc.lightCDF;
 
-    // S::LANES adjacent lanes share one slot (SpecQ: 4, each holding a quarter of the spectrum; the per-path scalar work is
-    // replicated, identically, in all of them); the first of them ("leader") writes the scalar state and the queue entries
-    constexpr uint32_t L = S::LANES;
-    const uint32_t slot = (blockIdx.x * kShadeBlock + threadIdx.x) / L;
-    const bool leader = L == 1 || (threadIdx.x & (L - 1)) == 0;
     bool emitExt = false, emitShadow = false, emitRegen = false;
     uint32_t* qw = pb.queueCount + (parity ^ 1) * kQueueSetWords;
 
@@ -462,8 +481,7 @@ __attribute__((amdgpu_waves_per_eu(S::N == 3 ? SLR_WAVES_RGB : (MF ? SLR_WAVES_S
     }
 
     if (slot < rp.numSlots) {
-        // ---- all state loads up front: one memory round trip instead of a dependent chain -----------
-        uint32_t flags = pb.flags[slot];
+        // ---- all state loads up front: one memory round trip instead of a dependent chain (flags: read above) -----------
         const uint4 r4 = pb.rng[slot];
         // The path's radiance sum (Kahan pair) and the pending light sample: RGB keeps them in registers (3 x 16 B,
         // requested with everything else); in spectral mode they are 3 x 64 B that most visits never touch, so they
@@ -809,6 +827,7 @@ __device__ __forceinline__ Spec16 storageAddend(const Spec16& val, float wlOffse
 
 template <class S>
 __global__ __launch_bounds__(kShadeBlock) void k_regen(DevScene sc, PathBuffers pb, RenderParams rp, uint32_t parity) {
+    if (pb.activeSlots[0] == 0) return;            // every slot is out of passes: the remaining launches of this block of iterations are no-ops
     const uint32_t shard = blockIdx.x % kShards;
     const uint32_t n = pb.queueCount[queueCounterIndex(parity, Q_REGEN, shard)];
     const uint32_t i = (blockIdx.x / kShards) * kShadeBlock + threadIdx.x;
@@ -915,6 +934,7 @@ __global__ void k_reset_slots(PathBuffers pb, RenderParams rp, uint32_t clearAcc
             pb.finishedMask[(size_t)rp.numPixels + slot] = 0ull;
         }
         pb.visible[slot] = 0;
+        if (threadIdx.x == 0) pb.blockDead[blockIdx.x] = 0u;
         // slot block b goes to region b % kShards at chunk b / kShards, exactly as k_logic would append it
         pb.regenQueue[(size_t)(blockIdx.x % kShards) * rp.shardCapacity + (blockIdx.x / kShards) * kShadeBlock + threadIdx.x] = slot;
         if (clearAccumulators) {

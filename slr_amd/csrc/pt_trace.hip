@@ -174,6 +174,7 @@ template <bool COUNT>
 __global__ __launch_bounds__(kTraceBlock) void k_trace_closest(DevScene sc, PathBuffers pb, uint32_t numSlots, uint32_t parity) {
     __shared__ TraceLds lds;
     __shared__ uint32_t red[4];
+    if (pb.activeSlots[0] == 0) return;            // every slot is out of passes (uniform)
     if (blockIdx.x == 0 && threadIdx.x < Q_KINDS * kShards) {
         // clear the counter set the logic kernel of this iteration fills
         pb.queueCount[queueCounterIndex(parity ^ 1, threadIdx.x / kShards, threadIdx.x % kShards)] = 0;
@@ -204,6 +205,7 @@ template <bool COUNT>
 __global__ __launch_bounds__(kTraceBlock) void k_trace_shadow(DevScene sc, PathBuffers pb, uint32_t shardCapacity, uint32_t parity) {
     __shared__ TraceLds lds;
     __shared__ uint32_t red[4];
+    if (pb.activeSlots[0] == 0) return;
     const uint32_t shard = blockIdx.x % kShards;
     const uint32_t n = pb.queueCount[queueCounterIndex(parity, Q_SHADOW, shard)];
     const uint32_t numTop = stageTopNodes(sc, lds);

@@ -276,6 +276,8 @@ __device__ __forceinline__ void wsConsume(const DevScene& sc, const PathBuffers&
                 // slab test of QBVH::Node::intersect (QBVH.h:55-76): tNear <= tFar.  (Tried: fma(plane, id, -(o * id)) on
                 // padded boxes, half the arithmetic — but for rays that start ON a surface the cancellation noise near t = 0
                 // admits the boxes around the origin: 3x the triangle tests for shadow rays, 4x slower on the 10 M grid.)
+                // (Tried in round 2: the 24 subtractions + 24 multiplications as packed fp32, v_pk_add_f32 / v_pk_mul_f32 — same
+                // roundings, 110 -> 87 VALU in this block — measured 23 % SLOWER per launch: 1.55 -> 1.90 ms at 22 M slots.)
                 const float tn0 = fmaxf(fmaxf((nX.x - ox) * idx, (nY.x - oy) * idy), fmaxf((nZ.x - oz) * idz, tmin));
                 const float tn1 = fmaxf(fmaxf((nX.y - ox) * idx, (nY.y - oy) * idy), fmaxf((nZ.y - oz) * idz, tmin));
                 const float tn2 = fmaxf(fmaxf((nX.z - ox) * idx, (nY.z - oy) * idy), fmaxf((nZ.z - oz) * idz, tmin));
@@ -402,6 +404,7 @@ __device__ __forceinline__ void wsConsume(const DevScene& sc, const PathBuffers&
 template <bool COUNT, int NC, bool QUANT>
 __global__ __launch_bounds__(64 * (NC + 1)) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_trace_ws(DevScene sc, PathBuffers pb, uint32_t numSlots, uint32_t shardCapacity, uint32_t parity, uint32_t refill) {
     __shared__ WsLds<NC> lds;
+    if (pb.activeSlots[0] == 0) return;            // every slot is out of passes (uniform): nothing to trace
     if (blockIdx.x == 0 && threadIdx.x < Q_KINDS * kShards) {
         // clear the counter set the logic kernel of this iteration fills
         pb.queueCount[queueCounterIndex(parity ^ 1, threadIdx.x / kShards, threadIdx.x % kShards)] = 0;
@@ -420,15 +423,25 @@ __global__ __launch_bounds__(64 * (NC + 1)) __attribute__((amdgpu_waves_per_eu(8
             // The state flags of kAhead chunks are fetched in one round trip, the ray records only for chunks that have a ray:
             // near the end of a render most slots are idle, and a producer that pays one memory round trip per 128 slots
             // whether or not they hold a ray makes an almost empty launch last ~58 us (28 dependent round trips per workgroup).
+            // Blocks of 256 slots whose slots have all run out of passes are marked by k_logic (PathBuffers::blockDead): their
+            // state is not read at all.  One 64-lane load fetches the marks of this workgroup's next 64 chunks.
             const uint32_t numChunks = (numSlots + chunk - 1) / chunk;
-            for (uint32_t c0 = blockIdx.x; ok && c0 < numChunks; c0 += gridDim.x * kAhead) {
+            uint64_t deadMask = 0;
+            uint32_t group = 0;
+            for (uint32_t c0 = blockIdx.x; ok && c0 < numChunks; c0 += gridDim.x * kAhead, group += kAhead) {
+                if ((group & 63u) == 0) {
+                    const uint64_t cl = (uint64_t)c0 + (uint64_t)lane * gridDim.x;       // this lane's chunk among the next 64
+                    deadMask = __ballot(cl >= numChunks || pb.blockDead[(cl * chunk) / 256u] != 0u);
+                }
+                const uint32_t deadBits = (uint32_t)(deadMask >> (group & 63u)) & ((1u << kAhead) - 1u);
+                if (deadBits == (1u << kAhead) - 1u) continue;                            // wave-uniform
                 uint32_t fl[kAhead][kSub];
 #pragma unroll
                 for (int a = 0; a < kAhead; ++a)
 #pragma unroll
                     for (int j = 0; j < kSub; ++j) {
                         const uint64_t s = (uint64_t)(c0 + a * gridDim.x) * chunk + j * 64 + lane;
-                        fl[a][j] = s < numSlots ? __builtin_nontemporal_load(&pb.flags[s]) : 0u;
+                        fl[a][j] = (s < numSlots && !((deadBits >> a) & 1u)) ? __builtin_nontemporal_load(&pb.flags[s]) : 0u;
                     }
 #pragma unroll
                 for (int a = 0; a < kAhead; ++a) {

@@ -136,7 +136,7 @@ struct slrhip_ctx {
     DevArray<uint4> hdr;
     DevArray<unsigned long long> finishedMask;
     DevArray<uint32_t> nextSample;
-    DevArray<uint32_t> flags, visible, shadowQueue, regenQueue, queueCount, activeSlots;
+    DevArray<uint32_t> flags, visible, shadowQueue, regenQueue, queueCount, activeSlots, blockDead;
     DevArray<uint64_t> totals;
     DevArray<float> resolveScratch;
     PathBuffers buffers;
@@ -469,7 +469,8 @@ int slrhip_upload_scene(slrhip_ctx* ctx, const slrhip_scene_desc* d) {
     HIP_TRY(ctx->nodes.upload(bvh.nodes));
     // trees beyond the L2 (>= 64 Ki nodes = 8 MiB) are also stored with 8-bit child boxes: half the bytes per node visit
     static const bool noQuant = [] { const char* e = getenv("SLRHIP_QUANT"); return e && std::string(e) == "0"; }();
-    const bool quant = bvh.nodes.size() >= 65536 && !noQuant;
+    static const bool forceQuant = [] { const char* e = getenv("SLRHIP_QUANT"); return e && std::string(e) == "1"; }();   // experiment: small trees too
+    const bool quant = (bvh.nodes.size() >= 65536 || forceQuant) && !noQuant;
     if (quant) { quantizeNodes(&bvh); HIP_TRY(ctx->nodesQ.upload(bvh.quantized)); }
     HIP_TRY(ctx->leafTris.upload(bvh.leafTris));
     HIP_TRY(ctx->shadeTris.upload(shade));
@@ -620,6 +621,7 @@ int slrhip_render_begin(slrhip_ctx* ctx, const slrhip_render_settings* st, slrhi
     const uint32_t numBlocks = (uint32_t)((numSlots + 255) / 256);
     const uint32_t shardCapacity = ((numBlocks + kShards - 1) / kShards) * 256;
     HIP_TRY(ctx->shadowQueue.alloc((size_t)shardCapacity * kShards, true)); HIP_TRY(ctx->regenQueue.alloc((size_t)shardCapacity * kShards, true));
+    HIP_TRY(ctx->blockDead.alloc(numBlocks));
     HIP_TRY(ctx->queueCount.alloc(2 * kQueueSetWords)); HIP_TRY(ctx->activeSlots.alloc(2));      // [0] live slots, [1] device error word
     HIP_TRY(ctx->totals.alloc((size_t)T_KINDS * kShards * kTotalStride));
     // The statistics restart here.  A memset of device memory is only ordered on the null stream, and slrhip_render may be
@@ -638,7 +640,7 @@ int slrhip_render_begin(slrhip_ctx* ctx, const slrhip_render_settings* st, slrhi
     pb.nee = ctx->nee.ptr;
     pb.pdfPrev = spectral ? ctx->pdfPrev.ptr : nullptr; pb.hdr = ctx->hdr.ptr; pb.finishedMask = ctx->finishedMask.ptr; pb.nextSample = ctx->nextSample.ptr; pb.shadowDir = ctx->shadowDir.ptr; pb.flags = ctx->flags.ptr;
     pb.visible = ctx->visible.ptr; pb.shadowQueue = ctx->shadowQueue.ptr; pb.regenQueue = ctx->regenQueue.ptr;
-    pb.queueCount = ctx->queueCount.ptr; pb.activeSlots = ctx->activeSlots.ptr; pb.errorWord = ctx->activeSlots.ptr + 1; pb.totals = ctx->totals.ptr;
+    pb.queueCount = ctx->queueCount.ptr; pb.activeSlots = ctx->activeSlots.ptr; pb.errorWord = ctx->activeSlots.ptr + 1; pb.blockDead = ctx->blockDead.ptr; pb.totals = ctx->totals.ptr;
     pb.pixelXY = ctx->pixelXY.ptr;
 
     RenderParams& rp = ctx->params;

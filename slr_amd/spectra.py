@@ -97,6 +97,8 @@ def resolve_upsampled(u, v):
         w[2] = F(one - s) * tt
         w[3] = s * tt
         return 4, w, [int(idx[0]), int(idx[1]), int(idx[2]), int(idx[3])]
+    if num_points < 2:                     # a cell outside the gamut's hull: no data point, the spectrum evaluates to zero
+        return 0, w, [0, 0, 0, 0]
     uv = t["point_uv"]
     p0 = uv[idx[0]]
     ex, ey = F(u - p0[0]), F(v - p0[1])

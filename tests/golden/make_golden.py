@@ -229,6 +229,26 @@ def main_round2(only):
     lib = ob.load("ref_rgb")
     if not only or "spectral_boxes" in only:
         make("spectral_boxes", scenes.cornell_box_boxes(1.0), spec, 48, 48, 8, 2)
+    if not only or "upsample_kat" in only:
+        # UpsampledContinuousSpectrum(spType, space, e0, e1, e2) of the compiled reference: (u, v, scale) for every colour space
+        import ctypes as C
+        up = spec.lib.slr_ref_upsample
+        up.argtypes = [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p]
+        rng = np.random.default_rng(2718)
+        rows = []
+        for i in range(768):
+            spt, space = int(rng.integers(0, 2)), int(rng.integers(0, 4))
+            e = rng.random(3).astype(np.float32)
+            if space == 2:
+                e[:2] = (0.2 + 0.4 * e[:2]).astype(np.float32)          # xyY: chromaticities inside the gamut
+            if i < 8:
+                e[:] = [(0, 0, 0), (1, 1, 1), (0.04045, 0.04045, 0.04045), (1, 0, 0), (0, 1, 0), (0, 0, 1), (0.5, 0.5, 0.5), (0.75, 0.25, 0.25)][i]
+                space = 1 if i != 0 else 3
+            out = np.zeros(3, np.float32)
+            assert up(spt, space, float(e[0]), float(e[1]), float(e[2]), out.ctypes.data) == 0
+            rows.append([spt, space, e[0], e[1], e[2], out[0], out[1], out[2]])
+        np.savez_compressed(os.path.join(HERE, "upsample_kat.npz"), rows=np.array(rows, np.float32))
+        print("upsample_kat", len(rows))
     if not only or "rgb_grid400" in only:
         make_procedural("rgb_grid400", "displaced_grid", (400, 16.0 / 9.0), lib, 160, 90, 8)
 

@@ -84,3 +84,37 @@ def test_tonemap_and_bmp_match_reference_saveimage(lib, name):
     assert (mine[:54] == ref[:54]).all()                          # headers
     a, b = mine[54:].reshape(h, byte_width)[:, :3 * w], ref[54:].reshape(h, byte_width)[:, :3 * w]
     assert (a == b).all(), "%d of %d pixel bytes differ" % ((a != b).sum(), a.size)
+
+
+def test_cpp_spectrum_construction_matches_the_reference_and_the_python_host(lib):
+    """slrhip_upsample / slrhip_resolve_upsampled (the C++ host's construction of spectral-mode spectra) against the compiled
+    reference's UpsampledContinuousSpectrum constructor (tests/golden/upsample_kat.npz: (u, v, scale) for 768 inputs over both
+    spectrum types and all four colour spaces, SpectrumTypes.h:180-237), and against slr_amd/spectra.py, whose payloads the
+    GPU parity tests render with: every float bit-equal."""
+    from helpers import assert_bit_equal
+    from slr_amd import spectra
+    g = load_golden("upsample_kat")["rows"]
+    for row in g:
+        out = np.zeros(3, np.float32)
+        assert lib.slrhip_upsample(int(row[0]), int(row[1]), C.c_float(row[2]), C.c_float(row[3]), C.c_float(row[4]), out.ctypes.data) == 0
+        assert_bit_equal(out, row[5:8], "slrhip_upsample %s" % row[:5])
+        assert_bit_equal(np.array(spectra.upsample(int(row[0]), int(row[1]), row[2], row[3], row[4]), np.float32), row[5:8], "spectra.upsample")
+    assert lib.slrhip_upsample(2, 0, C.c_float(0.5), C.c_float(0.5), C.c_float(0.5), np.zeros(3, np.float32).ctypes.data) == 1   # IOR from sRGB: the reference asserts
+    # the (u, v)-only half of evaluate(): cell, data points, weights and the interleaved payload
+    holder = type("T", (), {"_tables": None})()          # keeps the table arrays alive
+    sc_tables = abi.Scene.upsampling_tables(holder)
+    rng = np.random.default_rng(5)
+    uvs = np.concatenate([g[:, 5:7], rng.uniform(-1, 15, (512, 2)).astype(np.float32)])
+    kinds = set()
+    for u, v in uvs:
+        n = C.c_uint32(0)
+        payload = np.full(4 + 4 * 95, -1.0, np.float32)
+        assert lib.slrhip_resolve_upsampled(C.byref(sc_tables), C.c_float(u), C.c_float(v), C.byref(n), payload.ctypes.data) == 0
+        pn, pw, pidx = spectra.resolve_upsampled(u, v)
+        assert n.value == pn
+        kinds.add(pn)
+        assert_bit_equal(payload[:4], pw, "weights")
+        spec = spectra.tables()["point_spectrum"]
+        want = np.stack([spec[pidx[k]] if k < pn else np.zeros(95, np.float32) for k in range(4)], axis=1)
+        assert_bit_equal(payload[4:].reshape(95, 4), want, "payload")
+    assert kinds == {0, 3, 4}

@@ -70,6 +70,8 @@ def test_spectrum_construction_and_evaluation_bit_exact(oracle_spectral, ref_spe
     """a27 + a16: UpsampledContinuousSpectrum constructor (slr_amd/spectra.py) and the per-hit evaluation of all three kinds."""
     import ctypes as C
     from slr_amd import abi, spectra
+    from slr_amd import binding
+    hip_lib = binding.load_library()
     up = ref_spectral.lib.slr_ref_upsample
     up.argtypes = [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p]
     rng = np.random.default_rng(0)
@@ -79,6 +81,9 @@ def test_spectrum_construction_and_evaluation_bit_exact(oracle_spectral, ref_spe
         out = np.zeros(3, np.float32)
         assert up(spt, space, float(e[0]), float(e[1]), float(e[2]), out.ctypes.data) == 0
         assert_bit_equal(np.array(spectra.upsample(spt, space, *e), np.float32), out, "upsample")
+        mine = np.zeros(3, np.float32)            # the C++ host's constructor (include/slrhip.h)
+        assert hip_lib.slrhip_upsample(spt, space, C.c_float(e[0]), C.c_float(e[1]), C.c_float(e[2]), mine.ctypes.data) == 0
+        assert_bit_equal(mine, out, "slrhip_upsample")
     sc = scenes.cornell_box_spheres(1.0, 8, 4, "glass")
     d = sc.desc()
     fr, fo = ref_spectral.lib.slr_ref_eval_spectrum, oracle_spectral.lib.slr_oracle_eval_spectrum
