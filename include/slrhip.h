@@ -331,6 +331,15 @@ int slrhip_resolve_framebuffer(slrhip_ctx* ctx, float* device_dst, size_t num_fl
  * (ImageSensor.cpp:88-95).                                                                */
 int slrhip_read_framebuffer(slrhip_ctx* ctx, float* host_dst, size_t num_floats);
 
+/* The single exchange of the multi-GPU path: one process per GPU renders its tile shard (slrhip_render_begin's `shard`), then all
+ * ranks call this: the resolved frames (zeros outside a rank's tiles) are sum-reduced onto rank `root` with ONE ncclReduce over
+ * `nccl_comm` (an ncclComm_t of RCCL the caller created, e.g. ncclCommInitRank; the call is stream-ordered on `stream`).
+ * `device_dst` (DEVICE memory, num_floats >= width * height * components) receives the full image on `root`; other ranks may pass
+ * NULL.  The reference has no distributed path (one process, a thread pool over 8x8 tiles: PathTracingRenderer.cpp:72-81); this
+ * replaces "all tiles of the sensor are filled by this process" (ImageSensor.cpp:124-129) for a sensor spread over ranks.
+ * librccl.so is loaded on first use.                                                                                     */
+int slrhip_reduce_framebuffer(slrhip_ctx* ctx, void* nccl_comm, int root, float* device_dst, size_t num_floats, void* stream);
+
 int slrhip_synchronize(slrhip_ctx* ctx);
 int slrhip_get_counters(slrhip_ctx* ctx, slrhip_counters* out);
 int slrhip_components(const slrhip_ctx* ctx);   /* 3 or 16 */

@@ -50,6 +50,8 @@
 #include "SurfaceMaterials/basic_SurfaceMaterials.h"
 #include "Textures/constant_textures.h"
 
+#include "HIPPathTracingRenderer.h"     // slr_amd/csrc/libslr_adapter: the libSLR-side adapter of the HIP path
+
 using namespace SLR;
 
 // PathTracingRenderer::render sizes its pool from std::thread::hardware_concurrency()
@@ -655,6 +657,53 @@ int slr_ref_eval_spectrum(const slrhip_scene_desc* d, uint32_t index, float offs
     (void)d; (void)index; (void)offset; (void)out;
     return 3;
 #endif
+}
+
+// ---- the libSLR-side adapter (slr_amd/csrc/libslr_adapter), exercised on the reference's own Scene object ----------------
+// flatten(scene): returns a FlatScene handle (or null, message in slr_ref_flat_error); slr_ref_flat_desc fills a scene
+// description pointing into it.  The round-trip test builds a libSLR Scene from a flat description D (slr_ref_create) and
+// checks that flatten gives D back.
+static std::string g_flatError;
+const char* slr_ref_flat_error(void) { return g_flatError.c_str(); }
+void* slr_ref_flatten(slr_oracle_scene* s, const char* hipLibraryPath) {
+    FlatScene* flat = new FlatScene();
+    if (!s || !flattenSceneWithLibrary(s->scene, flat, &g_flatError, hipLibraryPath ? hipLibraryPath : "")) { delete flat; return nullptr; }
+    return flat;
+}
+void slr_ref_flat_desc(void* handle, slrhip_scene_desc* out) { *out = static_cast<FlatScene*>(handle)->desc(); }
+void slr_ref_flat_free(void* handle) { delete static_cast<FlatScene*>(handle); }
+
+// HIPPathTracingRenderer(spp).render(scene, settings) through the reference's Renderer vtable, exactly as
+// HostProgram/main.cpp:59 calls it; afterwards the camera's ImageSensor is read out like slr_ref_render_native does.
+int slr_ref_render_hip(slr_oracle_scene* s, const slrhip_render_settings* st, uint32_t spp, int device, const char* hipLibraryPath, float* fbSum) {
+    if (!s || !st || !fbSum) return 1;
+    RenderSettings settings;
+    settings.addItem(RenderSettingItem::ImageWidth, (int32_t)st->image_width);
+    settings.addItem(RenderSettingItem::ImageHeight, (int32_t)st->image_height);
+    settings.addItem(RenderSettingItem::TimeStart, st->time_start);
+    settings.addItem(RenderSettingItem::TimeEnd, st->time_end);
+    settings.addItem(RenderSettingItem::Brightness, st->brightness);
+    settings.addItem(RenderSettingItem::RNGSeed, (int32_t)st->rng_seed);
+    std::unique_ptr<Renderer> renderer(new HIPPathTracingRenderer(spp, device, hipLibraryPath ? hipLibraryPath : ""));
+    // render() writes NNN.bmp into the working directory, like the reference's own: run it in a scratch directory
+    char cwd[4096];
+    char tmpl[] = "/tmp/slr_ref_hip_XXXXXX";
+    if (!getcwd(cwd, sizeof(cwd)) || !mkdtemp(tmpl) || chdir(tmpl) != 0) return 4;
+    renderer->render(s->scene, settings);
+    if (chdir(cwd) != 0) return 4;
+    { std::string cmd = std::string("rm -rf ") + tmpl; if (system(cmd.c_str()) != 0) { /* scratch dir left behind */ } }
+    const ImageSensor* sensor = s->camera->getSensor();
+    for (int32_t y = 0; y < st->image_height; ++y)
+        for (int32_t x = 0; x < st->image_width; ++x) {
+            const DiscretizedSpectrum v = sensor->pixel((uint32_t)x, (uint32_t)y);
+            float* o = fbSum + ((size_t)y * st->image_width + x) * kComponents;
+#ifdef Use_Spectral_Representation
+            for (int i = 0; i < kComponents; ++i) o[i] = v.values[i];
+#else
+            o[0] = v.r; o[1] = v.g; o[2] = v.b;
+#endif
+        }
+    return 0;
 }
 
 int slr_ref_upsample(int spType, int space, float e0, float e1, float e2, float* uvs) {

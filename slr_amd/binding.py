@@ -12,7 +12,7 @@ CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(CSRC, "libslrhip.so")
 
 EXPORTS = ["slrhip_create", "slrhip_destroy", "slrhip_upload_scene", "slrhip_render_begin", "slrhip_render",
-           "slrhip_resolve_framebuffer", "slrhip_read_framebuffer", "slrhip_synchronize", "slrhip_get_counters",
+           "slrhip_resolve_framebuffer", "slrhip_reduce_framebuffer", "slrhip_read_framebuffer", "slrhip_synchronize", "slrhip_get_counters",
            "slrhip_components", "slrhip_get_profile", "slrhip_trace_rays", "slrhip_bsdf_queries", "slrhip_sample_seed", "slrhip_upsample", "slrhip_resolve_upsampled", "slrhip_tonemap_bgr8", "slrhip_save_bmp",
            "slrhip_last_error_string", "slrhip_version"]
 
@@ -46,6 +46,7 @@ def load_library():
     lib.slrhip_render_begin.argtypes = [C.c_void_p, C.POINTER(abi.RenderSettings), abi.Shard]
     lib.slrhip_render.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
     lib.slrhip_resolve_framebuffer.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.slrhip_reduce_framebuffer.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.slrhip_read_framebuffer.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     lib.slrhip_synchronize.argtypes = [C.c_void_p]
     lib.slrhip_get_counters.argtypes = [C.c_void_p, C.POINTER(abi.Counters)]

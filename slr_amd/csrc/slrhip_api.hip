@@ -7,6 +7,7 @@
 // flatten, build the 4-wide BVH, upload once, then drive the wavefront iterations.
 // There is no CPU fallback: without a HIP device every entry point fails loudly.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <atomic>
@@ -829,6 +830,32 @@ int slrhip_resolve_framebuffer(slrhip_ctx* ctx, float* deviceDst, size_t numFloa
     HIP_TRY(hipMemsetAsync(deviceDst, 0, need * sizeof(float), stream));
     if (rp.numPixels) launchResolve(ctx->buffers, rp, deviceDst, stream);
     HIP_TRY(hipGetLastError());
+    return SLRHIP_OK;
+}
+
+// The one exchange step of the multi-GPU path: every rank resolves its shard (zeros outside its tiles) and the
+// frames are summed onto `root` — disjoint supports, so the sum is a gather.  RCCL is loaded on first use (dlopen), so a
+// single-GPU host does not need librccl at all; the communicator is the caller's (one process per GPU, ncclCommInitRank).
+int slrhip_reduce_framebuffer(slrhip_ctx* ctx, void* ncclComm, int root, float* deviceDst, size_t numFloats, void* streamPtr) {
+    if (!ctx || !ncclComm) return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_reduce_framebuffer: null argument");
+    if (!ctx->haveRender) return fail(SLRHIP_ERR_NO_SCENE, "slrhip_reduce_framebuffer: nothing rendered");
+    const RenderParams& rp = ctx->params;
+    const size_t need = (size_t)rp.imageWidth * rp.imageHeight * (rp.spectral ? 16 : 3);
+    if (deviceDst && numFloats < need) return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_reduce_framebuffer: destination too small");
+    typedef int (*reduce_fn)(const void*, void*, size_t, int, int, int, void*, hipStream_t);
+    static reduce_fn ncclReduceFn = [] {
+        void* h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        return h ? reinterpret_cast<reduce_fn>(dlsym(h, "ncclReduce")) : nullptr;
+    }();
+    if (!ncclReduceFn) return fail(SLRHIP_ERR_UNSUPPORTED, "slrhip_reduce_framebuffer: librccl.so (ncclReduce) not found");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(ctx->resolveScratch.alloc(need));
+    int rc = slrhip_resolve_framebuffer(ctx, ctx->resolveScratch.ptr, need, streamPtr);
+    if (rc != SLRHIP_OK) return rc;
+    const int kNcclFloat32 = 7, kNcclSum = 0;      // rccl.h: ncclDataType_t / ncclRedOp_t
+    const int nrc = ncclReduceFn(ctx->resolveScratch.ptr, deviceDst, need, kNcclFloat32, kNcclSum, root, ncclComm, (hipStream_t)streamPtr);
+    if (nrc != 0) return fail(SLRHIP_ERR_HIP, "slrhip_reduce_framebuffer: ncclReduce failed (" + std::to_string(nrc) + ")");
     return SLRHIP_OK;
 }
 
