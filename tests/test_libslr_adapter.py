@@ -153,8 +153,12 @@ def test_reference_scene_object_renders_on_the_hip_path_through_the_renderer_vta
     rs = lib.scene(sc)
     fb = np.zeros((72, 96, rs.components), np.float32)
     assert lib.lib.slr_ref_render_hip(rs.handle, C.byref(st), spp, 0, binding.LIB_PATH.encode(), fb.ctypes.data) == 0
-    c = Context(mode=mode)          # same automatic stripe count as the adapter's context
-    direct = c.render_image(sc, st, spp)
+    c = Context(mode=mode)          # same automatic stripe count as the adapter's context ...
+    c.upload_scene(sc)
+    c.render_begin(st)
+    for begin, count in ((0, 1), (1, 1), (2, 2), (4, 4)):      # ... and the same calls: one per export of PathTracingRenderer.cpp:83-94
+        c.render(begin, count)
+    direct = c.read_framebuffer()
     c.close()
     assert_bit_equal(fb, direct, "through libSLR's Renderer vtable vs the flat scene directly")
     want, _ = ob.load("oracle", mode).scene(sc).render(st, spp)
