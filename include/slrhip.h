@@ -380,6 +380,15 @@ int slrhip_upsample(int32_t spectrum_type, int32_t color_space, float e0, float 
  * points (0, 3 or 4 -> slrhip_spectrum::reserved) and the 4 + 4 * SLRHIP_UPSAMPLING_SAMPLES floats of the UPSAMPLED payload. */
 int slrhip_resolve_upsampled(const slrhip_upsampling_tables* tables, float u, float v, uint32_t* num_points, float* payload);
 
+/* Replaces: Spectrum::create(spType, minLambda, maxLambda, values, n) / (spType, lambdas, values, n) of the reference's RGB build
+ * (libSLRSceneGraph/API.cpp:1149-1278,1326-1369): integrates the sampled spectrum against the CIE 2-degree colour-matching
+ * functions (trapezoids over the union of both sample grids, Kahan sums), normalises by integralCMF, converts XYZ -> linear sRGB
+ * (type ILLUMINANT) or sRGB_E (REFLECTANCE, IOR) and clamps negative components: the `rgb` of a slrhip_spectrum of kind REGULAR
+ * (lambdas == NULL; min / max wavelength given) or IRREGULAR (lambdas given), i.e. what RGB mode renders named spectra such as
+ * Spectrum("ID": "D65") or the refractive-index tables with.                                                              */
+int slrhip_spectrum_to_rgb(int32_t spectrum_type, const float* lambdas, float lambda_min, float lambda_max, const float* values,
+                           uint32_t num_samples, float rgb[3]);
+
 /* Host-side helpers on the float framebuffer.
  * slrhip_tonemap_bgr8: ImageSensor::saveImage (ImageSensor.cpp:138-186) pixel pipeline:
  * scale*sensitivity -> (spectral: XYZ->sRGB) -> 1-exp(-Y) tone map -> sRGB gamma -> 8-bit BGR,

@@ -706,6 +706,20 @@ int slr_ref_render_hip(slr_oracle_scene* s, const slrhip_render_settings* st, ui
     return 0;
 }
 
+// The pieces of the RGB build's Spectrum::create that live in libSLR (the integration loop itself is in libSLRSceneGraph/API.cpp,
+// which does not build here): the global integralCMF after initSpectrum() (BasicTypes/Spectrum.cpp:222-229) and the XYZ -> sRGB /
+// sRGB_E conversions (BasicTypes/Spectrum.h:59-78).  spType 1 = Illuminant -> XYZ_to_sRGB, else XYZ_to_sRGB_E (API.cpp:1326-1347).
+int slr_ref_rgb_pieces(int spType, const float* xyz, uint32_t n, float* rgb, float* integral) {
+    static bool inited = false;
+    if (!inited) { initSpectrum(); inited = true; }
+    if (integral) *integral = integralCMF;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (spType == 1) XYZ_to_sRGB(xyz + 3 * i, rgb + 3 * i);
+        else XYZ_to_sRGB_E(xyz + 3 * i, rgb + 3 * i);
+    }
+    return 0;
+}
+
 int slr_ref_upsample(int spType, int space, float e0, float e1, float e2, float* uvs) {
     if (!uvs) return 1;
     static const SpectrumType types[3] = {SpectrumType::Reflectance, SpectrumType::Illuminant, SpectrumType::IndexOfRefraction};

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(CSRC, "libslrhip.so")
 
 EXPORTS = ["slrhip_create", "slrhip_destroy", "slrhip_upload_scene", "slrhip_render_begin", "slrhip_render",
            "slrhip_resolve_framebuffer", "slrhip_reduce_framebuffer", "slrhip_read_framebuffer", "slrhip_synchronize", "slrhip_get_counters",
-           "slrhip_components", "slrhip_get_profile", "slrhip_trace_rays", "slrhip_bsdf_queries", "slrhip_sample_seed", "slrhip_upsample", "slrhip_resolve_upsampled", "slrhip_tonemap_bgr8", "slrhip_save_bmp",
+           "slrhip_components", "slrhip_get_profile", "slrhip_trace_rays", "slrhip_bsdf_queries", "slrhip_sample_seed", "slrhip_upsample", "slrhip_resolve_upsampled", "slrhip_spectrum_to_rgb", "slrhip_tonemap_bgr8", "slrhip_save_bmp",
            "slrhip_last_error_string", "slrhip_version"]
 
 
@@ -58,6 +58,7 @@ def load_library():
     lib.slrhip_sample_seed.restype = C.c_int32
     lib.slrhip_upsample.argtypes = [C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_void_p]
     lib.slrhip_resolve_upsampled.argtypes = [C.POINTER(abi.UpsamplingTables), C.c_float, C.c_float, C.POINTER(C.c_uint32), C.c_void_p]
+    lib.slrhip_spectrum_to_rgb.argtypes = [C.c_int32, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_uint32, C.c_void_p]
     lib.slrhip_tonemap_bgr8.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_size_t]
     lib.slrhip_save_bmp.argtypes = [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32]
     lib.slrhip_last_error_string.restype = C.c_char_p

@@ -77,10 +77,13 @@ uint32_t Scene::addIrregularSpectrum(const float* lambdas, const float* values, 
     payload.insert(payload.end(), values, values + numSamples);
     return addSpectrum(s, payload.data(), (uint32_t)payload.size());
 }
-uint32_t Scene::addD65Spectrum(float scale, const float rgb[3]) {
+uint32_t Scene::addD65Spectrum(float scale) {
     if (!m_hasTables) { std::fprintf(stderr, "SLRHip: addD65Spectrum needs loadSpectralTables()\n"); std::exit(-1); }
+    // RGB build: Spectrum::create(Illuminant, 300, 830, D65, 531) (API.cpp:405-406,1326-1347), then `* scale` on the RGB triple
+    float rgb[3];
+    if (slrhip_spectrum_to_rgb(SLRHIP_SPECTRUMTYPE_ILLUMINANT, nullptr, 300.0f, 830.0f, m_d65.data(), (uint32_t)m_d65.size(), rgb) != SLRHIP_OK) std::exit(-1);
     std::vector<float> v(m_d65);
-    for (float& x : v) x = scale * x;                  // RegularContinuousSpectrum::createScaled, SpectrumTypes.h:112-118
+    for (float& x : v) x = scale * x;                  // spectral build: RegularContinuousSpectrum::createScaled, SpectrumTypes.h:112-118
     const float scaled[3] = {scale * rgb[0], scale * rgb[1], scale * rgb[2]};
     return addRegularSpectrum(300.0f, 830.0f, v.data(), (uint32_t)v.size(), scaled);
 }

@@ -58,9 +58,10 @@ public:
     // UpsampledContinuousSpectrum (SpectrumTypes.h:180-237; its (u, v) cell look-up resolved here, slrhip_resolve_upsampled), in
     // the RGB build the (de-gamma'd) triple.  One record serves both modes.  Needs loadSpectralTables().
     uint32_t addUpsampledSpectrum(int32_t spectrumType, int32_t colorSpace, float e0, float e1, float e2);
-    // `Spectrum("ID": "D65") * scale` (API.cpp:405-406,443-462): RegularContinuousSpectrum 300-830 nm, 531 samples; `rgb` = its
-    // RGB-build value (the caller's conversion: API.cpp:1149-1214).  Needs loadSpectralTables().
-    uint32_t addD65Spectrum(float scale, const float rgb[3]);
+    // `Spectrum("ID": "D65") * scale` (API.cpp:405-406,443-462): RegularContinuousSpectrum 300-830 nm, 531 samples, and its
+    // RGB-build value through slrhip_spectrum_to_rgb (API.cpp:1149-1214,1326-1347).  One record serves both modes.
+    // Needs loadSpectralTables().
+    uint32_t addD65Spectrum(float scale);
     // RegularContinuousSpectrum / IrregularContinuousSpectrum from the caller's samples (refractive-index tables, API.cpp:420-441)
     uint32_t addRegularSpectrum(float lambdaMin, float lambdaMax, const float* values, uint32_t numSamples, const float rgb[3]);
     uint32_t addIrregularSpectrum(const float* lambdas, const float* values, uint32_t numSamples, const float rgb[3]);

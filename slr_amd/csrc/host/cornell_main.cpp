@@ -21,7 +21,7 @@ int main(int argc, char** argv) {
     const char* outdir = argc > 4 ? argv[4] : ".";
     const bool spectral = argc > 5 && std::string(argv[5]) == "spectral";
     Scene scene;
-    if (spectral && !scene.loadSpectralTables(argc > 6 ? argv[6] : "slr_amd/data/upsampling_tables.bin")) return -1;
+    if (!scene.loadSpectralTables(argc > 6 ? argv[6] : "slr_amd/data/upsampling_tables.bin")) return -1;
     cornell::build(scene, width, height, spectral);
 
     RenderSettings settings;                                     // HostProgram/main.cpp:51-57, defaults of API.cpp:1071-1092

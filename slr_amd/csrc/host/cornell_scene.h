@@ -21,7 +21,8 @@ static inline void quad(Scene& s, const float c[4][3], const float n[3], const f
 
 
 // spectral: the scene language's spectra — Spectrum(r, g, b) = an upsampled reflectance, Spectrum("ID": "D65") * 4 = a regular
-// spectrum — built in C++ (SLRHip::Scene::addUpsampledSpectrum / addD65Spectrum; needs scene.loadSpectralTables first)
+// spectrum — built in C++ (SLRHip::Scene::addUpsampledSpectrum / addD65Spectrum).  Both builds need scene.loadSpectralTables
+// first: the RGB build converts the D65 table to its RGB value (slrhip_spectrum_to_rgb).
 static inline void build(Scene& scene, int width, int height, bool spectral) {
     auto reflectance = [&](float r, float g, float b) {
         return spectral ? scene.addUpsampledSpectrum(SLRHIP_SPECTRUMTYPE_REFLECTANCE, SLRHIP_COLORSPACE_SRGB_NONLINEAR, r, g, b)
@@ -31,8 +32,7 @@ static inline void build(Scene& scene, int width, int height, bool spectral) {
         return scene.addMaterial(SLRHIP_MATERIAL_MATTE, (int32_t)reflectance(r, g, b), -1, -1, -1.0f, -1);
     };
     const uint32_t red = matte(0.75f, 0.25f, 0.25f), blue = matte(0.25f, 0.25f, 0.75f), white = matte(0.75f, 0.75f, 0.75f);
-    const float d65rgb[3] = {100.0f, 100.0f, 100.0f};
-    const uint32_t emit = spectral ? scene.addD65Spectrum(4.0f, d65rgb) : scene.addSpectrumRGB(400.0f, 400.0f, 400.0f);
+    const uint32_t emit = scene.addD65Spectrum(4.0f);      // Spectrum("ID": "D65") * 4 in either build (needs loadSpectralTables)
     const uint32_t light = scene.addMaterial(SLRHIP_MATERIAL_MATTE, (int32_t)reflectance(0.9f, 0.9f, 0.9f), -1, -1, -1.0f, (int32_t)emit);
     const float L[4][3] = {{-1.5f, 0, 2.55f}, {-1.5f, 0, -2.55f}, {-1.5f, 2.5f, -2.55f}, {-1.5f, 2.5f, 2.55f}};
     const float R[4][3] = {{1.5f, 0, -2.55f}, {1.5f, 0, 2.55f}, {1.5f, 2.5f, 2.55f}, {1.5f, 2.5f, -2.55f}};

@@ -3,7 +3,7 @@
 // slrhip_reduce_framebuffer over an RCCL communicator.  With the devices this process sees (a 1-GPU box: one rank, a
 // communicator of size 1) the ranks run one after the other inside one process through ncclCommInitAll + ncclGroupStart/End;
 // the sum of the shards must equal the unsharded frame bit for bit.
-//   usage: reduce_main [numShards] [width] [height] [spp]
+//   usage: reduce_main [numShards] [width] [height] [spp] [tables.bin]
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -24,6 +24,7 @@ int main(int argc, char** argv) {
     const int W = argc > 2 ? std::atoi(argv[2]) : 160, H = argc > 3 ? std::atoi(argv[3]) : 120;
     const uint32_t spp = argc > 4 ? (uint32_t)std::atoi(argv[4]) : 8;
     SLRHip::Scene scene;
+    if (!scene.loadSpectralTables(argc > 5 ? argv[5] : "slr_amd/data/upsampling_tables.bin")) return 1;
     cornell::build(scene, W, H, false);
     slrhip_scene_desc desc = scene.desc();
     slrhip_render_settings st = {W, H, 0.0f, 0.0f, 1.0f, 1509761209};

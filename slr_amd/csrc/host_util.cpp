@@ -1,6 +1,7 @@
 // host_util.cpp — host-only pieces of the C ABI: the seeding contract, and the image export of
 // the reference (ImageSensor::saveImage, Core/ImageSensor.cpp:138-186; saveBMP,
 // Helper/bmp_exporter.cpp:13-53) operating on the linear float framebuffer the GPU returns.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -8,6 +9,7 @@
 
 #include "../../include/slrhip.h"
 #include "cmf16_table.h"
+#include "cmf_2deg_table.h"
 
 namespace {
 
@@ -70,6 +72,114 @@ int slrhip_upsample(int32_t spectrumType, int32_t colorSpace, float e0, float e1
     uvs[2] = brightness / 0.009355121400914532f;                            // Upsampling::EqualEnergyReflectance
     uvs[0] = (float)(16.730260708356887 * x + 7.7801960340706 * y - 2.170152247475828);
     uvs[1] = (float)(-7.530081094743006 * x + 16.192422314095225 * y + 1.1125529268825947);
+    return SLRHIP_OK;
+}
+
+// RGB build of the reference: a sampled spectrum -> the RGBInputSpectrum the scene language creates for it
+// (libSLRSceneGraph/API.cpp:1149-1214 spectrum_to_XYZ for regular samples, :1216-1278 for irregular ones; :1326-1369 the
+// XYZ -> sRGB conversion by spectrum type and the clamp of negative components).  The integration walks the union of the CMF's
+// 1-nm grid and the spectrum's own sample positions with trapezoids and Kahan sums, all in float, then divides by integralCMF
+// (BasicTypes/Spectrum.cpp:222-229: the Kahan-summed trapezoid integral of ybar_2deg, evaluated with double literals).
+namespace {
+struct KahanSum {     // BasicTypes/CompensatedSum.h:15-32
+    float result = 0.0f, comp = 0.0f;
+    void add(float value) { float cInput = value - comp; float sumTemp = result + cInput; comp = (sumTemp - result) - cInput; result = sumTemp; }
+};
+float integralCMF() {
+    KahanSum cum;
+    for (int i = 1; i < 471; ++i) cum.add((float)((kCmf2Deg[1][i - 1] + kCmf2Deg[1][i]) * 1 * 0.5));
+    return cum.result;
+}
+}
+
+int slrhip_spectrum_to_rgb(int32_t spectrumType, const float* lambdas, float minLambda, float maxLambda, const float* values, uint32_t numSamples,
+                           float rgb[3]) {
+    if (!values || !rgb || numSamples < 2) return SLRHIP_ERR_INVALID_ARGUMENT;
+    if (spectrumType < SLRHIP_SPECTRUMTYPE_REFLECTANCE || spectrumType > SLRHIP_SPECTRUMTYPE_IOR) return SLRHIP_ERR_INVALID_ARGUMENT;
+    const float WavelengthLowBound = 360.0f, WavelengthHighBound = 830.0f;
+    const uint32_t NumCMFSamples = 471;
+    const float* xbar_2deg = kCmf2Deg[0];
+    const float* ybar_2deg = kCmf2Deg[1];
+    const float* zbar_2deg = kCmf2Deg[2];
+    const float CMFBinWidth = (WavelengthHighBound - WavelengthLowBound) / (NumCMFSamples - 1);
+    const float binWidth = lambdas ? 0.0f : (maxLambda - minLambda) / (numSamples - 1);
+    uint32_t curCMFIdx = 0, baseIdx = 0;
+    float curWL = WavelengthLowBound;
+    float prev_xbarVal = 0, prev_ybarVal = 0, prev_zbarVal = 0, prevValue = 0, halfWidth = 0;
+    KahanSum X, Y, Z;
+    for (uint32_t guard = 0; guard < 4u * (NumCMFSamples + numSamples); ++guard) {
+        float xbarValue, ybarValue, zbarValue;
+        if (curWL == WavelengthLowBound + curCMFIdx * CMFBinWidth) {
+            xbarValue = xbar_2deg[curCMFIdx]; ybarValue = ybar_2deg[curCMFIdx]; zbarValue = zbar_2deg[curCMFIdx];
+            ++curCMFIdx;
+        }
+        else if (curWL < WavelengthLowBound) {
+            // A spectrum that starts below 360 nm (D65 at 300 nm, the metals' tables) makes the reference's walk step BACK from
+            // 360 nm to the spectrum's first sample and climb up again; on the way it converts a negative float to unsigned
+            // (undefined behaviour; the x86-64 clang build clamps the index to 470 and reads one element past xbar_2deg).
+            // That is not reproducible.  Here the colour-matching functions are zero below 360 nm, which is what they are;
+            // the detour then contributes only its first, negative-width trapezoid (< 1e-4 of the result).
+            xbarValue = ybarValue = zbarValue = 0.0f;
+        }
+        else {
+            uint32_t idx = std::min(uint32_t((curWL - WavelengthLowBound) / CMFBinWidth), NumCMFSamples - 1);
+            if (idx + 1 >= NumCMFSamples) idx = NumCMFSamples - 2;          // the reference reads xbar_2deg[idx + 1]; stay inside the table
+            float CMFBaseWL = WavelengthLowBound + idx * CMFBinWidth;
+            float t = (curWL - CMFBaseWL) / CMFBinWidth;
+            xbarValue = (1 - t) * xbar_2deg[idx] + t * xbar_2deg[idx + 1];
+            ybarValue = (1 - t) * ybar_2deg[idx] + t * ybar_2deg[idx + 1];
+            zbarValue = (1 - t) * zbar_2deg[idx] + t * zbar_2deg[idx + 1];
+        }
+        float value;
+        if (lambdas) {                                                       // irregular samples, API.cpp:1243-1259
+            if (curWL < lambdas[0]) value = values[0];
+            else if (curWL > lambdas[numSamples - 1]) value = values[numSamples - 1];
+            else if (baseIdx < numSamples && curWL == lambdas[baseIdx]) { value = values[baseIdx]; ++baseIdx; }
+            else {
+                const float* lb = std::lower_bound(lambdas + std::max((int32_t)baseIdx - 1, 0), lambdas + numSamples, curWL);
+                uint32_t idx = (uint32_t)std::max(int32_t(lb - lambdas) - 1, 0);
+                if (idx + 1 >= numSamples) idx = numSamples - 2;
+                float t = (curWL - lambdas[idx]) / (lambdas[idx + 1] - lambdas[idx]);
+                value = (1 - t) * values[idx] + t * values[idx + 1];
+            }
+        }
+        else {                                                               // regular samples, API.cpp:1176-1192
+            if (curWL < minLambda) value = values[0];
+            else if (curWL > maxLambda) value = values[numSamples - 1];
+            else if (curWL == minLambda + baseIdx * binWidth) { value = values[baseIdx]; ++baseIdx; }
+            else {
+                uint32_t idx = std::min(uint32_t((curWL - minLambda) / binWidth), numSamples - 1);
+                if (idx + 1 >= numSamples) idx = numSamples - 2;
+                float baseWL = minLambda + idx * binWidth;
+                float t = (curWL - baseWL) / binWidth;
+                value = (1 - t) * values[idx] + t * values[idx + 1];
+            }
+        }
+        float avgValue = (prevValue + value) * 0.5f;
+        X.add(avgValue * (prev_xbarVal + xbarValue) * halfWidth);
+        Y.add(avgValue * (prev_ybarVal + ybarValue) * halfWidth);
+        Z.add(avgValue * (prev_zbarVal + zbarValue) * halfWidth);
+        prev_xbarVal = xbarValue; prev_ybarVal = ybarValue; prev_zbarVal = zbarValue;
+        prevValue = value;
+        float prevWL = curWL;
+        const float nextSample = baseIdx < numSamples ? (lambdas ? lambdas[baseIdx] : (minLambda + baseIdx * binWidth)) : INFINITY;
+        curWL = std::min(WavelengthLowBound + curCMFIdx * CMFBinWidth, nextSample);
+        halfWidth = (curWL - prevWL) * 0.5f;
+        if (curCMFIdx == NumCMFSamples) break;
+    }
+    const float norm = integralCMF();
+    const float XYZ[3] = {X.result / norm, Y.result / norm, Z.result / norm};
+    if (spectrumType == SLRHIP_SPECTRUMTYPE_ILLUMINANT) {                    // XYZ_to_sRGB, Spectrum.h:59-64
+        rgb[0] = (float)(3.2404542 * XYZ[0] - 1.5371385 * XYZ[1] - 0.4985314 * XYZ[2]);
+        rgb[1] = (float)(-0.9692660 * XYZ[0] + 1.8760108 * XYZ[1] + 0.0415560 * XYZ[2]);
+        rgb[2] = (float)(0.0556434 * XYZ[0] - 0.2040259 * XYZ[1] + 1.0572252 * XYZ[2]);
+    }
+    else {                                                                   // XYZ_to_sRGB_E, Spectrum.h:73-78 (reflectances and IORs)
+        rgb[0] = (float)(2.6897 * XYZ[0] - 1.2759 * XYZ[1] - 0.4138 * XYZ[2]);
+        rgb[1] = (float)(-1.0221 * XYZ[0] + 1.9783 * XYZ[1] + 0.0438 * XYZ[2]);
+        rgb[2] = (float)(0.0612 * XYZ[0] - 0.2245 * XYZ[1] + 1.1633 * XYZ[2]);
+    }
+    for (int i = 0; i < 3; ++i) rgb[i] = rgb[i] < 0.0f ? 0.0f : rgb[i];
     return SLRHIP_OK;
 }
 

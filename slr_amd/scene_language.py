@@ -743,10 +743,6 @@ class Interpreter:
         return b.build(camera, env=environment, name="scene_language")
 
 
-_LIBRARY_RGB = {("Aluminium", 0): "ALUMINIUM_ETA_RGB", ("Aluminium", 1): "ALUMINIUM_K_RGB", ("Air", 0): "AIR_ETA_RGB",
-                ("Glass_BK7", 0): "BK7_ETA_RGB", ("Titanium", 0): "TITANIUM_ETA_RGB", ("Titanium", 1): "TITANIUM_K_RGB"}
-
-
 def _bind_spectrum(b, sv):
     """Spectrum::create (API.cpp:1139-1147 spectral, :1281-1369 RGB) through SceneBuilder: both the RGB-mode value and the
     spectral descriptor."""
@@ -765,10 +761,10 @@ def _bind_spectrum(b, sv):
         name, idx = args
         if name == "D65":
             return b.spectrum_d65(scale, scenes.D65_RGB)
-        const = _LIBRARY_RGB.get((name, idx))
-        if const is None or not hasattr(scenes, const) or scale != 1.0:
-            raise UnsupportedFeature("library spectrum %r[%d]: no RGB-mode value tabulated in slr_amd/scenes.py" % (name, idx))
-        return b.spectrum_ior(name, idx, getattr(scenes, const))
+        from . import spectra
+        if ("ior_%s_meta" % name) not in spectra.tables() or idx not in (0, 1) or scale != 1.0:
+            raise UnsupportedFeature("library spectrum %r[%d] (scaled or not in spectrum_library.cpp)" % (name, idx))
+        return b.spectrum_ior(name, idx, spectra.named_rgb(name, idx))      # its RGB-build value: API.cpp:1216-1278,1326-1369
     raise UnsupportedFeature("spectrum constructor %r" % ctor)
 
 

@@ -195,11 +195,14 @@ class SceneBuilder:
 # Spectrum::create's RGB branch (libSLRSceneGraph/API.cpp:1326-1347: integrate the table
 # against the CMFs, XYZ -> sRGB, clamp).  Values below are fixed scene INPUTS of the
 # synthetic scene (the same numbers go to oracle, reference and GPU).
-D65_RGB = (100.0, 100.0, 100.0)        # x 4 = (400, 400, 400) for the Cornell light
-ALUMINIUM_ETA_RGB = (1.657, 0.880, 0.521)
-ALUMINIUM_K_RGB = (9.224, 6.270, 4.837)
-AIR_ETA_RGB = (1.000277, 1.000277, 1.000277)
-BK7_ETA_RGB = (1.5140, 1.5187, 1.5264)
+# RGB-build values of the named spectra: what Spectrum::create makes of the sampled tables in the reference's RGB build
+# (libSLRSceneGraph/API.cpp:1149-1278,1326-1369: CMF integration, XYZ -> sRGB / sRGB_E, clamp), computed by the C++ host
+# function slrhip_spectrum_to_rgb from the tables dumped from the compiled reference (spectra.named_rgb).
+D65_RGB = spectra.named_rgb("D65")        # ~ (98.89, 98.89, 98.88); x 4 for the Cornell light
+ALUMINIUM_ETA_RGB = spectra.named_rgb("Aluminium", 0)
+ALUMINIUM_K_RGB = spectra.named_rgb("Aluminium", 1)
+AIR_ETA_RGB = spectra.named_rgb("Air", 0)
+BK7_ETA_RGB = spectra.named_rgb("Glass_BK7", 0)
 
 
 def cornell_walls(b):
@@ -246,8 +249,8 @@ def tiny_box(aspect=1.0):
 
 
 # RGB-mode eta / k of titanium (Cornell_Box_Boxes.txt:32-33 uses the "Titanium" IOR table); fixed scene inputs.
-TITANIUM_ETA_RGB = (2.7407, 2.5418, 2.2370)
-TITANIUM_K_RGB = (3.8143, 3.4345, 3.0235)
+TITANIUM_ETA_RGB = spectra.named_rgb("Titanium", 0)
+TITANIUM_K_RGB = spectra.named_rgb("Titanium", 1)
 
 
 def cornell_lobes(kind, aspect=1.0, segments=16, rings=8):

@@ -193,3 +193,44 @@ class SpectrumSet:
         if regular:
             return self.regular(lo, hi, vals, rgb=rgb)
         return self.irregular(t["ior_%s_lambdas" % name], vals, rgb=rgb)
+
+
+# ---- RGB build: the RGBInputSpectrum of a named (sampled) spectrum ------------------------------------------------------
+_named_rgb_cache = {}
+
+
+def spectrum_to_rgb(sp_type, values, lambda_min=None, lambda_max=None, lambdas=None):
+    """Spectrum::create(spType, ...) of the reference's RGB build for a sampled spectrum (libSLRSceneGraph/API.cpp:1149-1278,
+    1326-1369): CMF integration -> XYZ -> linear sRGB (illuminants) or sRGB_E (reflectances, refractive indices), negative
+    components clamped.  Computed by the C++ host function slrhip_spectrum_to_rgb (host-only: needs no GPU)."""
+    import ctypes as C
+    from . import binding
+    lib = binding.load_library()
+    v = np.ascontiguousarray(values, F)
+    out = np.zeros(3, F)
+    if lambdas is None:
+        rc = lib.slrhip_spectrum_to_rgb(sp_type, None, C.c_float(lambda_min), C.c_float(lambda_max), v.ctypes.data, len(v), out.ctypes.data)
+    else:
+        lam = np.ascontiguousarray(lambdas, F)
+        rc = lib.slrhip_spectrum_to_rgb(sp_type, lam.ctypes.data, C.c_float(0.0), C.c_float(0.0), v.ctypes.data, len(v), out.ctypes.data)
+    if rc != 0:
+        raise ValueError("slrhip_spectrum_to_rgb failed (%d)" % rc)
+    return tuple(float(c) for c in out)
+
+
+def named_rgb(name, which=0):
+    """RGB-build value of Spectrum("ID": name, which): "D65" (API.cpp:405-406, an Illuminant) or a refractive-index table of
+    spectrum_library.cpp (API.cpp:420-441, IndexOfRefraction; which = 0 eta, 1 k)."""
+    key = (name, which)
+    if key not in _named_rgb_cache:
+        t = tables()
+        if name == "D65":
+            _named_rgb_cache[key] = spectrum_to_rgb(ILLUMINANT, t["d65"], 300.0, 830.0)
+        else:
+            lo, hi, regular, _ = t["ior_%s_meta" % name]
+            vals = t["ior_%s_etas" % name] if which == 0 else t["ior_%s_ks" % name]
+            if regular:
+                _named_rgb_cache[key] = spectrum_to_rgb(IOR, vals, float(lo), float(hi))
+            else:
+                _named_rgb_cache[key] = spectrum_to_rgb(IOR, vals, lambdas=t["ior_%s_lambdas" % name])
+    return _named_rgb_cache[key]

@@ -93,7 +93,8 @@ def make_procedural(name, generator, args, lib, width, height, spp):
     hits = ref.trace(rays)
     crc = zlib.crc32(sc.vertices.tobytes()) ^ zlib.crc32(sc.triangles.tobytes())
     np.savez_compressed(os.path.join(HERE, name + ".npz"), generator=generator, generator_args=np.array(args, np.float64),
-                        scene_crc=np.uint32(crc), num_triangles=len(sc.triangles), width=width, height=height, spp=spp,
+                        scene_crc=np.uint32(crc), num_triangles=len(sc.triangles), materials=sc.materials, spectra=sc.spectra,
+                        spectrum_data=sc.spectrum_data, width=width, height=height, spp=spp,
                         seed=st.rng_seed, framebuffer=fb, rays=rays, hits=hits)
     print(name, "framebuffer mean", fb.mean(), "hits", int((hits["triangle"] != 0xFFFFFFFF).sum()), "/", len(hits))
 
@@ -249,6 +250,23 @@ def main_round2(only):
             rows.append([spt, space, e[0], e[1], e[2], out[0], out[1], out[2]])
         np.savez_compressed(os.path.join(HERE, "upsample_kat.npz"), rows=np.array(rows, np.float32))
         print("upsample_kat", len(rows))
+    if not only or "rgb_conversion_kat" in only:
+        # the libSLR-held pieces of the RGB build's Spectrum::create: integralCMF and XYZ -> sRGB / sRGB_E on 256 XYZ triples
+        import ctypes as C
+        f = lib.lib.slr_ref_rgb_pieces
+        f.argtypes = [C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        rng = np.random.default_rng(31415)
+        xyz = (rng.random((256, 3)) * [1.2, 1.0, 1.4]).astype(np.float32)
+        xyz[0] = (0.95047, 1.0, 1.08883)
+        xyz[1] = 0.0
+        out = {}
+        integral = np.zeros(1, np.float32)
+        for tag, tp in (("illuminant", 1), ("reflectance", 0)):
+            rgb = np.zeros_like(xyz)
+            assert f(tp, xyz.ctypes.data, len(xyz), rgb.ctypes.data, integral.ctypes.data) == 0
+            out["rgb_" + tag] = rgb
+        np.savez_compressed(os.path.join(HERE, "rgb_conversion_kat.npz"), xyz=xyz, integral_cmf=integral, **out)
+        print("rgb_conversion_kat integralCMF", integral[0])
     if not only or "rgb_grid400" in only:
         make_procedural("rgb_grid400", "displaced_grid", (400, 16.0 / 9.0), lib, 160, 90, 8)
 

@@ -140,6 +140,9 @@ def procedural_scene(g):
     sc = getattr(scenes, str(g["generator"]))(int(a[0]), float(a[1]))
     assert (zlib.crc32(sc.vertices.tobytes()) ^ zlib.crc32(sc.triangles.tobytes())) == int(g["scene_crc"]), "generator output changed"
     assert len(sc.triangles) == int(g["num_triangles"])
+    # the small tables are stored: the fixture's frame was rendered with exactly these materials and spectra
+    assert sc.materials.tobytes() == g["materials"].tobytes() and sc.spectra.tobytes() == g["spectra"].tobytes()
+    assert sc.spectrum_data.tobytes() == g["spectrum_data"].tobytes()
     return sc
 
 
