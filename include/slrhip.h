@@ -284,6 +284,8 @@ typedef struct slrhip_profile {
 } slrhip_profile;
 
 /* config.flags */
+#define SLRHIP_FLAG_QUAD_LAYOUT   32u   /* also build the four-lanes-per-ray node / leaf layouts at slrhip_upload_scene
+                                         * (slrhip_trace_rays_timed, mapping 1): the lane-mapping experiment of DESIGN.md   */
 #define SLRHIP_FLAG_TEST_DEVICE_ERROR 16u /* test hook: the next slrhip_render raises the device-side error word, so that the
                                          * error path (SLRHIP_ERR_HIP + message) can be exercised; renders nothing useful */
 #define SLRHIP_FLAG_TIME_KERNELS   1u   /* bracket every launch with HIP events (a few us per launch)        */
@@ -352,6 +354,15 @@ int slrhip_get_profile(slrhip_ctx* ctx, slrhip_profile* out);
  * dist_max}; hits: n x {triangle index as uint32 bits (0xFFFFFFFF = miss), dist, b0, b1}
  * (Intersection::dist, ::u, ::v; TriangleMesh.cpp:169-173).  Host arrays; synchronises.        */
 int slrhip_trace_rays(slrhip_ctx* ctx, const float* rays, uint32_t n, float* hits);
+
+/* Measurement (lane-mapping experiment): the same closest-hit queries, copied to the device once, run `repeats` times
+ * under one lane mapping and timed with HIP events: mapping 0 = one lane per ray, 1 = four lanes per ray (one child box / one
+ * leaf triangle per lane; context created with SLRHIP_FLAG_QUAD_LAYOUT).  Same hits either way.  Host arrays; synchronises.   */
+int slrhip_trace_rays_timed(slrhip_ctx* ctx, const float* rays, uint32_t n, float* hits, int32_t mapping, uint32_t repeats,
+                            float* avg_milliseconds);
+/* Diagnostic: the extension rays stored in path slots [first, first + n) — after a render, every slot's last ray — in the
+ * layout slrhip_trace_rays takes: real secondary rays to measure traversal on.                                          */
+int slrhip_debug_read_rays(slrhip_ctx* ctx, uint32_t first, uint32_t n, float* rays);
 
 /* Diagnostic: function-level BSDF queries against material `material` of the uploaded scene,
  * through the same device functions the shading kernel calls: BSDF::sample / evaluate /

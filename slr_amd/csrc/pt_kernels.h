@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <vector>
+
 #include "device_types.h"
 
 namespace slrhip {
@@ -140,6 +142,9 @@ void launchBsdfQueries(const DevScene& sc, bool spectral, uint32_t material, uin
                        float4* geo, float4* misc, float4* fsSample, float4* fsEval, hipStream_t stream);
 void launchTraceBatch(const DevScene& sc, const float4* org, const float4* dir, float4* out, uint32_t n, hipStream_t stream);
 int traceBlocksPerCU();
+// four lanes per ray (pt_trace_quad.hip): the lane-mapping experiment; layouts built from the uploaded tree
+void buildQuadLayouts(const std::vector<QNode>& nodes, const std::vector<LeafTri>& leafTris, std::vector<float4>* nodes4, std::vector<float4>* packets);
+void launchTraceQuad(const float4* nodes4, const float4* packets, const float4* org, const float4* dir, float4* out, uint32_t n, hipStream_t stream);
 // wave-specialised traversal (pt_trace_ws.hip): same results, ONE launch for the extension and the shadow rays of an iteration
 void launchTraceWs(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, uint32_t blocks, bool count,
                    hipStream_t stream);

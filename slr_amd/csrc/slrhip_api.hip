@@ -111,6 +111,7 @@ struct slrhip_ctx {
     // scene
     DevArray<QNode> nodes;
     DevArray<QNodeQ> nodesQ;
+    DevArray<float4> quadNodes, quadPackets;      // SLRHIP_FLAG_QUAD_LAYOUT: the four-lanes-per-ray layouts (pt_trace_quad.hip)
     DevArray<LeafTri> leafTris;
     DevArray<ShadeTri> shadeTris;
     DevArray<LightTri> lightTris;
@@ -474,6 +475,12 @@ int slrhip_upload_scene(slrhip_ctx* ctx, const slrhip_scene_desc* d) {
     const bool quant = (bvh.nodes.size() >= 65536 || forceQuant) && !noQuant;
     if (quant) { quantizeNodes(&bvh); HIP_TRY(ctx->nodesQ.upload(bvh.quantized)); }
     HIP_TRY(ctx->leafTris.upload(bvh.leafTris));
+    if (ctx->config.flags & SLRHIP_FLAG_QUAD_LAYOUT) {
+        std::vector<float4> qn, qp;
+        buildQuadLayouts(bvh.nodes, bvh.leafTris, &qn, &qp);
+        HIP_TRY(ctx->quadNodes.upload(qn));
+        HIP_TRY(ctx->quadPackets.upload(qp));
+    }
     HIP_TRY(ctx->shadeTris.upload(shade));
     HIP_TRY(ctx->lightTris.upload(lights));
     HIP_TRY(ctx->materials.upload(mats));
@@ -936,6 +943,62 @@ int slrhip_trace_rays(slrhip_ctx* ctx, const float* rays, uint32_t n, float* hit
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(hits, dOut.ptr, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost));
+    return SLRHIP_OK;
+}
+
+// Measurement: closest-hit queries on device-resident rays, repeated and timed with HIP events, under one of the two lane
+// mappings (0: one lane per ray, pt_trace.hip's batch kernel; 1: four lanes per ray, pt_trace_quad.hip).
+int slrhip_trace_rays_timed(slrhip_ctx* ctx, const float* rays, uint32_t n, float* hits, int32_t mapping, uint32_t repeats, float* avgMs) {
+    if (!ctx || !rays || !hits || !avgMs) return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_trace_rays_timed: null argument");
+    if (!ctx->haveScene) return fail(SLRHIP_ERR_NO_SCENE, "slrhip_trace_rays_timed: no scene uploaded");
+    if (mapping != 0 && mapping != 1) return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_trace_rays_timed: mapping is 0 (lane per ray) or 1 (four lanes per ray)");
+    if (mapping == 1 && ctx->quadNodes.count <= 1) return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_trace_rays_timed: mapping 1 needs SLRHIP_FLAG_QUAD_LAYOUT at slrhip_create");
+    if (n == 0 || repeats == 0) return SLRHIP_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    std::vector<float4> org(n), dir(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        const float* r = rays + (size_t)i * 8;
+        org[i] = make_float4(r[0], r[1], r[2], r[6]);
+        dir[i] = make_float4(r[3], r[4], r[5], r[7]);
+    }
+    DevArray<float4> dOrg, dDir, dOut;
+    HIP_TRY(dOrg.upload(org));
+    HIP_TRY(dDir.upload(dir));
+    HIP_TRY(dOut.alloc(n));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    auto launch = [&] {
+        if (mapping == 0) launchTraceBatch(ctx->scene, dOrg.ptr, dDir.ptr, dOut.ptr, n, nullptr);
+        else launchTraceQuad(ctx->quadNodes.ptr, ctx->quadPackets.ptr, dOrg.ptr, dDir.ptr, dOut.ptr, n, nullptr);
+    };
+    launch();                                  // warm-up (caches, code object)
+    HIP_TRY(hipEventRecord(e0, nullptr));
+    for (uint32_t r = 0; r < repeats; ++r) launch();
+    HIP_TRY(hipEventRecord(e1, nullptr));
+    HIP_TRY(hipEventSynchronize(e1));
+    HIP_TRY(hipGetLastError());
+    float ms = 0.0f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    *avgMs = ms / (float)repeats;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    HIP_TRY(hipMemcpy(hits, dOut.ptr, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost));
+    return SLRHIP_OK;
+}
+
+// Diagnostic: the extension rays stored in path slots [first, first + n) (after a render: each slot's last ray).
+int slrhip_debug_read_rays(slrhip_ctx* ctx, uint32_t first, uint32_t n, float* rays) {
+    if (!ctx || !rays) return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_debug_read_rays: null argument");
+    if (!ctx->haveRender || (uint64_t)first + n > ctx->params.numSlots) return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_debug_read_rays: slot range out of bounds");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipDeviceSynchronize());
+    std::vector<float4> org(n), dir(n);
+    HIP_TRY(hipMemcpy(org.data(), ctx->rayOrg.ptr + first, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(dir.data(), ctx->rayDir.ptr + first, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < n; ++i) {
+        float* r = rays + (size_t)i * 8;
+        r[0] = org[i].x; r[1] = org[i].y; r[2] = org[i].z; r[3] = dir[i].x; r[4] = dir[i].y; r[5] = dir[i].z; r[6] = org[i].w; r[7] = dir[i].w;
+    }
     return SLRHIP_OK;
 }
 

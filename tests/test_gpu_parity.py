@@ -315,23 +315,39 @@ def test_two_contexts_on_non_blocking_streams_from_two_threads(oracle_rgb):
     its own host thread on its own NON-BLOCKING stream, the first render call of one of them starting at pass k > 0.  The
     cause was render_begin's null-stream memset of the queue counters racing k_reset_slots on the non-blocking stream
     (DESIGN.md); each half is checked against the oracle, and their Kahan-free sum against the full render."""
+    import ctypes as C
     import threading
-    import torch
+    # Non-blocking streams from the HIP runtime libslrhip.so itself is linked against — by its full path: torch ships a second
+    # copy of the runtime (imported by other test modules at collection), and a bare "libamdhip64.so" may resolve to that copy,
+    # which then reports hipErrorNoDevice
+    import re
+    from slr_amd import binding
+    binding.load_library()
+    paths = set(re.findall(r"(/\S*rocm\S*/libamdhip64\.so\S*)", open("/proc/self/maps").read()))
+    assert len(paths) == 1, paths
+    hip = C.CDLL(paths.pop())
+    hip.hipStreamCreateWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_uint]
+    hip.hipStreamDestroy.argtypes = [C.c_void_p]
+
+    def non_blocking_stream():
+        s = C.c_void_p()
+        assert hip.hipStreamCreateWithFlags(C.byref(s), 1) == 0       # hipStreamNonBlocking
+        return s
     sc = scenes.cornell_box_spheres(1.0, 24, 12, "matte")
     st = ob.settings(256, 192, seed=5)
     SPP = 32
     o = oracle_rgb.scene(sc)
     halves = [o.render(st, SPP // 2, spp_begin=i * SPP // 2)[0].copy() for i in range(2)]
     for attempt in range(3):
-        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
         ctxs = [Context(stripes=4), Context(stripes=4)]
+        streams = [non_blocking_stream(), non_blocking_stream()]
         got, errors = [None, None], []
 
         def work(i):
             try:
                 ctxs[i].upload_scene(sc)
                 ctxs[i].render_begin(st)
-                ctxs[i].render(i * SPP // 2, SPP // 2, streams[i].cuda_stream)
+                ctxs[i].render(i * SPP // 2, SPP // 2, streams[i])
                 got[i] = ctxs[i].read_framebuffer()
             except Exception as e:
                 errors.append(e)
@@ -339,9 +355,52 @@ def test_two_contexts_on_non_blocking_streams_from_two_threads(oracle_rgb):
         [t.start() for t in th]
         [t.join() for t in th]
         [c.close() for c in ctxs]
+        [hip.hipStreamDestroy(s_) for s_ in streams]
         assert not errors, errors
         for i in range(2):
             assert np.allclose(got[i], halves[i], rtol=2e-6, atol=1e-9), "context %d, attempt %d" % (i, attempt)
+
+
+def test_four_lanes_per_ray_mapping_returns_the_same_hits(oracle_rgb):
+    """The lane-mapping experiment (pt_trace_quad.hip: four lanes = one ray, one child box / one leaf triangle per lane) is only
+    a fair experiment if it answers the same question: on the reference's golden rays, on 200 000 real secondary rays of a
+    render (every slot's last extension ray) and on the displaced grid, its hits equal the lane-per-ray kernel's bit for bit
+    — t, both barycentrics and the triangle the tie rule picks — and the golden's."""
+    for name, make in (("rgb_cornell_glass", None), ("grid", lambda: scenes.displaced_grid(160, 16.0 / 9.0))):
+        c = Context(stripes=4, flags=abi.FLAG_QUAD_LAYOUT)
+        try:
+            if make is None:
+                g = load_golden(name)
+                sc = scene_from_golden(g)
+                r = g["rays"]
+                rays = np.concatenate([r["org"], r["dir"], r["dist_min"][:, None], r["dist_max"][:, None]], axis=1).astype(np.float32)
+            else:
+                sc, rays = make(), np.zeros((0, 8), np.float32)
+            st = ob.settings(320, 200, seed=3)
+            c.upload_scene(sc)
+            c.render_begin(st)
+            c.render(0, 8)
+            slot_rays = c.read_slot_rays(0, 200_000)
+            slot_rays = slot_rays[np.isfinite(slot_rays[:, :7]).all(axis=1) & (np.abs(slot_rays[:, 3:6]).sum(axis=1) > 0)]
+            rays = np.concatenate([rays, slot_rays])
+            lane, _ = c.trace_rays_timed(rays, 0, repeats=1)
+            quad, _ = c.trace_rays_timed(rays, 1, repeats=1)
+            assert (lane.view(np.uint32) == quad.view(np.uint32)).all(), name
+            assert (lane[:, 0].view(np.uint32) != 0xFFFFFFFF).mean() > 0.02       # (most last rays of the open grid scene leave it)
+            if make is None:
+                want = g["hits"]
+                assert (quad[:len(want), 0].view(np.uint32) == want["triangle"]).all()
+                hit = want["triangle"] != 0xFFFFFFFF
+                assert_bit_equal(quad[:len(want), 1][hit], want["dist"][hit], "quad dist vs golden")
+        finally:
+            c.close()
+    with pytest.raises(Exception, match="QUAD_LAYOUT"):
+        ctx2 = Context()
+        try:
+            ctx2.upload_scene(scenes.tiny_box(1.0))
+            ctx2.trace_rays_timed(np.zeros((4, 8), np.float32) + 1, 1)
+        finally:
+            ctx2.close()
 
 
 def test_errors_are_loud(ctx):
