@@ -263,6 +263,7 @@ typedef struct slrhip_counters {
     uint64_t bvh_nodes;          /* 4-wide nodes in the flattened tree                       */
     uint64_t bvh_depth;
     double   build_seconds;      /* host BVH build + upload                                  */
+    uint64_t bvh_leaf_references;/* triangles referenced from leaves: = triangle count, or more with spatial splits */
 } slrhip_counters;
 
 /* ---- per-kernel timing and traversal statistics (measurement) ------------- */
@@ -284,6 +285,10 @@ typedef struct slrhip_profile {
 } slrhip_profile;
 
 /* config.flags */
+#define SLRHIP_FLAG_BVH_SPATIAL_SPLITS 64u /* build the tree with spatial splits (sbvh.cpp; the reference's SBVH, Accelerator/SBVH.h:57-348):
+                                         * a triangle straddling a split plane is referenced from both sides with clipped boxes.
+                                         * Same hits; fewer triangle tests, more node visits: measured slower with these kernels on
+                                         * every BASELINE scene, so the object-split SAH tree stays the default          */
 #define SLRHIP_FLAG_QUAD_LAYOUT   32u   /* also build the four-lanes-per-ray node / leaf layouts at slrhip_upload_scene
                                          * (slrhip_trace_rays_timed, mapping 1): the lane-mapping experiment of DESIGN.md   */
 #define SLRHIP_FLAG_TEST_DEVICE_ERROR 16u /* test hook: the next slrhip_render raises the device-side error word, so that the

@@ -72,7 +72,7 @@ class Config(C.Structure):
 class Counters(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("extension_rays", C.c_uint64), ("shadow_rays", C.c_uint64),
                 ("iterations", C.c_uint64), ("bvh_nodes", C.c_uint64), ("bvh_depth", C.c_uint64),
-                ("build_seconds", C.c_double)]
+                ("build_seconds", C.c_double), ("bvh_leaf_references", C.c_uint64)]
 
 
 class Profile(C.Structure):
@@ -80,7 +80,7 @@ class Profile(C.Structure):
                 ("nodes", C.c_uint64 * 2), ("triangles", C.c_uint64 * 2), ("slot_visits", C.c_uint64)]
 
 
-FLAG_TIME_KERNELS, FLAG_COUNT_TRAVERSAL, FLAG_TRACE_BATCH, FLAG_SPECTRAL_QUAD, FLAG_TEST_DEVICE_ERROR, FLAG_QUAD_LAYOUT = 1, 2, 4, 8, 16, 32
+FLAG_TIME_KERNELS, FLAG_COUNT_TRAVERSAL, FLAG_TRACE_BATCH, FLAG_SPECTRAL_QUAD, FLAG_TEST_DEVICE_ERROR, FLAG_QUAD_LAYOUT, FLAG_BVH_SPATIAL_SPLITS = 1, 2, 4, 8, 16, 32, 64
 MAX_STRIPES = 64
 KERNEL_NAMES = ("trace_closest", "trace_shadow", "shade", "regen")
 

@@ -14,6 +14,7 @@
 #include <stdlib.h>
 
 #include <chrono>
+#include <string>
 
 #include <algorithm>
 #include <atomic>
@@ -26,8 +27,6 @@
 #include <thread>
 
 namespace slrhip {
-namespace {
-
 unsigned hostThreads() {
     unsigned nt = std::thread::hardware_concurrency();
     cpu_set_t set;
@@ -36,23 +35,7 @@ unsigned hostThreads() {
     return nt > 32 ? 32 : nt;
 }
 
-struct Box {
-    float lo[3], hi[3];
-    void reset() { for (int a = 0; a < 3; ++a) { lo[a] = INFINITY; hi[a] = -INFINITY; } }
-    void grow(const Box& b) { for (int a = 0; a < 3; ++a) { lo[a] = std::fmin(lo[a], b.lo[a]); hi[a] = std::fmax(hi[a], b.hi[a]); } }
-    void grow(const float* p) { for (int a = 0; a < 3; ++a) { lo[a] = std::fmin(lo[a], p[a]); hi[a] = std::fmax(hi[a], p[a]); } }
-    float area() const {
-        float d[3] = {hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]};
-        if (d[0] < 0 || d[1] < 0 || d[2] < 0) return 0.0f;
-        return 2.0f * (d[0] * d[1] + d[1] * d[2] + d[2] * d[0]);
-    }
-};
-
-struct BNode {
-    Box box;
-    uint32_t left, right;    // children (inner)
-    uint32_t first, count;   // primitive range (leaf: count > 0)
-};
+namespace {
 
 struct Builder {
     const std::vector<Box>& primBox;
@@ -262,7 +245,7 @@ void quantizeNodes(QBVH* out) {
     for (std::thread& th : pool) th.join();
 }
 
-int buildQBVH(const slrhip_vertex* verts, const slrhip_triangle* tris, uint32_t numTris, QBVH* out) {
+int buildQBVH(const slrhip_vertex* verts, const slrhip_triangle* tris, uint32_t numTris, QBVH* out, bool spatialSplits) {
     if (!verts || !tris || numTris == 0 || numTris > kLeafIndexMask) return 1;
     std::vector<Box> primBox(numTris);
     for (uint32_t i = 0; i < numTris; ++i) {
@@ -270,9 +253,29 @@ int buildQBVH(const slrhip_vertex* verts, const slrhip_triangle* tris, uint32_t 
         for (int k = 0; k < 3; ++k) primBox[i].grow(verts[tris[i].v[k]].position);
     }
     auto tA = std::chrono::steady_clock::now();
-    Builder b(primBox);
-    auto tB = std::chrono::steady_clock::now();
-    b.build();
+    // Binary tree: binned SAH over object partitions (default), or with spatial splits (sbvh.cpp; SLRHIP_BVH=sbvh, reference budget
+    // SLRHIP_SBVH_BUDGET x the triangle count, default 1.3).  Both feed the same 4-wide collapse below.
+    struct Binary { std::vector<BNode> nodes; std::vector<uint32_t> prims; } b;
+    static const bool envSbvh = [] { const char* e = getenv("SLRHIP_BVH"); return e && std::string(e) == "sbvh"; }();
+    const bool useSbvh = spatialSplits || envSbvh;
+    auto tB = tA;
+    if (useSbvh) {
+        const char* e = getenv("SLRHIP_SBVH_BUDGET");
+        SbvhStats st;
+        buildBinarySBVH(verts, tris, numTris, e ? (float)atof(e) : 1.3f, &b.nodes, &b.prims, &st);
+        out->spatialSplits = st.spatialSplits;
+        out->references = st.references;
+        if (getenv("SLRHIP_BVH_TIMING"))
+            fprintf(stderr, "sbvh: %llu spatial + %llu object splits, %llu references for %u triangles, binary depth %u\n",
+                    (unsigned long long)st.spatialSplits, (unsigned long long)st.objectSplits, (unsigned long long)st.references, numTris, st.depth);
+    }
+    else {
+        Builder sah(primBox);
+        tB = std::chrono::steady_clock::now();
+        sah.build();
+        b.nodes.swap(sah.nodes);
+        b.prims.swap(sah.prims);
+    }
     auto tC = std::chrono::steady_clock::now();
     if (getenv("SLRHIP_BVH_TIMING")) fprintf(stderr, "bvh: boxes+centroids %.2f s, binary build %.2f s\n",
         std::chrono::duration<double>(tB - tA).count(), std::chrono::duration<double>(tC - tB).count());

@@ -125,6 +125,7 @@ struct slrhip_ctx {
     DevArray<float> pointUV, pointSpectrum;
     DevScene scene;
     uint32_t bvhDepth = 0;
+    uint64_t bvhLeafRefs = 0;
     double buildSeconds = 0.0;
 
     // render state
@@ -363,7 +364,7 @@ int slrhip_upload_scene(slrhip_ctx* ctx, const slrhip_scene_desc* d) {
 
     // --- accelerator -------------------------------------------------------------------------------
     QBVH bvh;
-    if (buildQBVH(d->vertices, d->triangles, d->num_triangles, &bvh) != 0)
+    if (buildQBVH(d->vertices, d->triangles, d->num_triangles, &bvh, (ctx->config.flags & SLRHIP_FLAG_BVH_SPATIAL_SPLITS) != 0) != 0)
         return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: BVH build failed");
     if (3 * bvh.depth + 1 > 64)
         return fail(SLRHIP_ERR_UNSUPPORTED, "slrhip_upload_scene: tree deeper than the 64-entry traversal stack (QBVH.h:299)");
@@ -565,6 +566,7 @@ int slrhip_upload_scene(slrhip_ctx* ctx, const slrhip_scene_desc* d) {
     sc.envRowPDF = ctx->envRowPDF.ptr; sc.envRowCDF = ctx->envRowCDF.ptr;
     sc.camera = cam;
     ctx->bvhDepth = bvh.depth;
+    ctx->bvhLeafRefs = bvh.leafTris.size();
     ctx->haveScene = true;
     ctx->haveRender = false;
     ctx->buildSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -893,6 +895,7 @@ int slrhip_get_counters(slrhip_ctx* ctx, slrhip_counters* out) {
     std::memset(out, 0, sizeof(*out));
     out->bvh_nodes = ctx->nodes.count;
     out->bvh_depth = ctx->bvhDepth;
+    out->bvh_leaf_references = ctx->bvhLeafRefs;
     out->build_seconds = ctx->buildSeconds;
     out->iterations = ctx->iterations;
     if (ctx->haveRender) {

@@ -403,6 +403,37 @@ def test_four_lanes_per_ray_mapping_returns_the_same_hits(oracle_rgb):
             ctx2.close()
 
 
+def test_spatial_split_tree_gives_the_same_image(oracle_rgb):
+    """the tree built with spatial splits (sbvh.cpp: the reference's SBVH, Accelerator/SBVH.h:57-348 — references
+    duplicated across split planes with clipped boxes, Surface/TriangleMesh.cpp:19-125) is another tree over the same triangles:
+    frame, ray counts and closest hits must equal the object-split tree's and the oracle's bit for bit, it must actually contain
+    duplicated references on this scene (the walls' two-triangle quads span the whole box), and test fewer triangles per ray."""
+    sc = scenes.cornell_box_spheres(4.0 / 3.0, 32, 16, "glass")
+    st = ob.settings(160, 120, seed=12)
+    want, ctr = oracle_rgb.scene(sc).render(st, 8)
+    g = load_golden("rgb_cornell_glass")
+    out = {}
+    for name, flags in (("sah", abi.FLAG_COUNT_TRAVERSAL), ("sbvh", abi.FLAG_COUNT_TRAVERSAL | abi.FLAG_BVH_SPATIAL_SPLITS)):
+        c = Context(stripes=1, flags=flags)
+        try:
+            fb = c.render_image(sc, st, 8)
+            k, p = c.counters(), c.profile()
+            out[name] = (fb, int(k.extension_rays), int(k.shadow_rays), int(k.bvh_leaf_references), p.triangles[0] / p.rays[0], p.nodes[0] / p.rays[0])
+            c.upload_scene(scene_from_golden(g))
+            r = g["rays"]
+            tri, dist, b0, b1 = c.trace_rays(r["org"], r["dir"], r["dist_min"], r["dist_max"])
+            assert (tri == g["hits"]["triangle"]).all(), name
+            hit = g["hits"]["triangle"] != 0xFFFFFFFF
+            assert_bit_equal(dist[hit], g["hits"]["dist"][hit], name + " dist")
+        finally:
+            c.close()
+    assert_bit_equal(out["sah"][0], want, "object-split tree vs oracle")
+    assert_bit_equal(out["sbvh"][0], want, "spatial-split tree vs oracle")
+    assert out["sah"][1:3] == out["sbvh"][1:3] == (int(ctr.extension_rays), int(ctr.shadow_rays))
+    assert out["sah"][3] == len(sc.triangles) and out["sbvh"][3] > len(sc.triangles)
+    assert out["sbvh"][4] < out["sah"][4]            # triangles tested per extension ray
+
+
 def test_errors_are_loud(ctx):
     import ctypes as C
     from slr_amd.binding import SlrHipError
