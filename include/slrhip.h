@@ -24,9 +24,11 @@
 extern "C" {
 #endif
 
-#define SLRHIP_VERSION 4   /* 2: slrhip_material::param2, slrhip_scene_desc::upsampling, Ward / Ashikhmin lobes;
+#define SLRHIP_VERSION 5   /* 2: slrhip_material::param2, slrhip_scene_desc::upsampling, Ward / Ashikhmin lobes;
                             * 3: SLRHIP_MATERIAL_MULTI, slrhip_bsdf_queries (additive: version-2 callers are unaffected);
-                            * 4: stripes > 64 rejected, device error word, samples counted on the device (additive) */
+                            * 4: stripes > 64 rejected, device error word, samples counted on the device (additive);
+                            * 5: slrhip_texture (checkerboard textures, bump, alpha), appended to slrhip_scene_desc; host spectrum
+                            *    construction; slrhip_reduce_framebuffer                                                        */
 
 /* ---- status codes -------------------------------------------------------------- */
 enum {
@@ -144,14 +146,39 @@ enum {
 #define SLRHIP_MULTI_INVERSE_1 2
 typedef struct slrhip_material {
     uint32_t type;
-    int32_t spectrum[3];   /* indices into slrhip_scene_desc::spectra, -1 = unused          */
+    int32_t spectrum[3];   /* indices into slrhip_scene_desc::spectra, -1 = unused, SLRHIP_TEXTURE_REF(t) = texture t */
     float param;
     /* EmitterSurfaceMaterial(mat, DiffuseEmission(emittance)) surface_material.h:55-69,
      * DiffuseEmission.cpp:15-21: index of the emittance spectrum, or -1 if not emitting. */
     int32_t emittance;
     float param2;          /* second scalar of the anisotropic lobes (Ward anisoY, Ashikhmin nv), else 0 */
-    uint32_t reserved;
+    uint32_t reserved;     /* 0, or SLRHIP_MATERIAL_NORMAL_MAP(t) | SLRHIP_MATERIAL_ALPHA_MAP(t') */
 } slrhip_material;
+
+/* ---- textures ------------------------------------------------------- */
+/* The procedural textures the reference's libSLR itself holds (Textures/checker_board_textures.{h,cpp}), evaluated per hit at
+ * the hit's texture coordinate (Triangle::intersect interpolates it from the ORIGINAL barycentrics, TriangleMesh.cpp:160-161)
+ * through a Texture2DMapping (Core/textures.h:16-42): (u, v) -> ((u + offset[0]) * scale[0], (v + offset[1]) * scale[1]);
+ * offset 0 / scale 1 is the default mapping.
+ *   CHECKER_SPECTRUM  CheckerBoardSpectrumTexture: spectrum[((int)(2 x) + (int)(2 y)) % 2]           checker_board_textures.h:15-27
+ *   CHECKER_FLOAT     CheckerBoardFloatTexture:    value[...same index...]                           :43-53
+ *   CHECKER_NORMAL    CheckerBoardNormal3DTexture(stepWidth = value[0], reverse = value[1] != 0)     checker_board_textures.cpp:16-43
+ * A material's spectrum slot refers to a texture with SLRHIP_TEXTURE_REF(t); its normal map (BumpSingleSurfaceObject,
+ * Core/SurfaceObject.cpp:123-134) and its alpha texture (Triangle::m_alphaTex, TriangleMesh.cpp:163-167: a hit where the alpha
+ * value is 0 does not occur) ride in slrhip_material::reserved, as the material group of libSLRSceneGraph/TriangleMeshNode
+ * pairs them.                                                                                                              */
+enum { SLRHIP_TEXTURE_CHECKER_SPECTRUM = 0, SLRHIP_TEXTURE_CHECKER_FLOAT = 1, SLRHIP_TEXTURE_CHECKER_NORMAL = 2 };
+typedef struct slrhip_texture {
+    uint32_t kind;
+    float offset[2];
+    float scale[2];
+    int32_t spectrum[2];       /* CHECKER_SPECTRUM: indices into slrhip_scene_desc::spectra                    */
+    float value[2];            /* CHECKER_FLOAT: the two values; CHECKER_NORMAL: stepWidth in (0, 1], reverse   */
+    uint32_t reserved[3];
+} slrhip_texture;
+#define SLRHIP_TEXTURE_REF(t) (-2 - (int32_t)(t))              /* value of slrhip_material::spectrum[k] naming texture t */
+#define SLRHIP_MATERIAL_NORMAL_MAP(t) ((uint32_t)(t) + 1u)      /* OR into slrhip_material::reserved: bits 0..15  */
+#define SLRHIP_MATERIAL_ALPHA_MAP(t) (((uint32_t)(t) + 1u) << 16)   /* bits 16..31                              */
 
 /* ---- camera ---------------------------------------------------------------------- */
 /* SLR::PerspectiveCamera (libSLR/Cameras/PerspectiveCamera.cpp:15-24) with its
@@ -219,6 +246,8 @@ typedef struct slrhip_scene_desc {
     slrhip_camera camera;
     const slrhip_envmap* env;     /* NULL = no environment sphere (Scene::build envSphere = nullptr) */
     const slrhip_upsampling_tables* upsampling;   /* needed only with an environment map in spectral mode, else may be NULL */
+    const slrhip_texture* textures;               /* NULL / 0 = no textured material (version 5)                             */
+    uint32_t num_textures;
 } slrhip_scene_desc;
 
 /* ---- render settings -------------------------------------------------------------- */

@@ -304,9 +304,10 @@ struct Isect {             // Core/geometry.h:206-221 (fields the path uses)
     V3 p;
     V3 gNormal;
     float u, v;
+    float texU, texV;      // Intersection::texCoord (TriangleMesh.cpp:160-161,174)
     uint32_t tri;
     bool atInfinity;
-    Isect() : dist(INFINITY), u(0), v(0), tri(0xFFFFFFFFu), atInfinity(false) {}
+    Isect() : dist(INFINITY), u(0), v(0), texU(0), texV(0), tri(0xFFFFFFFFu), atInfinity(false) {}
 };
 
 struct SurfPt {            // Core/geometry.h:239-258
@@ -316,7 +317,7 @@ struct SurfPt {            // Core/geometry.h:239-258
     float u, v;
     Frame frame;
     uint32_t tri;          // obj; kEnvObject = the environment sphere
-    float texU, texV;      // texCoord (only the environment texture reads it)
+    float texU, texV;      // texCoord: the environment texture and the checkerboard textures read it
 };
 static const uint32_t kEnvObject = 0xFFFFFFFEu;
 
@@ -342,6 +343,7 @@ struct slr_oracle_scene {
     std::vector<slrhip_material> materials;
     std::vector<slrhip_spectrum> spectra;
     std::vector<float> spectrumData;
+    std::vector<slrhip_texture> textures;
     Camera camera;
     std::vector<uint32_t> lightTris;   // SurfaceObjectAggregate::m_lightList (SurfaceObject.cpp:232-249)
     Discrete1D lightDist;              // m_lightDist1D
@@ -442,6 +444,46 @@ inline bool boxHit(const BVHNode& nd, const Ray& r, V3 invDir) {
 // Surface/TriangleMesh.cpp:131-178  Triangle::intersect (Moller-Trumbore, no culling).
 // Returns true and fills *isect when the hit is accepted under the closest-hit rule;
 // ties at equal distance: larger triangle index wins (see file header).
+// ---- procedural textures: Textures/checker_board_textures.{h,cpp} through a Texture2DMapping (Core/textures.h:16-42) ---------
+inline void textureMap(const slrhip_texture& t, float u, float v, float* x, float* y) {
+    *x = (u + t.offset[0]) * t.scale[0];           // OffsetAndScale2DMapping::map :37-41 (offset 0, scale 1 = Texture2DMapping::map)
+    *y = (v + t.offset[1]) * t.scale[1];
+}
+inline int checkerIndex(const slrhip_texture& t, float u, float v) {
+    float x, y;
+    textureMap(t, u, v, &x, &y);
+    int idx = ((int)(x * 2) + (int)(y * 2)) % 2;   // checker_board_textures.h:23,49
+    return idx < 0 ? -idx : idx;                   // (the reference indexes its two-element array with -1 there: undefined)
+}
+// CheckerBoardNormal3DTexture::evaluate, checker_board_textures.cpp:16-43
+inline V3 checkerNormal(const slrhip_texture& t, float u, float v) {
+    float x, y;
+    textureMap(t, u, v, &x, &y);
+    const float stepWidth = t.value[0];
+    const bool reverse = t.value[1] != 0.0f;
+    float halfWidth = stepWidth * 0.5f;
+    float uComp = 0.0f;
+    float absWrapU = std::fmod(std::fabs(x), 1.0f);
+    if (absWrapU < halfWidth * 0.5f || absWrapU > 1.0f - halfWidth * 0.5f) uComp = 1.0f;
+    else if (absWrapU > 0.5f - halfWidth * 0.5f && absWrapU < 0.5f + halfWidth * 0.5f) uComp = -1.0f;
+    float vComp = 0.0f;
+    float absWrapV = std::fmod(std::fabs(y), 1.0f);
+    if (absWrapV < halfWidth * 0.5f || absWrapV > 1.0f - halfWidth * 0.5f) vComp = 1.0f;
+    else if (absWrapV > 0.5f - halfWidth * 0.5f && absWrapV < 0.5f + halfWidth * 0.5f) vComp = -1.0f;
+    if (absWrapV > 0.5f) uComp *= -1;
+    if (absWrapU > 0.5f) vComp *= -1;
+    if (reverse) { uComp *= -1; vComp *= -1; }
+    return normalize(V3(uComp, vComp, 1.0f));
+}
+inline const slrhip_texture* normalMapOf(const Scene& s, const slrhip_material& m) {
+    const uint32_t t = m.reserved & 0xFFFFu;
+    return t ? &s.textures[t - 1] : nullptr;
+}
+inline const slrhip_texture* alphaMapOf(const Scene& s, const slrhip_material& m) {
+    const uint32_t t = m.reserved >> 16;
+    return t ? &s.textures[t - 1] : nullptr;
+}
+
 inline bool triIntersect(const Scene& s, uint32_t ti, const Ray& ray, Isect* isect) {
     const Tri& tri = s.tris[ti];
     V3 p0 = vpos(s, tri.v[0]), p1 = vpos(s, tri.v[1]), p2 = vpos(s, tri.v[2]);
@@ -461,6 +503,17 @@ inline bool triIntersect(const Scene& s, uint32_t ti, const Ray& ray, Isect* ise
     if (tt < ray.distMin || tt > ray.distMax) return false;
     if (tt == ray.distMax && isect->tri != 0xFFFFFFFFu && ti < isect->tri) return false;  // tie rule
     float b0 = 1.0f - b1 - b2;
+    // TexCoord2D texCoord = b0 * v0.texCoord + b1 * v1.texCoord + b2 * v2.texCoord  (:160-161), from the ORIGINAL barycentrics
+    const float* tc0 = s.vertices[tri.v[0]].texcoord;
+    const float* tc1 = s.vertices[tri.v[1]].texcoord;
+    const float* tc2 = s.vertices[tri.v[2]].texcoord;
+    const float texU = (b0 * tc0[0] + b1 * tc1[0]) + b2 * tc2[0];
+    const float texV = (b0 * tc0[1] + b1 * tc1[1]) + b2 * tc2[1];
+    // "If zero, intersection doesn't occur" (:162-167)
+    if (const slrhip_texture* alpha = alphaMapOf(s, s.materials[tri.material]))
+        if (alpha->value[checkerIndex(*alpha, texU, texV)] == 0.0f) return false;
+    isect->texU = texU;
+    isect->texV = texV;
     isect->dist = tt;
     isect->p = ray.org + ray.dir * tt;
     isect->gNormal = normalize(cross(edge01, edge02));
@@ -607,7 +660,7 @@ template <> Spec<3> envEmittanceT<3>(const Scene& s, float u, float v, const Wls
 template <> Spec<16> envEmittanceT<16>(const Scene& s, float u, float v, const Wls<16>& wls) { return envEmittance16(s, u, v, wls); }
 
 // Surface/TriangleMesh.cpp:180-215  Triangle::getSurfacePoint (+ SingleSurfaceObject :60-63).
-// texCoord / texCoord0Dir are not restated: no texture or anisotropic lobe on this path reads them.
+// texCoord0Dir is not restated: no lobe on this path reads it.
 void getSurfacePoint(const Scene& s, const Isect& isect, SurfPt* sp) {
     if (isect.tri == kEnvObject) {
         // InfiniteSphere::getSurfacePoint, Surface/InfiniteSphere.cpp:48-59; texCoord from intersect :43
@@ -640,6 +693,20 @@ void getSurfacePoint(const Scene& s, const Isect& isect, SurfPt* sp) {
         sp->frame.x = normalize(sp->frame.x - dotNT * sp->frame.z);
     sp->frame.y = cross(sp->frame.z, sp->frame.x);
     sp->tri = isect.tri;
+    sp->texU = isect.texU;
+    sp->texV = isect.texV;
+    // BumpSingleSurfaceObject::getSurfacePoint, Core/SurfaceObject.cpp:123-134
+    if (const slrhip_texture* nm = normalMapOf(s, s.materials[tri.material])) {
+        V3 nLocal = checkerNormal(*nm, sp->texU, sp->texV);
+        V3 tLocal = V3(1, 0, 0) - dot(nLocal, V3(1, 0, 0)) * nLocal;
+        V3 bLocal = V3(0, 1, 0) - dot(nLocal, V3(0, 1, 0)) * nLocal;
+        V3 t = normalize(sp->frame.fromLocal(tLocal));
+        V3 b = normalize(sp->frame.fromLocal(bLocal));
+        V3 n = normalize(sp->frame.fromLocal(nLocal));
+        sp->frame.x = t;
+        sp->frame.y = b;
+        sp->frame.z = n;
+    }
 }
 
 // Surface/TriangleMesh.cpp:217-222  Triangle::area
@@ -1533,8 +1600,17 @@ float bsdfEvaluatePDF(const AnyBSDF<N>& f, const BSDFQuery<N>& q, V3 dir) {
 // SurfacePoint::createBSDF (geometry.cpp:56-58) -> SurfaceMaterial::getBSDF
 // (basic_SurfaceMaterials.cpp:15-43; EmitterSurfaceMaterial forwards to its base material,
 //  surface_material.h:65).  `scale * spectrum` with scale = 1.0f is an exact multiply.
+// A material's spectrum slot: a constant spectrum (ConstantSpectrumTexture) or, for SLRHIP_TEXTURE_REF values, a
+// CheckerBoardSpectrumTexture evaluated at the hit's texture coordinate (checker_board_textures.h:21-24).
 template <int N>
-BSDF<N> createLobe(const Scene& s, const slrhip_material& m, const Wls<N>& wls, float scale) {
+inline Spec<N> evalSlot(const Scene& s, int32_t slot, float texU, float texV, const Wls<N>& wls) {
+    if (slot >= -1) return EvalSpectrum<N>::eval(s, slot, wls);
+    const slrhip_texture& t = s.textures[-2 - slot];
+    return EvalSpectrum<N>::eval(s, t.spectrum[checkerIndex(t, texU, texV)], wls);
+}
+
+template <int N>
+BSDF<N> createLobe(const Scene& s, const slrhip_material& m, const Wls<N>& wls, float scale, float texU = 0.0f, float texV = 0.0f) {
     const uint16_t wlFlags = wls.flags;
     BSDF<N> f;
     f.kind = m.type;
@@ -1544,16 +1620,16 @@ BSDF<N> createLobe(const Scene& s, const slrhip_material& m, const Wls<N>& wls, 
     switch (m.type) {
     case SLRHIP_MATERIAL_WARD:
         f.type = DT_Reflection | DT_HighFreq;                                  // ModifiedWardDurBRDF.h:29
-        f.a = scale * EvalSpectrum<N>::eval(s, m.spectrum[0], wls);
+        f.a = scale * evalSlot<N>(s, m.spectrum[0], texU, texV, wls);
         break;
     case SLRHIP_MATERIAL_ASHIKHMIN:
         f.type = DT_Reflection | DT_HighFreq | DT_LowFreq;                     // AshikhminShirleyBRDF.h:29
-        f.a = scale * EvalSpectrum<N>::eval(s, m.spectrum[0], wls);             // scale * Rs
-        f.b = scale * EvalSpectrum<N>::eval(s, m.spectrum[1], wls);             // scale * Rd
+        f.a = scale * evalSlot<N>(s, m.spectrum[0], texU, texV, wls);             // scale * Rs
+        f.b = scale * evalSlot<N>(s, m.spectrum[1], texU, texV, wls);             // scale * Rd
         break;
     case SLRHIP_MATERIAL_MATTE:
         f.type = DT_Reflection | DT_LowFreq;                                   // basic_BSDFs.h:27, OrenNayerBRDF.h:29
-        f.a = scale * EvalSpectrum<N>::eval(s, m.spectrum[0], wls);
+        f.a = scale * evalSlot<N>(s, m.spectrum[0], texU, texV, wls);
         if (m.param >= 0.0f) {                                                 // OrenNayerBRDF.h:28-30 (double literals)
             float sigma = m.param;
             f.onA = (float)(1.0f - 0.5f * sigma * sigma / (sigma * sigma + 0.33));
@@ -1562,26 +1638,26 @@ BSDF<N> createLobe(const Scene& s, const slrhip_material& m, const Wls<N>& wls, 
         break;
     case SLRHIP_MATERIAL_MICROFACET_METAL:
         f.type = DT_Reflection | DT_HighFreq;                                  // MicrofacetBSDF.h:27-28
-        f.b = EvalSpectrum<N>::eval(s, m.spectrum[1], wls);
-        f.c = EvalSpectrum<N>::eval(s, m.spectrum[2], wls);
+        f.b = evalSlot<N>(s, m.spectrum[1], texU, texV, wls);
+        f.c = evalSlot<N>(s, m.spectrum[2], texU, texV, wls);
         break;
     case SLRHIP_MATERIAL_MICROFACET_GLASS:
         f.type = DT_Reflection | DT_Transmission | DT_HighFreq;                // MicrofacetBSDF.h:44-46
-        f.b = EvalSpectrum<N>::eval(s, m.spectrum[1], wls);
-        f.c = EvalSpectrum<N>::eval(s, m.spectrum[2], wls);
+        f.b = evalSlot<N>(s, m.spectrum[1], texU, texV, wls);
+        f.c = evalSlot<N>(s, m.spectrum[2], texU, texV, wls);
         break;
     case SLRHIP_MATERIAL_METAL:
         f.type = DT_Reflection | DT_Delta0D;                                   // basic_BSDFs.h:43
-        f.a = scale * EvalSpectrum<N>::eval(s, m.spectrum[0], wls);
-        f.b = EvalSpectrum<N>::eval(s, m.spectrum[1], wls);
-        f.c = EvalSpectrum<N>::eval(s, m.spectrum[2], wls);
+        f.a = scale * evalSlot<N>(s, m.spectrum[0], texU, texV, wls);
+        f.b = evalSlot<N>(s, m.spectrum[1], texU, texV, wls);
+        f.c = evalSlot<N>(s, m.spectrum[2], texU, texV, wls);
         break;
     case SLRHIP_MATERIAL_GLASS:
         // dispersive = !wls.lambdaSelected()  basic_SurfaceMaterials.cpp:42, basic_BSDFs.h:59-61
         f.type = DT_Reflection | DT_Transmission | DT_Delta0D | ((wlFlags & 1) ? 0u : (uint32_t)DT_Dispersive);
-        f.a = scale * EvalSpectrum<N>::eval(s, m.spectrum[0], wls);
-        f.b = EvalSpectrum<N>::eval(s, m.spectrum[1], wls);
-        f.c = EvalSpectrum<N>::eval(s, m.spectrum[2], wls);
+        f.a = scale * evalSlot<N>(s, m.spectrum[0], texU, texV, wls);
+        f.b = evalSlot<N>(s, m.spectrum[1], texU, texV, wls);
+        f.c = evalSlot<N>(s, m.spectrum[2], texU, texV, wls);
         break;
     default:
         f.type = 0;
@@ -1592,12 +1668,12 @@ BSDF<N> createLobe(const Scene& s, const slrhip_material& m, const Wls<N>& wls, 
 
 // SummedSurfaceMaterial.cpp:13-20 / MixedSurfaceMaterial.cpp:14-22 / InverseSurfaceMaterial basic_SurfaceMaterials.cpp:47-50
 template <int N>
-AnyBSDF<N> createBSDFOf(const Scene& s, const slrhip_material& m, const Wls<N>& wls) {
+AnyBSDF<N> createBSDFOf(const Scene& s, const slrhip_material& m, const Wls<N>& wls, float texU = 0.0f, float texV = 0.0f) {
     AnyBSDF<N> f;
     f.inverse[0] = f.inverse[1] = false;
     if (m.type != SLRHIP_MATERIAL_MULTI) {
         f.n = 0;
-        f.lobe[0] = createLobe<N>(s, m, wls, 1.0f);
+        f.lobe[0] = createLobe<N>(s, m, wls, 1.0f, texU, texV);
         f.lobe[1] = f.lobe[0];
         f.type = f.lobe[0].type;
         return f;
@@ -1606,14 +1682,14 @@ AnyBSDF<N> createBSDFOf(const Scene& s, const slrhip_material& m, const Wls<N>& 
     f.type = 0;
     const float scales[2] = {1.0f * m.param, 1.0f * m.param2};      // `scale * (1.0f - factor)`, `scale * factor` with scale = 1
     for (int i = 0; i < 2; ++i) {
-        f.lobe[i] = createLobe<N>(s, s.materials[m.spectrum[i]], wls, scales[i]);
+        f.lobe[i] = createLobe<N>(s, s.materials[m.spectrum[i]], wls, scales[i], texU, texV);
         f.inverse[i] = (m.spectrum[2] >> i) & 1;
         f.type |= f.inverse[i] ? dtFlip(f.lobe[i].type) : f.lobe[i].type;      // MultiBSDF::add :16, InverseBSDF ctor
     }
     return f;
 }
 template <int N>
-inline AnyBSDF<N> createBSDF(const Scene& s, const SurfPt& sp, const Wls<N>& wls) { return createBSDFOf<N>(s, s.materials[s.tris[sp.tri].material], wls); }
+inline AnyBSDF<N> createBSDF(const Scene& s, const SurfPt& sp, const Wls<N>& wls) { return createBSDFOf<N>(s, s.materials[s.tris[sp.tri].material], wls, sp.texU, sp.texV); }
 
 inline bool isEmitting(const Scene& s, uint32_t tri) { return tri == kEnvObject || s.materials[s.tris[tri].material].emittance >= 0; }
 template <int N>
@@ -2029,6 +2105,23 @@ slr_oracle_scene* slr_oracle_create(const slrhip_scene_desc* d, int mode) {
     s->materials.assign(d->materials, d->materials + d->num_materials);
     if (d->spectra) s->spectra.assign(d->spectra, d->spectra + d->num_spectra);
     if (d->spectrum_data) s->spectrumData.assign(d->spectrum_data, d->spectrum_data + d->num_spectrum_data);
+    if (d->textures) s->textures.assign(d->textures, d->textures + d->num_textures);
+    for (const slrhip_texture& t : s->textures) {              // every index a texture names must exist
+        bool ok = t.kind <= SLRHIP_TEXTURE_CHECKER_NORMAL;
+        if (ok && t.kind == SLRHIP_TEXTURE_CHECKER_SPECTRUM)
+            ok = t.spectrum[0] >= 0 && t.spectrum[1] >= 0 && (uint32_t)t.spectrum[0] < d->num_spectra && (uint32_t)t.spectrum[1] < d->num_spectra;
+        if (!ok) { delete s; return nullptr; }
+    }
+    for (uint32_t i = 0; i < d->num_materials; ++i) {          // texture references of single-lobe materials
+        const slrhip_material& m = s->materials[i];
+        bool ok = (m.reserved & 0xFFFFu) <= s->textures.size() && (m.reserved >> 16) <= s->textures.size();
+        if (ok && (m.reserved & 0xFFFFu)) ok = s->textures[(m.reserved & 0xFFFFu) - 1].kind == SLRHIP_TEXTURE_CHECKER_NORMAL;
+        if (ok && (m.reserved >> 16)) ok = s->textures[(m.reserved >> 16) - 1].kind == SLRHIP_TEXTURE_CHECKER_FLOAT;
+        for (int k = 0; k < 3 && ok && m.type != SLRHIP_MATERIAL_MULTI; ++k)
+            if (m.spectrum[k] < -1)
+                ok = (uint32_t)(-2 - m.spectrum[k]) < s->textures.size() && s->textures[-2 - m.spectrum[k]].kind == SLRHIP_TEXTURE_CHECKER_SPECTRUM;
+        if (!ok) { delete s; return nullptr; }
+    }
     for (uint32_t i = 0; i < d->num_materials; ++i) {          // the restrictions include/slrhip.h states for MULTI
         const slrhip_material& m = s->materials[i];
         if (m.type != SLRHIP_MATERIAL_MULTI) continue;

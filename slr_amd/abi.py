@@ -28,6 +28,16 @@ spectrum_dtype = np.dtype([("kind", "<u4"), ("rgb", "<f4", 3), ("u", "<f4"), ("v
                            ("data_offset", "<u4"), ("reserved", "<u4")])
 
 
+texture_dtype = np.dtype([("kind", "<u4"), ("offset", "<f4", 2), ("scale", "<f4", 2), ("spectrum", "<i4", 2), ("value", "<f4", 2),
+                          ("reserved", "<u4", 3)])
+TEX_CHECKER_SPECTRUM, TEX_CHECKER_FLOAT, TEX_CHECKER_NORMAL = 0, 1, 2
+
+
+def texture_ref(t):
+    """SLRHIP_TEXTURE_REF: the value of a material's spectrum slot that names texture t."""
+    return -2 - int(t)
+
+
 class Camera(C.Structure):
     _fields_ = [("local_to_world", C.c_float * 16), ("world_to_local", C.c_float * 16),
                 ("aspect", C.c_float), ("fov_y", C.c_float), ("lens_radius", C.c_float),
@@ -53,7 +63,8 @@ class SceneDesc(C.Structure):
                 ("spectrum_data", C.c_void_p), ("num_spectrum_data", C.c_uint32),
                 ("camera", Camera),
                 ("env", C.POINTER(EnvMap)),
-                ("upsampling", C.POINTER(UpsamplingTables))]
+                ("upsampling", C.POINTER(UpsamplingTables)),
+                ("textures", C.c_void_p), ("num_textures", C.c_uint32)]
 
 
 class RenderSettings(C.Structure):
@@ -90,7 +101,7 @@ DEFAULT_SEED = 1509761209  # libSLRSceneGraph/API.cpp:1080
 class Scene:
     """Flat scene (numpy arrays) + the ctypes view handed across the ABI."""
 
-    def __init__(self, vertices, triangles, materials, spectra, spectrum_data, camera, env=None, name="scene"):
+    def __init__(self, vertices, triangles, materials, spectra, spectrum_data, camera, env=None, name="scene", textures=None):
         self.vertices = np.ascontiguousarray(vertices, dtype=vertex_dtype)
         self.triangles = np.ascontiguousarray(triangles, dtype=triangle_dtype)
         mats = np.asarray(materials)
@@ -103,6 +114,7 @@ class Scene:
         self.spectra = np.ascontiguousarray(spectra, dtype=spectrum_dtype)
         self.spectrum_data = np.ascontiguousarray(spectrum_data, dtype=np.float32)
         self.camera = camera
+        self.textures = np.ascontiguousarray(textures if textures is not None else np.zeros(0, texture_dtype), dtype=texture_dtype)
         self.env_texels = None
         self.env = None
         self.env_uvs = None
@@ -136,6 +148,11 @@ class Scene:
         single = self.materials["type"] != MAT_MULTI      # a MULTI record's spectrum[] holds component material indices (checked by the library)
         if (single.any() and self.materials["spectrum"][single].max() >= ns) or self.materials["emittance"].max() >= ns:
             raise ValueError("material references a spectrum out of range")
+        nt = len(self.textures)
+        if single.any() and self.materials["spectrum"][single].min() < -1 - nt:
+            raise ValueError("material references a texture out of range")
+        if nt and (self.textures["spectrum"][self.textures["kind"] == TEX_CHECKER_SPECTRUM].max(initial=-1) >= ns):
+            raise ValueError("texture references a spectrum out of range")
 
     def upsampling_tables(self):
         if self._tables is None:
@@ -160,6 +177,7 @@ class Scene:
         env = self.env_uvs if (mode == MODE_SPECTRAL and self.env_uvs is not None) else self.env
         d.env = C.pointer(env) if env is not None else None
         d.upsampling = C.pointer(self.upsampling_tables()) if (env is not None and mode == MODE_SPECTRAL) else None
+        d.textures, d.num_textures = (self.textures.ctypes.data if len(self.textures) else None), len(self.textures)
         return d
 
 

@@ -56,6 +56,7 @@ class SceneBuilder:
         self.vertices, self.triangles, self.materials = [], [], []     # vertices / triangles: lists of structured-array chunks
         self.num_vertices = 0
         self.sset = spectra.SpectrumSet()     # every constant carries its RGB value and its spectral descriptor
+        self.textures = []
 
     # --- spectra (the scene language's Spectrum(...) overloads, libSLRSceneGraph/API.cpp:286-441) -------
     def spectrum_rgb(self, r, g, b, uvs=None):
@@ -82,10 +83,38 @@ class SceneBuilder:
         """Spectrum("ID": name, which): eta (0) or k (1) of spectrum_library.cpp; `rgb` is its RGB-mode value."""
         return self.sset.ior(name, which, rgb)
 
+    # --- textures (libSLR/Textures/checker_board_textures.h; mapping = OffsetAndScale2DMapping, Core/textures.h:32-42) -------
+    def _texture(self, kind, offset, scale, spectrum=(-1, -1), value=(0.0, 0.0)):
+        rec = np.zeros((), dtype=abi.texture_dtype)
+        rec["kind"], rec["offset"], rec["scale"], rec["spectrum"], rec["value"] = kind, offset, scale, spectrum, value
+        self.textures.append(rec)
+        return len(self.textures) - 1
+
+    def checker_spectrum(self, s0, s1, offset=(0.0, 0.0), scale=(1.0, 1.0)):
+        """CheckerBoardSpectrumTexture over two constant spectra; returns the VALUE to put in a material's spectrum slot."""
+        return abi.texture_ref(self._texture(abi.TEX_CHECKER_SPECTRUM, offset, scale, spectrum=(s0, s1)))
+
+    def checker_float(self, v0, v1, offset=(0.0, 0.0), scale=(1.0, 1.0)):
+        """CheckerBoardFloatTexture (texture index: use as alpha_map=)."""
+        return self._texture(abi.TEX_CHECKER_FLOAT, offset, scale, value=(v0, v1))
+
+    def checker_normal(self, step_width, reverse=False, offset=(0.0, 0.0), scale=(1.0, 1.0)):
+        """CheckerBoardNormal3DTexture (texture index: use as normal_map=)."""
+        return self._texture(abi.TEX_CHECKER_NORMAL, offset, scale, value=(step_width, 1.0 if reverse else 0.0))
+
     # --- materials -----------------------------------------------------------------
-    def material(self, mtype, spectra=(-1, -1, -1), param=-1.0, emittance=-1, param2=0.0):
+    def material(self, mtype, spectra=(-1, -1, -1), param=-1.0, emittance=-1, param2=0.0, normal_map=None, alpha_map=None):
         rec = np.zeros((), dtype=abi.material_dtype)
         rec["type"], rec["spectrum"], rec["param"], rec["emittance"], rec["param2"] = mtype, spectra, param, emittance, param2
+        rec["reserved"] = (0 if normal_map is None else normal_map + 1) | (0 if alpha_map is None else (alpha_map + 1) << 16)
+        self.materials.append(rec)
+        return len(self.materials) - 1
+
+    def with_maps(self, material, normal_map=None, alpha_map=None):
+        """A copy of `material` with a normal map (BumpSingleSurfaceObject) and / or an alpha texture (Triangle::m_alphaTex): the
+        material group of libSLRSceneGraph's TriangleMeshNode pairs a surface material with both."""
+        rec = self.materials[material].copy()
+        rec["reserved"] = (0 if normal_map is None else normal_map + 1) | (0 if alpha_map is None else (alpha_map + 1) << 16)
         self.materials.append(rec)
         return len(self.materials) - 1
 
@@ -188,7 +217,8 @@ class SceneBuilder:
         return abi.Scene(np.concatenate(self.vertices), np.concatenate(self.triangles),
                          np.array(self.materials, dtype=abi.material_dtype),
                          np.array(self.sset.records, dtype=abi.spectrum_dtype),
-                         np.array(self.sset.data, dtype=np.float32), camera, env, name)
+                         np.array(self.sset.data, dtype=np.float32), camera, env, name,
+                         textures=np.array(self.textures, dtype=abi.texture_dtype) if self.textures else None)
 
 
 # RGB-mode constants of the scene's named spectra.  In the reference these come from
@@ -239,6 +269,33 @@ def cornell_box_spheres(aspect=4.0 / 3.0, segments=48, rings=24, right="glass"):
         mat = b.matte(b.spectrum_srgb_nonlinear(0.75, 0.75, 0.25))
     b.add_uv_sphere(segments, rings, mat, _translate(0.7, 0, 0) @ _scale(0.5) @ _translate(0, 1, 0))
     return b.build(cornell_camera(aspect), name="cornell_box_spheres_" + right)
+
+
+def cornell_textured(aspect=1.0, segments=16, rings=8):
+    """SURVEY 8 row f3, the textured half: the Cornell walls with a CHECKERBOARD floor (two reflectances, 4 x 6 squares through an
+    offset-and-scale mapping), a bump-mapped Oren-Nayar sphere (CheckerBoardNormal3DTexture through BumpSingleSurfaceObject), a
+    quad in front of the back wall whose alpha texture (CheckerBoardFloatTexture 1 / 0) cuts half of its squares away, and a mirror
+    sphere whose coefficient is a checker of two greys."""
+    b = SceneBuilder()
+    red = b.matte(b.spectrum_srgb_nonlinear(0.75, 0.25, 0.25))
+    blue = b.matte(b.spectrum_srgb_nonlinear(0.25, 0.25, 0.75))
+    white = b.matte(b.spectrum_srgb_nonlinear(0.75, 0.75, 0.75))
+    floor = b.matte(b.checker_spectrum(b.spectrum_srgb_nonlinear(0.8, 0.8, 0.8), b.spectrum_srgb_nonlinear(0.2, 0.3, 0.2), (0.125, 0.0), (2.0, 3.0)))
+    b.add_quad([(-1.5, 0, 2.55), (-1.5, 0, -2.55), (-1.5, 2.5, -2.55), (-1.5, 2.5, 2.55)], (1, 0, 0), (0, 0, -1), red)
+    b.add_quad([(1.5, 0, -2.55), (1.5, 0, 2.55), (1.5, 2.5, 2.55), (1.5, 2.5, -2.55)], (-1, 0, 0), (0, 0, 1), blue)
+    b.add_quad([(-1.5, 0, 2.55), (1.5, 0, 2.55), (1.5, 0, -2.55), (-1.5, 0, -2.55)], (0, 1, 0), (1, 0, 0), floor)
+    b.add_quad([(-1.5, 0, -2.55), (1.5, 0, -2.55), (1.5, 2.5, -2.55), (-1.5, 2.5, -2.55)], (0, 0, 1), (1, 0, 0), white)
+    b.add_quad([(-1.5, 2.5, -2.55), (1.5, 2.5, -2.55), (1.5, 2.5, 2.55), (-1.5, 2.5, 2.55)], (0, -1, 0), (1, 0, 0), white)
+    light = b.matte(b.spectrum_srgb_nonlinear(0.9, 0.9, 0.9), emittance=b.spectrum_d65(4.0, D65_RGB))
+    b.add_quad([(-0.5, 2.499, -0.5), (0.5, 2.499, -0.5), (0.5, 2.499, 0.5), (-0.5, 2.499, 0.5)], (0, -1, 0), (1, 0, 0), light)
+    bumpy = b.with_maps(b.matte(b.spectrum_srgb_nonlinear(0.7, 0.6, 0.3), sigma=0.4), normal_map=b.checker_normal(0.3, False, (0.0, 0.0), (6.0, 3.0)))
+    b.add_uv_sphere(segments, rings, bumpy, _translate(0.7, 0, 0) @ _scale(0.5) @ _translate(0, 1, 0))
+    coeff = b.checker_spectrum(b.spectrum_grey(1.0), b.spectrum_grey(0.4), (0.0, 0.0), (4.0, 2.0))
+    mirror = b.metal(coeff, b.spectrum_ior("Aluminium", 0, ALUMINIUM_ETA_RGB), b.spectrum_ior("Aluminium", 1, ALUMINIUM_K_RGB))
+    b.add_uv_sphere(segments, rings, mirror, _translate(-0.7, 0, -1.05) @ _scale(0.5) @ _translate(0, 1, 0))
+    lattice = b.with_maps(b.matte(b.spectrum_srgb_nonlinear(0.3, 0.5, 0.8)), alpha_map=b.checker_float(1.0, 0.0, (0.0, 0.0), (3.0, 3.0)))
+    b.add_quad([(-1.0, 0.2, -1.9), (1.0, 0.2, -1.9), (1.0, 1.8, -1.9), (-1.0, 1.8, -1.9)], (0, 0, 1), (1, 0, 0), lattice)
+    return b.build(cornell_camera(aspect), name="cornell_textured")
 
 
 def tiny_box(aspect=1.0):

@@ -29,6 +29,8 @@ def scene_arrays(sc):
         if sc.env_uvs is not None:
             assert np.array_equal(sc.env_texels_uvs.astype(np.float16).astype(np.float32), sc.env_texels_uvs)
             env.update(env_texels_uvs=sc.env_texels_uvs.astype(np.float16), env_importance_uvs=sc.env_importance_uvs)
+    if len(sc.textures):
+        env["textures"] = sc.textures
     return dict(env, vertices=sc.vertices, triangles=sc.triangles, materials=sc.materials, spectra=sc.spectra,
                 spectrum_data=sc.spectrum_data,
                 camera=np.array(list(cam.local_to_world) + list(cam.world_to_local) +
@@ -230,6 +232,10 @@ def main_round2(only):
     lib = ob.load("ref_rgb")
     if not only or "spectral_boxes" in only:
         make("spectral_boxes", scenes.cornell_box_boxes(1.0), spec, 48, 48, 8, 2)
+    if not only or "rgb_textured" in only:
+        make("rgb_textured", scenes.cornell_textured(1.0, 12, 6), lib, 48, 48, 8, 2)
+    if not only or "spectral_textured" in only:
+        make("spectral_textured", scenes.cornell_textured(1.0, 10, 5), spec, 40, 40, 8, 2)
     if not only or "upsample_kat" in only:
         # UpsampledContinuousSpectrum(spType, space, e0, e1, e2) of the compiled reference: (u, v, scale) for every colour space
         import ctypes as C

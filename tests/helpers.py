@@ -35,7 +35,8 @@ def scene_from_golden(g, name="golden", prefix=""):
         env = (g["env_texels"].astype(np.float32), float(g["env_scale"]), g["env_importance"])
         if "env_texels_uvs" in g.files:
             env = env + (g["env_texels_uvs"].astype(np.float32), g["env_importance_uvs"])
-    return abi.Scene(g["vertices"], g["triangles"], g["materials"], g["spectra"], g["spectrum_data"], cam, env, name)
+    textures = g["textures"] if "textures" in g.files else None
+    return abi.Scene(g["vertices"], g["triangles"], g["materials"], g["spectra"], g["spectrum_data"], cam, env, name, textures=textures)
 
 
 def bits(a):

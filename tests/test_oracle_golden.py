@@ -9,7 +9,8 @@ from slr_amd import abi
 
 SCENES = ["rgb_tiny_box", "rgb_cornell_glass", "rgb_cornell_matte", "rgb_oren_nayar", "rgb_ggx_metal", "rgb_ggx_glass", "rgb_ward", "rgb_ashikhmin",
           "rgb_ibl", "rgb_ibl_area",
-          "rgb_multi", "rgb_multi_libm_free"]     # environment sphere alone / next to a triangle light (Scene::selectLight)
+          "rgb_multi", "rgb_multi_libm_free",
+          "rgb_textured"]     # checkerboard reflectance + bump-mapped sphere + alpha-cut quad     # environment sphere alone / next to a triangle light (Scene::selectLight)
 
 
 def test_rng_known_answers(oracle_rgb):
@@ -112,7 +113,7 @@ def test_rejects_bad_scene(oracle_rgb):
 
 SPECTRAL_SCENES = ["spectral_cornell_glass", "spectral_cornell_matte", "spectral_oren_nayar", "spectral_ggx_metal", "spectral_ggx_glass", "spectral_ashikhmin",
                    "spectral_ibl", "spectral_multi", "spectral_multi_libm_free",
-                   "spectral_boxes"]   # BASELINE configs[2]: Cornell_Box_Boxes-shaped, GGX titanium box, spectral build     # environment texels as (u, v, s), looked up in the Meng-15 grid at run time, + an area light
+                   "spectral_boxes", "spectral_textured"]   # BASELINE configs[2]: Cornell_Box_Boxes-shaped, GGX titanium box, spectral build     # environment texels as (u, v, s), looked up in the Meng-15 grid at run time, + an area light
 
 
 @pytest.mark.parametrize("name", SPECTRAL_SCENES)

@@ -120,3 +120,32 @@ def test_light_sampling_and_multibsdf_frames_bit_exact(request, oracle_rgb, orac
     a, _ = orc.scene(sc).render(st, 6)
     b, _ = ref.scene(sc).render(st, 6)
     assert_bit_equal(a, b, "cornell_multi " + mode)
+
+
+@pytest.mark.parametrize("mode", ["rgb", "spectral"])
+def test_textured_scene_bit_exact(request, oracle_rgb, oracle_spectral, mode):
+    """texture coordinates from the original barycentrics, CheckerBoardSpectrumTexture in a reflectance and in a
+    mirror coefficient, CheckerBoardNormal3DTexture through BumpSingleSurfaceObject, CheckerBoardFloatTexture as a triangle's
+    alpha texture — the reference's own classes (ref_shim builds them) against the restatement on a fresh size and seed:
+    frames, single samples and closest hits through the alpha-cut quad."""
+    orc = oracle_rgb if mode == "rgb" else oracle_spectral
+    ref = request.getfixturevalue("ref_" + mode)
+    sc = scenes.cornell_textured(4.0 / 3.0, 14, 7)
+    st = ob.settings(64, 48, seed=2718)
+    so, sr = orc.scene(sc), ref.scene(sc)
+    a, _ = so.render(st, 6)
+    b, _ = sr.render(st, 6)
+    assert_bit_equal(a, b, "cornell_textured " + mode)
+    rng = np.random.default_rng(5)
+    rays = np.zeros(1024, dtype=ob.ray_dtype)
+    rays["org"] = rng.uniform([-1.2, 0.2, 0.5], [1.2, 2.0, 2.4], size=(1024, 3)).astype(np.float32)
+    d = rng.normal(size=(1024, 3)) * [0.5, 0.4, 0.2] - [0, 0, 1.0]                 # towards the lattice in front of the back wall
+    rays["dir"] = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    rays["dist_max"] = np.inf
+    ho, hr = so.trace(rays), sr.trace(rays)
+    assert (ho["triangle"] == hr["triangle"]).all()
+    lattice = len(sc.triangles) - 2
+    assert (ho["triangle"] >= lattice).sum() > 30 and (ho["triangle"] < lattice).sum() > 100    # some rays pass through the holes
+    hit = hr["triangle"] != 0xFFFFFFFF
+    for f in ("dist", "b0", "b1"):
+        assert_bit_equal(ho[f][hit], hr[f][hit], f)
