@@ -386,6 +386,7 @@ int buildQBVH(const slrhip_vertex* verts, const slrhip_triangle* tris, uint32_t 
                         lt.e2[a] = p2[a] - p0[a];      // edge02, TriangleMesh.cpp:137
                     }
                     lt.tri = t;
+                    lt.alpha = kNoAlpha;               // set by slrhip_upload_scene for triangles whose material has an alpha texture
                     out->leafTris[first + k] = lt;
                 }
             }

@@ -45,9 +45,10 @@ static_assert(sizeof(QNodeQ) == 64, "QNodeQ must be half a 128-byte line");
 
 struct alignas(16) LeafTri {
     float v0[3]; uint32_t tri;
-    float e1[3]; uint32_t pad0;
+    float e1[3]; uint32_t alpha;         // index into the alpha records (Triangle::m_alphaTex, pt_tex.h), kNoAlpha = none
     float e2[3]; uint32_t pad1;
 };
+static const uint32_t kNoAlpha = 0xFFFFFFFFu;
 static_assert(sizeof(LeafTri) == 48, "LeafTri is three float4");
 
 struct alignas(16) ShadeTri {
@@ -113,6 +114,23 @@ struct alignas(16) DevSpectrum {
     uint32_t cellOffset;    // IRREGULAR: pool offset of the 472-byte search table built at upload, 0xFFFFFFFF = none
 };
 static_assert(sizeof(DevSpectrum) == 32, "DevSpectrum layout");
+
+// One slrhip_texture (checkerboard textures, pt_tex.h), 64 B = four float4; the RGB build's values of a CHECKER_SPECTRUM's two
+// spectra are resolved at upload, the spectral build reads the spectrum indices.
+struct alignas(16) DevTexture {
+    uint32_t kind; float ox, oy, sx;
+    float sy, v0, v1; int32_t spec0;
+    int32_t spec1; float rgb0[3];
+    float rgb1[3]; uint32_t pad;
+};
+static_assert(sizeof(DevTexture) == 64, "DevTexture layout");
+
+// Per material, for scenes with textures: the texture behind each spectrum slot (-1 = constant) and the normal map (-1 = none)
+struct alignas(16) DevMatTex {
+    int32_t slot[3];
+    int32_t normalMap;
+};
+static const uint32_t kMatTexturedBit = 0x100u;      // ORed into DevMaterial(S)::type when any DevMatTex field is set
 
 // PerspectiveCamera constants (PerspectiveCamera.cpp:15-24) computed on the host with the same
 // libm the reference uses, so the device never evaluates tan/pow.

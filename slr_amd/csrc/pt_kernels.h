@@ -28,6 +28,12 @@ struct DevScene {
     uint32_t lightPow2;           // prevPowerOf2(numLights)
     uint32_t hasMicrofacet;       // any SLRHIP_MATERIAL_MICROFACET_* in the scene
     uint32_t hasMulti;            // any SLRHIP_MATERIAL_MULTI: k_logic with the MultiBSDF code
+    // textures: null / 0 when the scene has none
+    const DevTexture* textures;
+    const DevMatTex* matTex;      // per material
+    const float4* triUV;          // per scene triangle: (u0, v0, u1, v1), (u2, v2, -, -)
+    const float4* alphaTris;      // per alpha record (LeafTri::alpha): the same two float4 + the alpha texture index
+    uint32_t numTextures;
     uint32_t numSpectra;
     uint32_t numSpectrumData;     // floats in spectrumPool (padded to a multiple of 4 on upload)
     // environment sphere (InfiniteSphereSurfaceObject, SurfaceObject.cpp:137-222); RGB mode
@@ -81,7 +87,7 @@ struct PathBuffers {
     uint4* rng;                   // xorshift128 state
     float4* rayOrg;               // extension / shadow ray origin, w = distMin
     float4* rayDir;               // extension ray direction, w = distMax
-    float4* hit;                  // x = triangle (bits), y = t, z = b0, w = b1
+    float4* hit;                  // x = triangle (bits), y = t, z = b1, w = b2 (Moller-Trumbore's barycentrics)
     // spectrum-valued records: RGB = one float4 per slot (scalar in .w); spectral = 4 planes of numSlots float4
     float4* alpha;                // path throughput (+ pdf of the sampled direction)
     float4* spR;                  // path radiance Kahan sum (sp) (+ camera weight)
@@ -144,7 +150,7 @@ void launchTraceBatch(const DevScene& sc, const float4* org, const float4* dir, 
 int traceBlocksPerCU();
 // four lanes per ray (pt_trace_quad.hip): the lane-mapping experiment; layouts built from the uploaded tree
 void buildQuadLayouts(const std::vector<QNode>& nodes, const std::vector<LeafTri>& leafTris, std::vector<float4>* nodes4, std::vector<float4>* packets);
-void launchTraceQuad(const float4* nodes4, const float4* packets, const float4* org, const float4* dir, float4* out, uint32_t n, hipStream_t stream);
+void launchTraceQuad(const DevScene& sc, const float4* nodes4, const float4* packets, const float4* org, const float4* dir, float4* out, uint32_t n, hipStream_t stream);
 // wave-specialised traversal (pt_trace_ws.hip): same results, ONE launch for the extension and the shadow rays of an iteration
 void launchTraceWs(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, uint32_t blocks, bool count,
                    hipStream_t stream);

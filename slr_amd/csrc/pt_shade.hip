@@ -22,7 +22,7 @@ void launchLogic(const DevScene& sc, const PathBuffers& pb, const RenderParams& 
                            (!rp.spectral || (sc.numSpectra <= (uint32_t)kLdsSpectra && sc.numSpectrumData <= (uint32_t)kLdsPoolFloats));
     // The microfacet (GGX) code costs ~45 VGPRs, so scenes without such lobes get kernels without it.
     const bool glossy = sc.hasMicrofacet != 0;
-    if (sc.hasMulti) {
+    if (sc.hasMulti || sc.numTextures) {
         // MultiBSDF scenes: one kernel per mode, tables in HBM (a component is re-read per use), all lobes compiled in
         launchLogicMulti(sc, pb, rp, parity, stream);
         return;

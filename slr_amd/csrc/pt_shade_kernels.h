@@ -27,6 +27,7 @@
 #include "pt_bsdf.h"
 #include "pt_bsdf_multi.h"
 #include "pt_kernels.h"
+#include "pt_tex.h"
 
 namespace slrhip {
 
@@ -415,7 +416,33 @@ struct ShadeLds {
 #ifndef SLR_WAVES_RGB
 #define SLR_WAVES_RGB 2
 #endif
-template <class S, bool LDS_TABLES, bool MF, bool MULTI = false>
+// A CheckerBoardSpectrumTexture behind a material's spectrum slot (checker_board_textures.h:21-24): one of its two constant
+// spectra.  RGB build: their values are in the texture record; spectral build: evaluated at the path's wavelengths like any
+// other constant (tables in HBM: textured scenes run the kernel variant without LDS tables).
+template <class S> struct TexSpectrum {
+    static __device__ __forceinline__ S eval(const DevScene& sc, const DevTexture& t, int which, float wlOffset) {
+        return evalSpectrum<S>(sc.spectra, sc.spectrumPool, which ? t.spec1 : t.spec0, wlOffset);
+    }
+};
+template <> struct TexSpectrum<RGB> {
+    static __device__ __forceinline__ RGB eval(const DevScene&, const DevTexture& t, int which, float) {
+        return which ? RGB(t.rgb1[0], t.rgb1[1], t.rgb1[2]) : RGB(t.rgb0[0], t.rgb0[1], t.rgb0[2]);
+    }
+};
+
+// Textured scenes: replaces the constants of the textured spectrum slots of material record `matIndex` by the textures' values
+// at texture coordinate (texU, texV) and returns the material's normal map (-1 = none).
+template <class S>
+__device__ __forceinline__ int32_t texturizeMat(const DevScene& sc, Mat<S>& mm, uint32_t matIndex, float texU, float texV, float wlOffset) {
+    mm.type &= ~kMatTexturedBit;
+    const int4 mt = *reinterpret_cast<const int4*>(sc.matTex + matIndex);
+    if (mt.x >= 0) { const DevTexture t = loadTexture(sc.textures, (uint32_t)mt.x); mm.a = 1.0f * TexSpectrum<S>::eval(sc, t, checkerIndex(t, texU, texV), wlOffset); }
+    if (mt.y >= 0) { const DevTexture t = loadTexture(sc.textures, (uint32_t)mt.y); mm.b = TexSpectrum<S>::eval(sc, t, checkerIndex(t, texU, texV), wlOffset); }
+    if (mt.z >= 0) { const DevTexture t = loadTexture(sc.textures, (uint32_t)mt.z); mm.c = TexSpectrum<S>::eval(sc, t, checkerIndex(t, texU, texV), wlOffset); }
+    return mt.w;
+}
+
+template <class S, bool LDS_TABLES, bool MF, bool MULTI = false, bool TEX = false>
 __global__ __launch_bounds__(kShadeBlock)
 __attribute__((amdgpu_waves_per_eu(S::N == 3 ? SLR_WAVES_RGB : (MF ? SLR_WAVES_SPECTRAL_GLOSSY : SLR_WAVES_SPECTRAL)))) void k_logic(DevScene sc, PathBuffers pb, RenderParams rp, uint32_t parity) {
     __shared__ ShadeLds<S::N != 3> lds;
@@ -526,6 +553,9 @@ __attribute__((amdgpu_waves_per_eu(S::N == 3 ? SLR_WAVES_RGB : (MF ? SLR_WAVES_S
 
             // ---- 2. the hit that just came back ------------------------------------------------------------
             Mat<S> m;
+            float texU = 0.0f, texV = 0.0f;
+            int32_t normalMap = -1;
+            const auto texturize = [&](Mat<S>& mm, uint32_t matIndex) -> int32_t { return texturizeMat<S>(sc, mm, matIndex, texU, texV, wlOffset); };
             if (!hasHit) {
                 finish = true;                      // ST_FINISH, or a miss: :148 return Zero / :226 break
                 if (state != ST_FINISH && sc.hasEnv) {
@@ -560,13 +590,37 @@ __attribute__((amdgpu_waves_per_eu(S::N == 3 ? SLR_WAVES_RGB : (MF ? SLR_WAVES_S
                 surf.light = (int32_t)__float_as_uint(q1.w);
                 surf.areaPDF = q2.w;
                 m = MatIO<S>::template load<LDS_TABLES>(sc, lds.mats, surf.material, wlOffset);
-                const float b0 = h.z, b1 = h.w;
+                // the hit record carries Moller-Trumbore's (b1, b2); Intersection::u = b0 = 1 - b1 - b2 as Triangle::intersect
+                // computes it (TriangleMesh.cpp:159), and getSurfacePoint re-derives ITS b2 from (u, v) (:190-191)
+                const float b1 = h.z, b2hit = h.w;
+                const float b0 = 1.0f - b1 - b2hit;
                 const float b2 = 1.0f - b0 - b1;
+                if constexpr (TEX) {
+                    // texCoord from the original barycentrics (TriangleMesh.cpp:160-161), then the textures of this material
+                    const float4 uvA = sc.triUV[(size_t)tri * 2], uvB = sc.triUV[(size_t)tri * 2 + 1];
+                    hitTexCoord(uvA, uvB, b1, b2hit, &texU, &texV);
+                    if (m.type & kMatTexturedBit) normalMap = texturize(m, surf.material);
+                }
                 surf.frame.z = normalize(b0 * xyz(q0) + b1 * xyz(q1) + b2 * xyz(q2));
                 surf.frame.x = normalize(b0 * xyz(q3) + b1 * xyz(q4) + b2 * xyz(q5));
                 const float dotNT = dot(surf.frame.z, surf.frame.x);
                 if (fabsf(dotNT) >= 0.01f) surf.frame.x = normalize(surf.frame.x - dotNT * surf.frame.z);
                 surf.frame.y = cross(surf.frame.z, surf.frame.x);
+                if constexpr (TEX) {
+                    if (normalMap >= 0) {
+                        // BumpSingleSurfaceObject::getSurfacePoint, Core/SurfaceObject.cpp:123-134
+                        const DevTexture nt = loadTexture(sc.textures, (uint32_t)normalMap);
+                        float uc, vc;
+                        checkerNormalComponents(nt, texU, texV, &uc, &vc);
+                        const V3 nLocal = normalize(V3(uc, vc, 1.0f));
+                        const V3 tLocal = V3(1.0f, 0.0f, 0.0f) - dot(nLocal, V3(1.0f, 0.0f, 0.0f)) * nLocal;
+                        const V3 bLocal = V3(0.0f, 1.0f, 0.0f) - dot(nLocal, V3(0.0f, 1.0f, 0.0f)) * nLocal;
+                        const V3 tt = normalize(surf.frame.fromLocal(tLocal));
+                        const V3 bb = normalize(surf.frame.fromLocal(bLocal));
+                        const V3 nn = normalize(surf.frame.fromLocal(nLocal));
+                        surf.frame.x = tt; surf.frame.y = bb; surf.frame.z = nn;
+                    }
+                }
                 haveSurf = true;
                 dirOut_sn = surf.frame.toLocal(-rayDir);
                 if (surf.light >= 0) {
@@ -605,7 +659,11 @@ __attribute__((amdgpu_waves_per_eu(S::N == 3 ? SLR_WAVES_RGB : (MF ? SLR_WAVES_S
                     V3 gNorm_sn = surf.frame.toLocal(surf.gNormal);
                     uint32_t type = bsdfType(m.type, wlSel);
                     // SLRHIP_MATERIAL_MULTI: a MultiBSDF whose components are fetched from the material table on demand
-                    const auto loadComponent = [&](uint32_t idx) { return MatIO<S>::template load<LDS_TABLES>(sc, lds.mats, idx, wlOffset); };
+                    const auto loadComponent = [&](uint32_t idx) {
+                        Mat<S> cm = MatIO<S>::template load<LDS_TABLES>(sc, lds.mats, idx, wlOffset);
+                        if constexpr (TEX) { if (cm.type & kMatTexturedBit) (void)texturize(cm, idx); }
+                        return cm;
+                    };
                     const bool isMulti = MULTI && m.type == SLRHIP_MATERIAL_MULTI;
                     MultiRec multiRec = {};
                     if constexpr (MULTI) {
@@ -992,14 +1050,19 @@ __global__ void __launch_bounds__(64) k_bsdf_queries(DevScene sc, uint32_t mater
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float* q = in + 12 * (size_t)i;
-    const Mat<S> m = MatIO<S>::template load<false>(sc, nullptr, material, wlOffset);
+    Mat<S> m = MatIO<S>::template load<false>(sc, nullptr, material, wlOffset);
+    if (m.type & kMatTexturedBit) (void)texturizeMat<S>(sc, m, material, 0.0f, 0.0f, wlOffset);     // textures at texCoord (0, 0)
     const V3 dirOut(q[0], q[1], q[2]), gNorm(q[3], q[4], q[5]), dirIn(q[6], q[7], q[8]);
     BsdfSample bs;
     bs.dir_sn = V3(0, 0, 0);
     S fs, fe;
     float pdf;
     if (m.type == SLRHIP_MATERIAL_MULTI) {
-        const auto loadComponent = [&](uint32_t idx) { return MatIO<S>::template load<false>(sc, nullptr, idx, wlOffset); };
+        const auto loadComponent = [&](uint32_t idx) {
+            Mat<S> cm = MatIO<S>::template load<false>(sc, nullptr, idx, wlOffset);
+            if (cm.type & kMatTexturedBit) (void)texturizeMat<S>(sc, cm, idx, 0.0f, 0.0f, wlOffset);
+            return cm;
+        };
         const MultiBSDF<S, decltype(loadComponent)> multi = {decodeMulti(m), 0u, loadComponent};
         const uint32_t type = multiType(multi.rec, 0u);
         fs = multi.sample(type, dirOut, gNorm, wl, q[9], q[10], q[11], &bs);

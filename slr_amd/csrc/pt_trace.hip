@@ -15,6 +15,7 @@
 
 #include "pt_device.h"
 #include "pt_kernels.h"
+#include "pt_tex.h"
 
 namespace slrhip {
 
@@ -29,14 +30,14 @@ int traceBlocksPerCU() { return kBlocksPerCU; }
 
 struct HitRec {
     uint32_t tri;
-    float t, b0, b1;
+    float t, b1, b2;       // Moller-Trumbore's own barycentrics: b0 = 1 - b1 - b2 is re-derived where it is needed (pt_shade_kernels.h)
 };
 struct TravCount {
     uint32_t nodes, tris;
 };
 
 template <bool ANY_HIT, bool COUNT>
-__device__ __forceinline__ bool traverse(const float4* __restrict__ nodes4, const float4* __restrict__ tris4, const float4* topNodes,
+__device__ __forceinline__ bool traverse(const DevScene& sc, const float4* __restrict__ nodes4, const float4* __restrict__ tris4, const float4* topNodes,
                                          uint32_t numTop, V3 org, V3 dir, float tmin, float tmax, HitRec* hit,
                                          uint32_t* ldsStack /* [kLdsStack][blockDim], this lane's column */, TravCount* cnt,
                                          uint32_t* errorWord = nullptr) {
@@ -50,7 +51,7 @@ __device__ __forceinline__ bool traverse(const float4* __restrict__ nodes4, cons
     int sp = 0;
     uint32_t cur = 0;                      // root
     bool found = false;
-    hit->tri = 0xFFFFFFFFu; hit->t = INFINITY; hit->b0 = 0.0f; hit->b1 = 0.0f;
+    hit->tri = 0xFFFFFFFFu; hit->t = INFINITY; hit->b1 = 0.0f; hit->b2 = 0.0f;
 
     for (;;) {
         if (cur & kLeafFlag) {
@@ -75,6 +76,8 @@ __device__ __forceinline__ bool traverse(const float4* __restrict__ nodes4, cons
                 if (b2 < 0.0f || b1 + b2 > 1.0f) continue;
                 float tt = dot(e2, q) * invDet;
                 if (tt < tmin || tt > tmax) continue;
+                // alpha texture of the triangle (TriangleMesh.cpp:162-167); LeafTri::alpha rides in e1's fourth word
+                if (__float_as_uint(b.w) != kNoAlpha && !alphaPasses(sc.alphaTris, sc.textures, __float_as_uint(b.w), b1, b2)) continue;
                 if (ANY_HIT) return true;
                 // equal distance: the larger scene index wins (tree-independent tie rule)
                 if (tt == tmax && found && triIdx < hit->tri) continue;
@@ -82,8 +85,8 @@ __device__ __forceinline__ bool traverse(const float4* __restrict__ nodes4, cons
                 tmax = tt;                                  // ray.distMax = isect->dist (QBVH.h:335)
                 hit->tri = triIdx;
                 hit->t = tt;
-                hit->b0 = 1.0f - b1 - b2;                   // TriangleMesh.cpp:162,172-173
-                hit->b1 = b1;
+                hit->b1 = b1;                               // Intersection::u = 1 - b1 - b2, ::v = b1 (TriangleMesh.cpp:159,172-173)
+                hit->b2 = b2;
             }
             if (sp == 0) break;
             --sp;
@@ -189,9 +192,9 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace_closest(DevScene sc, Path
             const float4 o = pb.rayOrg[slot];
             const float4 d = pb.rayDir[slot];
             HitRec hit;
-            traverse<false, COUNT>(sc.nodes, sc.leafTris, lds.top, numTop, V3(o.x, o.y, o.z), V3(d.x, d.y, d.z), o.w, d.w, &hit,
+            traverse<false, COUNT>(sc, sc.nodes, sc.leafTris, lds.top, numTop, V3(o.x, o.y, o.z), V3(d.x, d.y, d.z), o.w, d.w, &hit,
                                    lds.stack + threadIdx.x, &cnt, pb.errorWord);
-            pb.hit[slot] = make_float4(__uint_as_float(hit.tri), hit.t, hit.b0, hit.b1);
+            pb.hit[slot] = make_float4(__uint_as_float(hit.tri), hit.t, hit.b1, hit.b2);
             ++rays;
         }
     }
@@ -218,7 +221,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace_shadow(DevScene sc, PathB
         const float4 o = pb.rayOrg[slot];
         const float4 d = pb.shadowDir[slot];
         HitRec hit;
-        const bool occluded = traverse<true, COUNT>(sc.nodes, sc.leafTris, lds.top, numTop, V3(o.x, o.y, o.z), V3(d.x, d.y, d.z),
+        const bool occluded = traverse<true, COUNT>(sc, sc.nodes, sc.leafTris, lds.top, numTop, V3(o.x, o.y, o.z), V3(d.x, d.y, d.z),
                                                     kRayEpsilon, d.w, &hit, lds.stack + threadIdx.x, &cnt, pb.errorWord);
         pb.visible[slot] = occluded ? 0u : 1u;
         ++rays;
@@ -235,9 +238,9 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace_batch(DevScene sc, const 
     for (uint32_t i = blockIdx.x * kTraceBlock + threadIdx.x; i < n; i += gridDim.x * kTraceBlock) {
         const float4 o = org[i], d = dir[i];
         HitRec hit;
-        const bool found = traverse<false, false>(sc.nodes, sc.leafTris, lds.top, numTop, V3(o.x, o.y, o.z), V3(d.x, d.y, d.z), o.w, d.w,
+        const bool found = traverse<false, false>(sc, sc.nodes, sc.leafTris, lds.top, numTop, V3(o.x, o.y, o.z), V3(d.x, d.y, d.z), o.w, d.w,
                                                   &hit, lds.stack + threadIdx.x, &cnt);
-        out[i] = found ? make_float4(__uint_as_float(hit.tri), hit.t, hit.b0, hit.b1) : make_float4(__uint_as_float(0xFFFFFFFFu), INFINITY, 0.f, 0.f);
+        out[i] = found ? make_float4(__uint_as_float(hit.tri), hit.t, hit.b1, hit.b2) : make_float4(__uint_as_float(0xFFFFFFFFu), INFINITY, 0.f, 0.f);
     }
 }
 

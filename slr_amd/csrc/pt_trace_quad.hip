@@ -17,6 +17,7 @@
 
 #include "pt_device.h"
 #include "pt_kernels.h"
+#include "pt_tex.h"
 
 namespace slrhip {
 
@@ -39,7 +40,7 @@ __device__ __forceinline__ uint32_t quadOr(uint32_t v) {
 
 static const int kQuadBlock = 256;
 
-__global__ __launch_bounds__(kQuadBlock) void k_trace_quad(const float4* __restrict__ nodes, const float4* __restrict__ packets,
+__global__ __launch_bounds__(kQuadBlock) void k_trace_quad(DevScene sc, const float4* __restrict__ nodes, const float4* __restrict__ packets,
                                                            const float4* __restrict__ org, const float4* __restrict__ dir,
                                                            float4* __restrict__ out, uint32_t n) {
     __shared__ uint32_t stackLds[kQuadBlock / 64][64][16];
@@ -59,7 +60,7 @@ __global__ __launch_bounds__(kQuadBlock) void k_trace_quad(const float4* __restr
         uint32_t cur = 0;
         int sp = 0;
         uint32_t hitTri = 0xFFFFFFFFu;
-        float hitT = INFINITY, hitB0 = 0.0f, hitB1 = 0.0f;
+        float hitT = INFINITY, hitB1 = 0.0f, hitB2 = 0.0f;
 
         while (__ballot(!done)) {
             if (!done && !(cur & kLeafFlag)) {
@@ -110,6 +111,7 @@ __global__ __launch_bounds__(kQuadBlock) void k_trace_quad(const float4* __restr
                     accept = accept && !(b2 < 0.0f || b1 + b2 > 1.0f);
                     tt = dot(e2, qv) * invDet;
                     accept = accept && !(tt < tmin || tt > tmax);
+                    if (accept && __float_as_uint(b.w) != kNoAlpha) accept = alphaPasses(sc.alphaTris, sc.textures, __float_as_uint(b.w), b1, b2);
                 }
                 // the leaf's best candidate: smallest t; among equal t the larger scene index (tie rule)
                 const float m = quadMin(accept ? tt : INFINITY);
@@ -121,8 +123,8 @@ __global__ __launch_bounds__(kQuadBlock) void k_trace_quad(const float4* __restr
                     // distance replaces the current one only if its index is larger
                     if (!(m == tmax && hitTri != 0xFFFFFFFFu && winTri < hitTri)) {
                         const bool win = cand && triIdx == winTri;
-                        hitB0 = __uint_as_float(quadOr(win ? __float_as_uint(1.0f - b1 - b2) : 0u));      // TriangleMesh.cpp:162,172-173
-                        hitB1 = __uint_as_float(quadOr(win ? __float_as_uint(b1) : 0u));
+                        hitB1 = __uint_as_float(quadOr(win ? __float_as_uint(b1) : 0u));      // Intersection::u = 1 - b1 - b2, ::v = b1
+                        hitB2 = __uint_as_float(quadOr(win ? __float_as_uint(b2) : 0u));
                         tmax = m;                                                                       // ray.distMax = isect->dist (QBVH.h:335)
                         hitT = m;
                         hitTri = winTri;
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(kQuadBlock) void k_trace_quad(const float4* __restr
                 else { --sp; cur = stack[sp * 16]; }
             }
         }
-        if (ray < n && k == 0u) out[ray] = make_float4(__uint_as_float(hitTri), hitT, hitB0, hitB1);
+        if (ray < n && k == 0u) out[ray] = make_float4(__uint_as_float(hitTri), hitT, hitB1, hitB2);
     }
 }
 
@@ -155,7 +157,7 @@ void buildQuadLayouts(const std::vector<QNode>& nodes, const std::vector<LeafTri
                 for (uint32_t t = 0; t < count && t < 4; ++t) {
                     const LeafTri& lt = leafTris[first + t];
                     (*packets)[(size_t)p * 12 + t] = make_float4(lt.v0[0], lt.v0[1], lt.v0[2], hostBitsToFloat(lt.tri));
-                    (*packets)[(size_t)p * 12 + 4 + t] = make_float4(lt.e1[0], lt.e1[1], lt.e1[2], 0.0f);
+                    (*packets)[(size_t)p * 12 + 4 + t] = make_float4(lt.e1[0], lt.e1[1], lt.e1[2], hostBitsToFloat(lt.alpha));
                     (*packets)[(size_t)p * 12 + 8 + t] = make_float4(lt.e2[0], lt.e2[1], lt.e2[2], 0.0f);
                 }
                 child = kLeafFlag | (count << kLeafCountShift) | p;
@@ -166,10 +168,10 @@ void buildQuadLayouts(const std::vector<QNode>& nodes, const std::vector<LeafTri
     }
 }
 
-void launchTraceQuad(const float4* nodes4, const float4* packets, const float4* org, const float4* dir, float4* out, uint32_t n, hipStream_t stream) {
+void launchTraceQuad(const DevScene& sc, const float4* nodes4, const float4* packets, const float4* org, const float4* dir, float4* out, uint32_t n, hipStream_t stream) {
     uint32_t blocks = (n + 63) / 64;             // 16 rays per wave, 4 waves per block
     if (blocks > 2048) blocks = 2048;            // 8 resident blocks per CU (16 KiB of LDS each), striding over the rays
-    hipLaunchKernelGGL(k_trace_quad, dim3(blocks), dim3(kQuadBlock), 0, stream, nodes4, packets, org, dir, out, n);
+    hipLaunchKernelGGL(k_trace_quad, dim3(blocks), dim3(kQuadBlock), 0, stream, sc, nodes4, packets, org, dir, out, n);
 }
 
 } // namespace slrhip

@@ -22,6 +22,7 @@
 
 #include "pt_device.h"
 #include "pt_kernels.h"
+#include "pt_tex.h"
 
 namespace slrhip {
 
@@ -153,7 +154,7 @@ __device__ __forceinline__ void wsConsume(const DevScene& sc, const PathBuffers&
     uint32_t cur = 0;
     int sp = 0;
     uint32_t hitTri = 0xFFFFFFFFu;
-    float hitT = INFINITY, hitB0 = 0.0f, hitB1 = 0.0f;
+    float hitT = INFINITY, hitB1 = 0.0f, hitB2 = 0.0f;
 #ifdef SLR_WS_NOSPILL
     uint32_t* spill = nullptr;      // timing experiment only: no scratch, pushes beyond the LDS part are dropped
 #else
@@ -192,7 +193,7 @@ __device__ __forceinline__ void wsConsume(const DevScene& sc, const PathBuffers&
                     dx = d.x; dy = d.y; dz = d.z; tmax = d.w;
                     idx = 1.0f / dx; idy = 1.0f / dy; idz = 1.0f / dz;          // Vector3.h:60 reciprocal()
                     cur = 0; sp = 0;
-                    hitTri = 0xFFFFFFFFu; hitT = INFINITY; hitB0 = 0.0f; hitB1 = 0.0f;
+                    hitTri = 0xFFFFFFFFu; hitT = INFINITY; hitB1 = 0.0f; hitB2 = 0.0f;
                 }
                 // Ring space is handed back IN RESERVATION ORDER: `released` is a watermark, the producer overwrites
                 // everything below it, so this wave may only move it past its own entries once every earlier
@@ -361,6 +362,8 @@ __device__ __forceinline__ void wsConsume(const DevScene& sc, const PathBuffers&
                 accept = accept && !(b2 < 0.0f || b1 + b2 > 1.0f);
                 const float tt = dot(e2, q) * invDet;
                 accept = accept && !(tt < tmin || tt > tmax);
+                // alpha texture of the triangle (TriangleMesh.cpp:162-167); LeafTri::alpha rides in e1's fourth word
+                if (accept && __float_as_uint(b.w) != kNoAlpha) accept = alphaPasses(sc.alphaTris, sc.textures, __float_as_uint(b.w), b1, b2);
                 if (accept) {
                     if (anyHit) {
                         hitTri = triIdx;
@@ -371,8 +374,8 @@ __device__ __forceinline__ void wsConsume(const DevScene& sc, const PathBuffers&
                         tmax = tt;                                  // ray.distMax = isect->dist (QBVH.h:335)
                         hitTri = triIdx;
                         hitT = tt;
-                        hitB0 = 1.0f - b1 - b2;                     // TriangleMesh.cpp:162,172-173
-                        hitB1 = b1;
+                        hitB1 = b1;                                 // Intersection::u = 1 - b1 - b2, ::v = b1 (TriangleMesh.cpp:159,172-173)
+                        hitB2 = b2;
                     }
                 }
                 if (!finished) {
@@ -387,7 +390,7 @@ __device__ __forceinline__ void wsConsume(const DevScene& sc, const PathBuffers&
             }
             if (finished) {
                 if (slot & kShadowBit) pb.visible[slot & ~kShadowBit] = hitTri == 0xFFFFFFFFu ? 1u : 0u;      // testVisibility
-                else pb.hit[slot] = make_float4(__uint_as_float(hitTri), hitT, hitB0, hitB1);
+                else pb.hit[slot] = make_float4(__uint_as_float(hitTri), hitT, hitB1, hitB2);
                 slot = kIdle;
             }
         }

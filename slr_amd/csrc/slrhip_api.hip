@@ -111,6 +111,9 @@ struct slrhip_ctx {
     // scene
     DevArray<QNode> nodes;
     DevArray<QNodeQ> nodesQ;
+    DevArray<DevTexture> textures;
+    DevArray<DevMatTex> matTex;
+    DevArray<float4> triUV, alphaTris;
     DevArray<float4> quadNodes, quadPackets;      // SLRHIP_FLAG_QUAD_LAYOUT: the four-lanes-per-ray layouts (pt_trace_quad.hip)
     DevArray<LeafTri> leafTris;
     DevArray<ShadeTri> shadeTris;
@@ -179,6 +182,19 @@ static int readTotals(slrhip_ctx* ctx, uint64_t* out) {
                 (unsigned long long)out[T_WS_NODE_BLOCKS], (unsigned long long)out[T_WS_TRI_BLOCKS], (unsigned long long)out[T_WS_ACTIVE_LANES],
                 (unsigned long long)out[T_SHADOW_RAYS], (unsigned long long)out[T_NODES_SHADOW], (unsigned long long)out[T_TRIS_SHADOW]);
     return SLRHIP_OK;
+}
+
+// The kernels' hit record is (triangle, t, b1, b2) — Moller-Trumbore's barycentrics; the ABI reports Intersection::u, ::v =
+// (b0, b1) with b0 = 1 - b1 - b2 exactly as Triangle::intersect computes it (TriangleMesh.cpp:159,172-173).
+static void hitsToUV(float* hits, uint32_t n) {
+    for (uint32_t i = 0; i < n; ++i) {
+        float* h = hits + (size_t)i * 4;
+        const float b1 = h[2], b2 = h[3];
+        const float b0 = 1.0f - b1 - b2;
+        uint32_t tri; std::memcpy(&tri, h, 4);
+        h[2] = tri == 0xFFFFFFFFu ? 0.0f : b0;
+        h[3] = tri == 0xFFFFFFFFu ? 0.0f : b1;
+    }
 }
 
 extern "C" {
@@ -252,6 +268,60 @@ int slrhip_upload_scene(slrhip_ctx* ctx, const slrhip_scene_desc* d) {
             return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: triangle index out of range");
     }
     const bool spectral = ctx->config.mode == SLRHIP_MODE_SPECTRAL;
+    // --- textures: checkerboard spectrum / float / normal textures ----------------------------------------
+    const uint32_t numTextures = d->textures ? d->num_textures : 0u;
+    if (numTextures > 32767u) return fail(SLRHIP_ERR_UNSUPPORTED, "slrhip_upload_scene: more than 32767 textures");
+    std::vector<DevTexture> devTextures(numTextures);
+    for (uint32_t i = 0; i < numTextures; ++i) {
+        const slrhip_texture& t = d->textures[i];
+        DevTexture dt;
+        std::memset(&dt, 0, sizeof(dt));
+        dt.kind = t.kind; dt.ox = t.offset[0]; dt.oy = t.offset[1]; dt.sx = t.scale[0]; dt.sy = t.scale[1];
+        dt.v0 = t.value[0]; dt.v1 = t.value[1]; dt.spec0 = dt.spec1 = -1;
+        if (t.kind == SLRHIP_TEXTURE_CHECKER_SPECTRUM) {
+            for (int k = 0; k < 2; ++k) {
+                if (t.spectrum[k] < 0 || (uint32_t)t.spectrum[k] >= d->num_spectra)
+                    return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: texture names a spectrum out of range");
+                if (spectral && d->spectra[t.spectrum[k]].kind == SLRHIP_SPECTRUM_RGB_ONLY)
+                    return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: spectral mode needs a spectral descriptor for every spectrum in use");
+            }
+            dt.spec0 = t.spectrum[0]; dt.spec1 = t.spectrum[1];
+            for (int c = 0; c < 3; ++c) { dt.rgb0[c] = d->spectra[t.spectrum[0]].rgb[c]; dt.rgb1[c] = d->spectra[t.spectrum[1]].rgb[c]; }
+        }
+        else if (t.kind == SLRHIP_TEXTURE_CHECKER_NORMAL) {
+            if (!(t.value[0] > 0.0f && t.value[0] <= 1.0f))        // SLRAssert of the reference's constructor
+                return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: checkerboard normal texture needs stepWidth in (0, 1]");
+        }
+        else if (t.kind != SLRHIP_TEXTURE_CHECKER_FLOAT) return fail(SLRHIP_ERR_UNSUPPORTED, "slrhip_upload_scene: unknown texture kind");
+        devTextures[i] = dt;
+    }
+    std::vector<DevMatTex> matTex(d->num_materials);
+    std::vector<int32_t> alphaOfMaterial(d->num_materials, -1);
+    bool anyAlpha = false;
+    for (uint32_t i = 0; i < d->num_materials; ++i) {
+        const slrhip_material& m = d->materials[i];
+        DevMatTex mt = {{-1, -1, -1}, -1};
+        const uint32_t nmap = m.reserved & 0xFFFFu, amap = m.reserved >> 16;
+        if (nmap > numTextures || amap > numTextures) return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: material names a texture out of range");
+        if (nmap) {
+            if (d->textures[nmap - 1].kind != SLRHIP_TEXTURE_CHECKER_NORMAL) return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: a normal map must be a CHECKER_NORMAL texture");
+            mt.normalMap = (int32_t)nmap - 1;
+        }
+        if (amap) {
+            if (d->textures[amap - 1].kind != SLRHIP_TEXTURE_CHECKER_FLOAT) return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: an alpha map must be a CHECKER_FLOAT texture");
+            alphaOfMaterial[i] = (int32_t)amap - 1;
+            anyAlpha = true;
+        }
+        if (m.emittance < -1) return fail(SLRHIP_ERR_UNSUPPORTED, "slrhip_upload_scene: textured emittance is not supported");
+        for (int k = 0; k < 3 && m.type != SLRHIP_MATERIAL_MULTI; ++k) {
+            if (m.spectrum[k] >= -1) continue;
+            const uint32_t t = (uint32_t)(-2 - m.spectrum[k]);
+            if (t >= numTextures || d->textures[t].kind != SLRHIP_TEXTURE_CHECKER_SPECTRUM)
+                return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: material spectrum slot names a texture that is not a CHECKER_SPECTRUM");
+            mt.slot[k] = (int32_t)t;
+        }
+        matTex[i] = mt;
+    }
     std::vector<DevMaterial> mats(d->num_materials);
     std::vector<DevMaterialS> matsS(d->num_materials);
     std::vector<char> emitting(d->num_materials, 0);
@@ -319,13 +389,13 @@ int slrhip_upload_scene(slrhip_ctx* ctx, const slrhip_scene_desc* d) {
         // `scale * spectrum` with scale = 1.0f (basic_SurfaceMaterials.cpp:22,33,42) is exact
         if (!fetch(m.spectrum[0], dm.a) || !fetch(m.spectrum[1], dm.b) || !fetch(m.spectrum[2], dm.c) || !fetch(m.emittance, dm.emittance))
             return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: spectrum index out of range");
-        if (m.spectrum[0] < 0 && m.type <= SLRHIP_MATERIAL_GLASS)
+        if (m.spectrum[0] == -1 && m.type <= SLRHIP_MATERIAL_GLASS)
             return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: material without its first spectrum");
-        if (m.type == SLRHIP_MATERIAL_ASHIKHMIN && (m.spectrum[0] < 0 || m.spectrum[1] < 0))
+        if (m.type == SLRHIP_MATERIAL_ASHIKHMIN && (m.spectrum[0] == -1 || m.spectrum[1] == -1))
             return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: Ashikhmin needs Rs and Rd");
-        if (m.type == SLRHIP_MATERIAL_WARD && m.spectrum[0] < 0)
+        if (m.type == SLRHIP_MATERIAL_WARD && m.spectrum[0] == -1)
             return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: Ward needs R");
-        if (m.type >= SLRHIP_MATERIAL_METAL && m.type <= SLRHIP_MATERIAL_MICROFACET_GLASS && (m.spectrum[1] < 0 || m.spectrum[2] < 0))
+        if (m.type >= SLRHIP_MATERIAL_METAL && m.type <= SLRHIP_MATERIAL_MICROFACET_GLASS && (m.spectrum[1] == -1 || m.spectrum[2] == -1))
             return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: material without its eta / k spectra");
         emitting[i] = m.emittance >= 0;
         mats[i] = dm;
@@ -337,6 +407,10 @@ int slrhip_upload_scene(slrhip_ctx* ctx, const slrhip_scene_desc* d) {
             for (int k = 0; k < 4; ++k)
                 if (ds.spec[k] >= 0 && d->spectra[ds.spec[k]].kind == SLRHIP_SPECTRUM_RGB_ONLY)
                     return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: spectral mode needs a spectral descriptor for every spectrum in use");
+    }
+    for (uint32_t i = 0; i < d->num_materials; ++i) {
+        const DevMatTex& mt = matTex[i];
+        if (mt.slot[0] >= 0 || mt.slot[1] >= 0 || mt.slot[2] >= 0 || mt.normalMap >= 0) { mats[i].type |= kMatTexturedBit; matsS[i].type |= kMatTexturedBit; }
     }
     // spectrum table (spectral mode): descriptors + the float pool, bounds-checked here because the kernels index it
     std::vector<DevSpectrum> devSpectra(d->num_spectra);
@@ -475,7 +549,37 @@ int slrhip_upload_scene(slrhip_ctx* ctx, const slrhip_scene_desc* d) {
     static const bool forceQuant = [] { const char* e = getenv("SLRHIP_QUANT"); return e && std::string(e) == "1"; }();   // experiment: small trees too
     const bool quant = (bvh.nodes.size() >= 65536 || forceQuant) && !noQuant;
     if (quant) { quantizeNodes(&bvh); HIP_TRY(ctx->nodesQ.upload(bvh.quantized)); }
+    // alpha textures (Triangle::m_alphaTex): one record per triangle that has one, named by its leaf entries; texture coordinates
+    // of every triangle for the textured shading kernels
+    std::vector<float4> alphaTris, triUV;
+    if (anyAlpha) {
+        std::vector<uint32_t> recordOf(d->num_triangles, kNoAlpha);
+        for (uint32_t i = 0; i < d->num_triangles; ++i) {
+            const int32_t a = alphaOfMaterial[d->triangles[i].material];
+            if (a < 0) continue;
+            recordOf[i] = (uint32_t)(alphaTris.size() / 2);
+            const slrhip_triangle& t = d->triangles[i];
+            const float* u0 = d->vertices[t.v[0]].texcoord; const float* u1 = d->vertices[t.v[1]].texcoord; const float* u2 = d->vertices[t.v[2]].texcoord;
+            float texIdx; const uint32_t bits = (uint32_t)a; std::memcpy(&texIdx, &bits, 4);
+            alphaTris.push_back(make_float4(u0[0], u0[1], u1[0], u1[1]));
+            alphaTris.push_back(make_float4(u2[0], u2[1], texIdx, 0.0f));
+        }
+        for (LeafTri& lt : bvh.leafTris) lt.alpha = recordOf[lt.tri];
+    }
+    if (numTextures) {
+        triUV.resize((size_t)d->num_triangles * 2);
+        for (uint32_t i = 0; i < d->num_triangles; ++i) {
+            const slrhip_triangle& t = d->triangles[i];
+            const float* u0 = d->vertices[t.v[0]].texcoord; const float* u1 = d->vertices[t.v[1]].texcoord; const float* u2 = d->vertices[t.v[2]].texcoord;
+            triUV[(size_t)i * 2] = make_float4(u0[0], u0[1], u1[0], u1[1]);
+            triUV[(size_t)i * 2 + 1] = make_float4(u2[0], u2[1], 0.0f, 0.0f);
+        }
+    }
     HIP_TRY(ctx->leafTris.upload(bvh.leafTris));
+    HIP_TRY(ctx->textures.upload(devTextures));
+    HIP_TRY(ctx->matTex.upload(matTex));
+    HIP_TRY(ctx->triUV.upload(triUV));
+    HIP_TRY(ctx->alphaTris.upload(alphaTris));
     if (ctx->config.flags & SLRHIP_FLAG_QUAD_LAYOUT) {
         std::vector<float4> qn, qp;
         buildQuadLayouts(bvh.nodes, bvh.leafTris, &qn, &qp);
@@ -528,6 +632,8 @@ int slrhip_upload_scene(slrhip_ctx* ctx, const slrhip_scene_desc* d) {
     sc.spectrumPool = ctx->spectrumPool.ptr;
     sc.lightPMF = ctx->lightPMF.ptr;
     sc.lightCDF = ctx->lightCDF.ptr;
+    sc.textures = ctx->textures.ptr; sc.matTex = ctx->matTex.ptr; sc.triUV = ctx->triUV.ptr; sc.alphaTris = ctx->alphaTris.ptr;
+    sc.numTextures = numTextures;
     sc.numNodes = (uint32_t)bvh.nodes.size();
     sc.nodesQ = quant ? reinterpret_cast<const float4*>(ctx->nodesQ.ptr) : nullptr;
     sc.numMaterials = (uint32_t)mats.size();
@@ -536,8 +642,8 @@ int slrhip_upload_scene(slrhip_ctx* ctx, const slrhip_scene_desc* d) {
     sc.hasMicrofacet = 0;
     sc.hasMulti = 0;
     for (const DevMaterial& dm : mats) {
-        if (dm.type >= SLRHIP_MATERIAL_MICROFACET_METAL) sc.hasMicrofacet = 1;     // GGX, Ward, Ashikhmin: the kernels with the glossy-lobe code
-        if (dm.type == SLRHIP_MATERIAL_MULTI) sc.hasMulti = 1;
+        if ((dm.type & 0xFFu) >= SLRHIP_MATERIAL_MICROFACET_METAL) sc.hasMicrofacet = 1;     // GGX, Ward, Ashikhmin: the kernels with the glossy-lobe code
+        if ((dm.type & 0xFFu) == SLRHIP_MATERIAL_MULTI) sc.hasMulti = 1;
     }
     sc.lightPow2 = prevPowerOf2(sc.numLights);
     sc.hasEnv = d->env ? 1u : 0u;
@@ -946,6 +1052,7 @@ int slrhip_trace_rays(slrhip_ctx* ctx, const float* rays, uint32_t n, float* hit
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(hits, dOut.ptr, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost));
+    hitsToUV(hits, n);
     return SLRHIP_OK;
 }
 
@@ -973,7 +1080,7 @@ int slrhip_trace_rays_timed(slrhip_ctx* ctx, const float* rays, uint32_t n, floa
     HIP_TRY(hipEventCreate(&e1));
     auto launch = [&] {
         if (mapping == 0) launchTraceBatch(ctx->scene, dOrg.ptr, dDir.ptr, dOut.ptr, n, nullptr);
-        else launchTraceQuad(ctx->quadNodes.ptr, ctx->quadPackets.ptr, dOrg.ptr, dDir.ptr, dOut.ptr, n, nullptr);
+        else launchTraceQuad(ctx->scene, ctx->quadNodes.ptr, ctx->quadPackets.ptr, dOrg.ptr, dDir.ptr, dOut.ptr, n, nullptr);
     };
     launch();                                  // warm-up (caches, code object)
     HIP_TRY(hipEventRecord(e0, nullptr));
@@ -986,6 +1093,7 @@ int slrhip_trace_rays_timed(slrhip_ctx* ctx, const float* rays, uint32_t n, floa
     *avgMs = ms / (float)repeats;
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     HIP_TRY(hipMemcpy(hits, dOut.ptr, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost));
+    hitsToUV(hits, n);
     return SLRHIP_OK;
 }
 
