@@ -124,8 +124,35 @@ void Scene::setEnvironment(const float* texels, uint32_t width, uint32_t height,
     m_env.map_width = mapWidth; m_env.map_height = mapHeight;
     m_hasEnv = true;
 }
-uint32_t Scene::addMaterial(uint32_t type, int32_t s0, int32_t s1, int32_t s2, float param, int32_t emittance, float param2) {
-    slrhip_material m = {type, {s0, s1, s2}, param, emittance, param2, 0u};
+static slrhip_texture makeTexture(uint32_t kind, float ox, float oy, float sx, float sy) {
+    slrhip_texture t;
+    std::memset(&t, 0, sizeof(t));
+    t.kind = kind; t.offset[0] = ox; t.offset[1] = oy; t.scale[0] = sx; t.scale[1] = sy;
+    t.spectrum[0] = t.spectrum[1] = -1;
+    return t;
+}
+int32_t Scene::addCheckerSpectrumTexture(uint32_t spectrum0, uint32_t spectrum1, float ox, float oy, float sx, float sy) {
+    slrhip_texture t = makeTexture(SLRHIP_TEXTURE_CHECKER_SPECTRUM, ox, oy, sx, sy);
+    t.spectrum[0] = (int32_t)spectrum0; t.spectrum[1] = (int32_t)spectrum1;
+    m_textures.push_back(t);
+    return SLRHIP_TEXTURE_REF(m_textures.size() - 1);
+}
+uint32_t Scene::addCheckerFloatTexture(float v0, float v1, float ox, float oy, float sx, float sy) {
+    slrhip_texture t = makeTexture(SLRHIP_TEXTURE_CHECKER_FLOAT, ox, oy, sx, sy);
+    t.value[0] = v0; t.value[1] = v1;
+    m_textures.push_back(t);
+    return (uint32_t)m_textures.size() - 1;
+}
+uint32_t Scene::addCheckerNormalTexture(float stepWidth, bool reverse, float ox, float oy, float sx, float sy) {
+    slrhip_texture t = makeTexture(SLRHIP_TEXTURE_CHECKER_NORMAL, ox, oy, sx, sy);
+    t.value[0] = stepWidth; t.value[1] = reverse ? 1.0f : 0.0f;
+    m_textures.push_back(t);
+    return (uint32_t)m_textures.size() - 1;
+}
+uint32_t Scene::addMaterial(uint32_t type, int32_t s0, int32_t s1, int32_t s2, float param, int32_t emittance, float param2, int32_t normalMap,
+                            int32_t alphaMap) {
+    const uint32_t maps = (normalMap >= 0 ? SLRHIP_MATERIAL_NORMAL_MAP(normalMap) : 0u) | (alphaMap >= 0 ? SLRHIP_MATERIAL_ALPHA_MAP(alphaMap) : 0u);
+    slrhip_material m = {type, {s0, s1, s2}, param, emittance, param2, maps};
     m_materials.push_back(m);
     return (uint32_t)m_materials.size() - 1;
 }
@@ -149,6 +176,8 @@ slrhip_scene_desc Scene::desc() const {
     d.camera = m_camera;
     d.env = nullptr;
     d.upsampling = m_hasTables ? &m_tables : nullptr;
+    d.textures = m_textures.empty() ? nullptr : m_textures.data();
+    d.num_textures = (uint32_t)m_textures.size();
     if (m_hasEnv) {
         // the descriptor points into this object: valid as long as the Scene is
         const_cast<Scene*>(this)->m_env.texels = m_envTexels.data();

@@ -40,6 +40,7 @@ class Scene {
     std::vector<slrhip_material> m_materials;
     std::vector<slrhip_spectrum> m_spectra;
     std::vector<float> m_spectrumData;
+    std::vector<slrhip_texture> m_textures;
     slrhip_camera m_camera;
     std::vector<float> m_envTexels, m_envImportance;
     slrhip_envmap m_env;
@@ -75,7 +76,14 @@ public:
     // `scale` of IBLEmission, and the quarter-resolution luminance map ImageSpectrumTexture::createIBLImportanceMap would build.
     void setEnvironment(const float* texels, uint32_t width, uint32_t height, float scale, const float* importance, uint32_t mapWidth,
                         uint32_t mapHeight);
-    uint32_t addMaterial(uint32_t type, int32_t s0, int32_t s1, int32_t s2, float param, int32_t emittance, float param2 = 0.0f);
+    // Checkerboard textures of libSLR (Textures/checker_board_textures.h) over an OffsetAndScale2DMapping (Core/textures.h:32-42).
+    // addCheckerSpectrumTexture returns the VALUE for a material's spectrum slot (SLRHIP_TEXTURE_REF); the other two return the
+    // texture index for addMaterial's normalMap / alphaMap (BumpSingleSurfaceObject, Triangle's alpha texture).
+    int32_t addCheckerSpectrumTexture(uint32_t spectrum0, uint32_t spectrum1, float offsetX = 0, float offsetY = 0, float scaleX = 1, float scaleY = 1);
+    uint32_t addCheckerFloatTexture(float v0, float v1, float offsetX = 0, float offsetY = 0, float scaleX = 1, float scaleY = 1);
+    uint32_t addCheckerNormalTexture(float stepWidth, bool reverse, float offsetX = 0, float offsetY = 0, float scaleX = 1, float scaleY = 1);
+    uint32_t addMaterial(uint32_t type, int32_t s0, int32_t s1, int32_t s2, float param, int32_t emittance, float param2 = 0.0f,
+                         int32_t normalMap = -1, int32_t alphaMap = -1);
     // SurfaceMaterial::createSummedMaterial / createMixedMaterial (constant factor) over two single-lobe materials, either of
     // which may be wrapped as SurfaceMaterial::createInverseMaterial would (libSLR/Core/surface_material.h; API.cpp:583-636).
     uint32_t addSummedMaterial(uint32_t mat0, uint32_t mat1, bool inverse0 = false, bool inverse1 = false, int32_t emittance = -1);

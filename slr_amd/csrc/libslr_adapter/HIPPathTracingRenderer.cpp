@@ -10,6 +10,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <tuple>
+#include <typeinfo>
 
 #include "Accelerator/QBVH.h"
 #include "Accelerator/SBVH.h"
@@ -27,6 +29,7 @@
 #include "SurfaceMaterials/ModifiedWardDurReflection.h"
 #include "SurfaceMaterials/SummedSurfaceMaterial.h"
 #include "SurfaceMaterials/basic_SurfaceMaterials.h"
+#include "Textures/checker_board_textures.h"
 #include "Textures/constant_textures.h"
 
 namespace SLR {
@@ -42,6 +45,8 @@ slrhip_scene_desc FlatScene::desc() const {
     d.camera = camera;
     d.env = nullptr;
     d.upsampling = gridCells.empty() ? nullptr : &tables;
+    d.textures = textures.empty() ? nullptr : textures.data();
+    d.num_textures = (uint32_t)textures.size();
     return d;
 }
 
@@ -54,16 +59,51 @@ struct Flattener {
     std::map<const Vertex*, uint32_t> vertexIndex;
     std::map<const InputSpectrum*, int32_t> spectrumIndex;
     std::map<const SurfaceMaterial*, uint32_t> materialIndex;
+    std::map<const void*, uint32_t> textureIndex;
+    // a material record is keyed by (material, normal map, alpha texture): the material group of TriangleMeshNode pairs them
+    std::map<std::tuple<const SurfaceMaterial*, const Normal3DTexture*, const FloatTexture*>, uint32_t> groupIndex;
 
     bool fail(const std::string &what) { *error = "HIPPathTracingRenderer: " + what; return false; }
 
-    // ConstantSpectrumTexture -> its InputSpectrum -> a slrhip_spectrum record (by content of the reference object)
+    bool mappingOf(const Texture2DMapping* mapping, slrhip_texture* rec) {
+        rec->offset[0] = rec->offset[1] = 0.0f; rec->scale[0] = rec->scale[1] = 1.0f;
+        if (const OffsetAndScale2DMapping* os = dynamic_cast<const OffsetAndScale2DMapping*>(mapping)) {
+            rec->offset[0] = os->m_offsetX; rec->offset[1] = os->m_offsetY; rec->scale[0] = os->m_scaleX; rec->scale[1] = os->m_scaleY;
+            return true;
+        }
+        if (mapping && typeid(*mapping) == typeid(Texture2DMapping)) return true;       // the default mapping: texCoord itself
+        return fail("only the default and the offset-and-scale 2D texture mappings are supported");
+    }
+    uint32_t pushTexture(const void* key, const slrhip_texture& rec) {
+        out->textures.push_back(rec);
+        textureIndex[key] = (uint32_t)out->textures.size() - 1;
+        return (uint32_t)out->textures.size() - 1;
+    }
+
+    // a SpectrumTexture in a material slot -> the slot's value: a spectrum index (ConstantSpectrumTexture) or SLRHIP_TEXTURE_REF
+    // (CheckerBoardSpectrumTexture over two constant spectra)
     bool spectrumOf(const SpectrumTexture* tex, int32_t* index) {
         *index = -1;
         if (!tex) return true;
+        if (const CheckerBoardSpectrumTexture* cb = dynamic_cast<const CheckerBoardSpectrumTexture*>(tex)) {
+            auto it = textureIndex.find(cb);
+            if (it == textureIndex.end()) {
+                slrhip_texture rec;
+                std::memset(&rec, 0, sizeof(rec));
+                rec.kind = SLRHIP_TEXTURE_CHECKER_SPECTRUM;
+                if (!mappingOf(cb->m_mapping, &rec)) return false;
+                for (int k = 0; k < 2; ++k) if (!inputSpectrumOf(cb->m_values[k], &rec.spectrum[k])) return false;
+                *index = SLRHIP_TEXTURE_REF(pushTexture(cb, rec));
+            }
+            else *index = SLRHIP_TEXTURE_REF(it->second);
+            return true;
+        }
         const ConstantSpectrumTexture* c = dynamic_cast<const ConstantSpectrumTexture*>(tex);
-        if (!c) return fail("only constant spectrum textures are on the hot path (image / procedural textures are not)");
-        const InputSpectrum* sp = c->m_value;
+        if (!c) return fail("only constant and checkerboard spectrum textures are on the hot path (image textures are not)");
+        return inputSpectrumOf(c->m_value, index);
+    }
+
+    bool inputSpectrumOf(const InputSpectrum* sp, int32_t* index) {
         auto it = spectrumIndex.find(sp);
         if (it != spectrumIndex.end()) { *index = it->second; return true; }
         slrhip_spectrum rec;
@@ -102,6 +142,49 @@ struct Flattener {
         out->spectra.push_back(rec);
         *index = (int32_t)out->spectra.size() - 1;
         spectrumIndex[sp] = *index;
+        return true;
+    }
+
+    bool normalMapOf(const Normal3DTexture* tex, uint32_t* index) {
+        const CheckerBoardNormal3DTexture* cb = dynamic_cast<const CheckerBoardNormal3DTexture*>(tex);
+        if (!cb) return fail("only the checkerboard normal map is supported");
+        auto it = textureIndex.find(cb);
+        if (it != textureIndex.end()) { *index = it->second; return true; }
+        slrhip_texture rec;
+        std::memset(&rec, 0, sizeof(rec));
+        rec.kind = SLRHIP_TEXTURE_CHECKER_NORMAL;
+        if (!mappingOf(cb->m_mapping, &rec)) return false;
+        rec.value[0] = cb->m_stepWidth; rec.value[1] = cb->m_reverse ? 1.0f : 0.0f;
+        *index = pushTexture(cb, rec);
+        return true;
+    }
+    bool alphaMapOf(const FloatTexture* tex, uint32_t* index) {
+        const CheckerBoardFloatTexture* cb = dynamic_cast<const CheckerBoardFloatTexture*>(tex);
+        if (!cb) return fail("only the checkerboard float texture is supported as an alpha texture");
+        auto it = textureIndex.find(cb);
+        if (it != textureIndex.end()) { *index = it->second; return true; }
+        slrhip_texture rec;
+        std::memset(&rec, 0, sizeof(rec));
+        rec.kind = SLRHIP_TEXTURE_CHECKER_FLOAT;
+        if (!mappingOf(cb->m_mapping, &rec)) return false;
+        rec.value[0] = cb->m_values[0]; rec.value[1] = cb->m_values[1];
+        *index = pushTexture(cb, rec);
+        return true;
+    }
+    // the material record of one object: its surface material + the object's normal map + its triangle's alpha texture
+    bool groupOf(const SurfaceMaterial* mat, const Normal3DTexture* nmap, const FloatTexture* alpha, uint32_t* index) {
+        if (!nmap && !alpha) return materialOf(mat, index);
+        auto key = std::make_tuple(mat, nmap, alpha);
+        auto it = groupIndex.find(key);
+        if (it != groupIndex.end()) { *index = it->second; return true; }
+        uint32_t base;
+        if (!materialOf(mat, &base)) return false;
+        slrhip_material m = out->materials[base];
+        if (nmap) { uint32_t t; if (!normalMapOf(nmap, &t)) return false; m.reserved |= SLRHIP_MATERIAL_NORMAL_MAP(t); }
+        if (alpha) { uint32_t t; if (!alphaMapOf(alpha, &t)) return false; m.reserved |= SLRHIP_MATERIAL_ALPHA_MAP(t); }
+        out->materials.push_back(m);
+        *index = (uint32_t)out->materials.size() - 1;
+        groupIndex[key] = *index;
         return true;
     }
 
@@ -199,7 +282,7 @@ struct Flattener {
 } // namespace
 
 bool flattenScene(const Scene &scene, FlatScene* out, std::string* error, slrhip_resolve_upsampled_fn resolve) {
-    Flattener f = {out, error, resolve, {}, {}, {}};
+    Flattener f = {out, error, resolve, {}, {}, {}, {}, {}};
     *out = FlatScene();
     std::memset(&out->tables, 0, sizeof(out->tables));
 #ifdef Use_Spectral_Representation
@@ -235,8 +318,8 @@ bool flattenScene(const Scene &scene, FlatScene* out, std::string* error, slrhip
     std::vector<const SingleSurfaceObject*> objs;
     for (const SurfaceObject* o : *list) {
         const SingleSurfaceObject* s = dynamic_cast<const SingleSurfaceObject*>(o);
-        if (!s || dynamic_cast<const BumpSingleSurfaceObject*>(o) || dynamic_cast<const InfiniteSphereSurfaceObject*>(o))
-            return f.fail("only plain SingleSurfaceObjects over Triangles are on the hot path (no bump, instancing or nested aggregates)");
+        if (!s || dynamic_cast<const InfiniteSphereSurfaceObject*>(o))
+            return f.fail("only SingleSurfaceObjects over Triangles are on the hot path (no instancing or nested aggregates)");
         objs.push_back(s);
     }
     std::sort(objs.begin(), objs.end(), [](const SingleSurfaceObject* a, const SingleSurfaceObject* b) { return a->m_surface < b->m_surface; });
@@ -247,7 +330,6 @@ bool flattenScene(const Scene &scene, FlatScene* out, std::string* error, slrhip
     for (const SingleSurfaceObject* o : objs) {
         const Triangle* t = dynamic_cast<const Triangle*>(o->m_surface);
         if (!t) return f.fail("only Triangle surfaces are on the hot path");
-        if (t->m_alphaTex) return f.fail("alpha-textured triangles are not supported");
         for (int k = 0; k < 3; ++k) verts.push_back(t->m_v[k]);
     }
     std::sort(verts.begin(), verts.end());
@@ -267,7 +349,8 @@ bool flattenScene(const Scene &scene, FlatScene* out, std::string* error, slrhip
         const Triangle* t = static_cast<const Triangle*>(objs[i]->m_surface);
         slrhip_triangle &d = out->triangles[i];
         for (int k = 0; k < 3; ++k) d.v[k] = f.vertexIndex[t->m_v[k]];
-        if (!f.materialOf(objs[i]->m_material, &d.material)) return false;
+        const BumpSingleSurfaceObject* bump = dynamic_cast<const BumpSingleSurfaceObject*>(objs[i]);
+        if (!f.groupOf(objs[i]->m_material, bump ? bump->m_normalMap : nullptr, t->m_alphaTex, &d.material)) return false;
     }
     // the light list must come out in the reference's order (Scene::selectLight indexes it): emitting triangles appear in
     // out->triangles in the order of m_lightList (SurfaceObject.cpp:232-249)

@@ -31,6 +31,7 @@ struct FlatScene {
     std::vector<slrhip_material> materials;
     std::vector<slrhip_spectrum> spectra;
     std::vector<float> spectrumData;
+    std::vector<slrhip_texture> textures;
     slrhip_camera camera;
     // spectral build: libSLR's own Meng-15 tables (BasicTypes/Spectrum.h:197-575) in the layout of slrhip_upsampling_tables
     std::vector<uint8_t> gridCells;
@@ -43,8 +44,9 @@ struct FlatScene {
 // material / texture / spectrum objects behind them.  One slrhip_triangle per SingleSurfaceObject, in the order of the Triangle
 // objects in memory (= the order libSLRSceneGraph/TriangleMeshNode.cpp:80-112 created them in), which keeps the light list
 // (SurfaceObject.cpp:232-249) in the reference's order.  Returns false with a message for anything outside the hot path
-// (BumpSingleSurfaceObject, TransformedSurfaceObject, image textures, an environment sphere over an image texture, nested
-// MultiBSDF materials).  `resolve` = slrhip_resolve_upsampled of the HIP library (spectral build only; may be null in the RGB build).
+// (TransformedSurfaceObject, image textures, an environment sphere over an image texture, nested MultiBSDF materials).
+// Checkerboard spectrum textures in material slots, a BumpSingleSurfaceObject's checkerboard normal map and a Triangle's
+// checkerboard alpha texture become slrhip_texture records.  `resolve` = slrhip_resolve_upsampled of the HIP library (spectral build only; may be null in the RGB build).
 typedef int (*slrhip_resolve_upsampled_fn)(const slrhip_upsampling_tables*, float, float, uint32_t*, float*);
 bool flattenScene(const Scene &scene, FlatScene* out, std::string* error, slrhip_resolve_upsampled_fn resolve);
 // Same, with the helper taken from libslrhip.so (`libraryPath` as in HIPPathTracingRenderer's constructor).

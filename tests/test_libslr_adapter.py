@@ -49,7 +49,8 @@ def _flatten(lib, ref_scene):
     lib.lib.slr_ref_flat_desc(h, C.byref(d))
     out = dict(vertices=_array(d.vertices, d.num_vertices, abi.vertex_dtype), triangles=_array(d.triangles, d.num_triangles, abi.triangle_dtype),
                materials=_array(d.materials, d.num_materials, abi.material_dtype), spectra=_array(d.spectra, d.num_spectra, abi.spectrum_dtype),
-               spectrum_data=_array(d.spectrum_data, d.num_spectrum_data, np.float32), camera=bytes(d.camera), has_tables=bool(d.upsampling))
+               spectrum_data=_array(d.spectrum_data, d.num_spectrum_data, np.float32), camera=bytes(d.camera), has_tables=bool(d.upsampling),
+               textures=_array(d.textures, d.num_textures, abi.texture_dtype))
     lib.lib.slr_ref_flat_free(h)
     return out
 
@@ -69,13 +70,33 @@ def _spectrum_content(spectra, data, idx, mode):
     return head + (payload,)
 
 
+def _texture_content(sc, t_idx, mode):
+    t = sc["textures"][t_idx]
+    head = (int(t["kind"]), t["offset"].tobytes(), t["scale"].tobytes())
+    if int(t["kind"]) == abi.TEX_CHECKER_SPECTRUM:
+        return head + tuple(_spectrum_content(sc["spectra"], sc["spectrum_data"], int(i), mode) for i in t["spectrum"])
+    return head + (t["value"].tobytes(),)
+
+
+def _slot_content(sc, slot, mode):
+    """A material's spectrum slot: a constant spectrum or (SLRHIP_TEXTURE_REF) a checkerboard of two."""
+    return _texture_content(sc, -2 - slot, mode) if slot < -1 else _spectrum_content(sc["spectra"], sc["spectrum_data"], slot, mode)
+
+
 def _material_content(sc, m_idx, mode):
+    m = sc["materials"][m_idx]
+    t = int(m["type"])
+    maps = tuple(_texture_content(sc, k - 1, mode) if k else None for k in (int(m["reserved"]) & 0xFFFF, int(m["reserved"]) >> 16))
+    return maps + _lobe_content(sc, m_idx, mode)
+
+
+def _lobe_content(sc, m_idx, mode):
     m = sc["materials"][m_idx]
     t = int(m["type"])
     emit = _spectrum_content(sc["spectra"], sc["spectrum_data"], int(m["emittance"]), mode)
     scalars = (np.float32(m["param"]).tobytes(), np.float32(m["param2"]).tobytes())
     if t == abi.MAT_MULTI:
-        return (t, scalars, int(m["spectrum"][2]), _material_content(sc, int(m["spectrum"][0]), mode), _material_content(sc, int(m["spectrum"][1]), mode), emit)
+        return (t, scalars, int(m["spectrum"][2]), _lobe_content(sc, int(m["spectrum"][0]), mode), _lobe_content(sc, int(m["spectrum"][1]), mode), emit)
     # the spectra a lobe reads (include/slrhip.h); unused slots are not compared
     used = {abi.MAT_MATTE: (0,), abi.MAT_METAL: (0, 1, 2), abi.MAT_GLASS: (0, 1, 2), abi.MAT_MF_METAL: (1, 2), abi.MAT_MF_GLASS: (1, 2),
             abi.MAT_WARD: (0,), abi.MAT_ASHIKHMIN: (0, 1)}[t]
@@ -85,11 +106,12 @@ def _material_content(sc, m_idx, mode):
         scalars = ()
     elif t in (abi.MAT_MF_METAL, abi.MAT_MF_GLASS, abi.MAT_MATTE):
         scalars = scalars[:1]
-    return (t, scalars, tuple(_spectrum_content(sc["spectra"], sc["spectrum_data"], int(m["spectrum"][k]), mode) for k in used), emit)
+    return (t, scalars, tuple(_slot_content(sc, int(m["spectrum"][k]), mode) for k in used), emit)
 
 
 def _as_dict(scene):
-    return dict(vertices=scene.vertices, triangles=scene.triangles, materials=scene.materials, spectra=scene.spectra, spectrum_data=scene.spectrum_data)
+    return dict(vertices=scene.vertices, triangles=scene.triangles, materials=scene.materials, spectra=scene.spectra, spectrum_data=scene.spectrum_data,
+                textures=scene.textures)
 
 
 SCENES = {
@@ -98,6 +120,7 @@ SCENES = {
     "material_zoo": lambda: scenes.material_zoo()[0],
     "cornell_multi": lambda: scenes.cornell_multi(1.0, 10, 5),
     "lobes_ward": lambda: scenes.cornell_lobes("ward", segments=8, rings=4),
+    "textured": lambda: scenes.cornell_textured(1.0, 10, 5),          # checkerboard slots, BumpSingleSurfaceObject, alpha texture
 }
 
 
