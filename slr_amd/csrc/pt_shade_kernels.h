@@ -897,11 +897,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_regen(DevScene sc, PathBuffers 
         const uint32_t flags = pb.flags[slot];
         const uint4 hdr = pb.hdr[slot];
         uint32_t sampleIdx = hdr.x;
-#if defined(SLR_REGEN_EXP) && SLR_REGEN_EXP == 3
-        if (false) {
-#else
         if (F_HASPATH(flags)) {
-#endif
             // sensor->add(p.x, p.y, wls, weight * C)  PathTracingRenderer.cpp:126-130
             S C, accR, accC;
             float unusedW;
@@ -934,11 +930,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_regen(DevScene sc, PathBuffers 
             const uint32_t xy = pb.pixelXY[pix];
             const uint32_t px = xy & 0xFFFFu, py = xy >> 16;
             Rng rng;
-#if defined(SLR_REGEN_EXP) && SLR_REGEN_EXP == 1
-            rng.s0 = px * 747796405u + pass; rng.s1 = py * 2891336453u + 1u; rng.s2 = pass * 277803737u + 7u; rng.s3 = 88675123u;      // timing experiment: no seeding
-#else
             rng.seed(sampleSeed(rp.rngSeed, px, py, pass));
-#endif
             float v = rng.nextFloat();
             float time = rp.timeStart * (1 - v) + rp.timeEnd * v;
             (void)time;
@@ -972,16 +964,12 @@ __global__ __launch_bounds__(kShadeBlock) void k_regen(DevScene sc, PathBuffers 
             // weight :126
             float camWeight = absDot(rayDir, lensN) / (sc.camera.areaPDF * dirPDF * selectWLPDF);
             pb.flags[slot] = F_MAKE((uint32_t)ST_FIRST_HIT, 0u, wl, 0u, 0u, 0u);
-#if !(defined(SLR_REGEN_EXP) && SLR_REGEN_EXP == 2)
             pb.rng[slot] = make_uint4(rng.s0, rng.s1, rng.s2, rng.s3);
-#endif
             // alpha = 1, pdfPrev = 0 and sp = 0 are implied by ST_FIRST_HIT (see SpAcc): 48 B (RGB) / 196 B (spectral) not written
             newHdr.y = __float_as_uint(camWeight);
             newHdr.z = __float_as_uint(wlOffset);
-#if !(defined(SLR_REGEN_EXP) && SLR_REGEN_EXP == 2)
             pb.rayOrg[slot] = make_float4(lensP.x, lensP.y, lensP.z, 0.0f);
             pb.rayDir[slot] = make_float4(rayDir.x, rayDir.y, rayDir.z, INFINITY);
-#endif
         }
         pb.hdr[slot] = newHdr;
     }
