@@ -101,6 +101,9 @@ struct Builder {
         std::vector<Job> stack;
         stack.push_back(first);
         const int kBins = 16;
+        // development knobs (tree-quality experiments): largest leaf and the leaf-versus-split bias
+        static const uint32_t maxLeaf = [] { const char* e = getenv("SLRHIP_BVH_MAXLEAF"); int v = e ? atoi(e) : (int)kMaxLeafTris; return (uint32_t)std::min((int)kMaxLeafTris, std::max(1, v)); }();
+        static const float leafBias = [] { const char* e = getenv("SLRHIP_BVH_LEAFBIAS"); return e ? (float)atof(e) : 0.125f; }();
         while (!stack.empty()) {
             Job j = stack.back();
             stack.pop_back();
@@ -121,10 +124,7 @@ struct Builder {
             nd.left = nd.right = 0;
             nd.first = j.begin;
             nd.count = n;
-            if (n <= kMaxLeafTris) {
-                // SAH says whether splitting a small set still pays; leaves of <= 4 always fit a packet.
-                if (n <= 1) { nodes[j.node] = nd; continue; }
-            }
+            if (n <= 1) { nodes[j.node] = nd; continue; }       // (a set of <= maxLeaf references may still be split: SAH decides below)
             // binned SAH over the three axes
             float bestCost = INFINITY;
             int bestAxis = -1, bestSplit = 0;
@@ -160,7 +160,7 @@ struct Builder {
             uint32_t mid;
             if (bestAxis >= 0) {
                 float leafCost = box.area() * n;
-                if (n <= kMaxLeafTris && bestCost + 0.125f * box.area() >= leafCost) { nodes[j.node] = nd; continue; }
+                if (n <= maxLeaf && bestCost + leafBias * box.area() >= leafCost) { nodes[j.node] = nd; continue; }
                 float ext = cbox.hi[bestAxis] - cbox.lo[bestAxis];
                 float scale = kBins / ext;
                 float lo = cbox.lo[bestAxis];
@@ -172,7 +172,7 @@ struct Builder {
                 mid = (uint32_t)(it - prims.begin());
             }
             else {
-                if (n <= kMaxLeafTris) { nodes[j.node] = nd; continue; }
+                if (n <= maxLeaf) { nodes[j.node] = nd; continue; }
                 mid = j.begin + n / 2;        // identical centroids: split the list
             }
             if (mid == j.begin || mid == j.end) mid = j.begin + n / 2;
