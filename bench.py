@@ -229,7 +229,8 @@ def main():
                 kernels.pop("trace_shadow")
                 rays["trace"] = 1.0        # unit = one launch's worth of both kinds, bytes below
                 per_ray["trace"] = rays["trace_closest"] * per_ray["trace_closest"] + rays["trace_shadow"] * per_ray["trace_shadow"]
-            dom = max(kernels, key=lambda n: kernels[n]["ms_total"])
+            # the tail kernel (the last paths of a frame, one launch) is listed with the others but is not a roofline subject
+            dom = max((n for n in kernels if n != "tail"), key=lambda n: kernels[n]["ms_total"])
             if dom == "shade":
                 # every live slot is visited once per iteration = once per extension ray (+ idle tail ignored)
                 units, unit_bytes = rays["trace_closest"], slot_bytes
@@ -281,9 +282,10 @@ def main():
             try:
                 # whole-iteration HBM figure: PMC traffic of all kernels of an iteration over their summed launch times
                 ent = traffic_entry(args, W, H, spp)
-                if ent and world == 1 and all(k in ent for k in kernels):
-                    tot_b = sum(ent[k]["traffic_bytes_per_launch"] for k in kernels)
-                    tot_s = sum(kernels[k]["ms_total"] / max(kernels[k]["launches"], 1) for k in kernels) * 1e-3
+                it_kernels = [k for k in kernels if k != "tail"]      # the three launches of a wavefront iteration
+                if ent and world == 1 and all(k in ent for k in it_kernels):
+                    tot_b = sum(ent[k]["traffic_bytes_per_launch"] for k in it_kernels)
+                    tot_s = sum(kernels[k]["ms_total"] / max(kernels[k]["launches"], 1) for k in it_kernels) * 1e-3
                     roof["iteration_traffic_bytes"] = round(tot_b)
                     roof["iteration_frac"] = round(tot_b / tot_s / 1e9 / HBM_PEAK_GBS, 5)
             except (OSError, ValueError):

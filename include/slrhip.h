@@ -24,11 +24,12 @@
 extern "C" {
 #endif
 
-#define SLRHIP_VERSION 5   /* 2: slrhip_material::param2, slrhip_scene_desc::upsampling, Ward / Ashikhmin lobes;
+#define SLRHIP_VERSION 6   /* 2: slrhip_material::param2, slrhip_scene_desc::upsampling, Ward / Ashikhmin lobes;
                             * 3: SLRHIP_MATERIAL_MULTI, slrhip_bsdf_queries (additive: version-2 callers are unaffected);
                             * 4: stripes > 64 rejected, device error word, samples counted on the device (additive);
                             * 5: slrhip_texture (checkerboard textures, bump, alpha), appended to slrhip_scene_desc; host spectrum
-                            *    construction; slrhip_reduce_framebuffer                                                        */
+                            *    construction; slrhip_reduce_framebuffer;
+                            * 6: SLRHIP_KERNEL_TAIL (slrhip_profile grows by one kernel class), SLRHIP_FLAG_NO_TAIL                  */
 
 /* ---- status codes -------------------------------------------------------------- */
 enum {
@@ -302,7 +303,9 @@ enum {
     SLRHIP_KERNEL_TRACE_SHADOW = 1,    /* Scene::testVisibility       */
     SLRHIP_KERNEL_SHADE = 2,           /* k_logic: getSurfacePoint .. bsdf->sample (PathTracingRenderer.cpp:149-258) */
     SLRHIP_KERNEL_REGEN = 3,           /* k_regen: sensor->add + Job::kernel's camera ray (:100-130)  */
-    SLRHIP_KERNEL_COUNT = 4
+    SLRHIP_KERNEL_TAIL = 4,            /* k_tail: the last paths of a render call, each taken to its end by one lane (all of the above
+                                        * in one launch, once no pixel has a pass left to hand out)      */
+    SLRHIP_KERNEL_COUNT = 5
 };
 typedef struct slrhip_profile {
     uint64_t launches[SLRHIP_KERNEL_COUNT];
@@ -314,6 +317,8 @@ typedef struct slrhip_profile {
 } slrhip_profile;
 
 /* config.flags */
+#define SLRHIP_FLAG_NO_TAIL 128u        /* never switch to the tail kernel: the wavefront iterations run until the last path ends.
+                                         * Identical results (every path's arithmetic is the same); kept for A/B checks and timing */
 #define SLRHIP_FLAG_BVH_SPATIAL_SPLITS 64u /* build the tree with spatial splits (sbvh.cpp; the reference's SBVH, Accelerator/SBVH.h:57-348):
                                          * a triangle straddling a split plane is referenced from both sides with clipped boxes.
                                          * Same hits; fewer triangle tests, more node visits: measured slower with these kernels on

@@ -118,6 +118,13 @@ struct PathBuffers {
     // touching their state — the last iterations of a render, in which a few long paths are left, then cost launch overhead
     uint32_t* blockDead;
     uint32_t* errorWord;          // ERR_* bits, sticky until the next slrhip_render call; read back with activeSlots
+    // The end of a render call (pt_tail_kernels.h): as soon as at most RenderParams::tailSlots slots are still live (a slot
+    // goes idle only when its pixel has no pass left, so by then nearly every pixel is done), the traversal kernel of that
+    // iteration raises tailMode (= 1 + the iteration's parity) instead of tracing: every later wavefront launch of the call is
+    // a no-op and the host runs the tail kernels, which take each remaining path — and the passes the remaining pixels still
+    // have to hand out — to the end in one launch.  tailWords = {list length, list cursor}.
+    uint32_t* tailMode;
+    uint32_t* tailWords;
     uint64_t* totals;             // [kind][shard], see totalIndex
     const uint32_t* pixelXY;      // pixel-of-shard -> x | y << 16
 };
@@ -133,7 +140,18 @@ struct RenderParams {
     uint32_t spectral;            // 0 = RGB (3 components), 1 = 16 wavelength samples
     uint32_t spectralQuad;        // spectral shade kernel with four lanes per slot (SLRHIP_FLAG_SPECTRAL_QUAD)
     uint32_t injectError;         // SLRHIP_FLAG_TEST_DEVICE_ERROR: the reset kernel raises the device error word
+    uint32_t tailSlots;           // enter tail mode once at most this many slots are live; 0 = never
 };
+
+// Evaluated by every workgroup of the traversal launch of an iteration: its input is stable during that launch (activeSlots
+// is written by k_regen only), so all workgroups agree; the first one records the decision for the kernels that follow.
+__device__ __forceinline__ bool tailModeBegins(const PathBuffers& pb, uint32_t tailSlots, uint32_t parity) {
+    if (tailSlots == 0u) return false;
+    if (pb.tailMode[0]) return true;
+    if (pb.activeSlots[0] > tailSlots) return false;
+    if (blockIdx.x == 0 && threadIdx.x == 0) pb.tailMode[0] = 1u + parity;
+    return true;
+}
 
 void launchResetSlots(const PathBuffers& pb, const RenderParams& rp, bool clearAccumulators, hipStream_t stream);
 void launchRegen(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, hipStream_t stream);
@@ -143,6 +161,8 @@ void launchTraceShadow(const DevScene& sc, const PathBuffers& pb, const RenderPa
                        hipStream_t stream);
 void launchLogic(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, hipStream_t stream);
 void launchCountSamples(const PathBuffers& pb, const RenderParams& rp, hipStream_t stream);
+// the rest of a render call in one launch (after tailMode was raised): list the live slots, then one lane per path to its end
+void launchTail(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t liveSlots, uint32_t parity, int numCUs, hipStream_t stream);
 void launchResolve(const PathBuffers& pb, const RenderParams& rp, float* dst, hipStream_t stream);
 void launchBsdfQueries(const DevScene& sc, bool spectral, uint32_t material, uint32_t n, const float* in, float wlOffset, uint32_t wl,
                        float4* geo, float4* misc, float4* fsSample, float4* fsEval, hipStream_t stream);

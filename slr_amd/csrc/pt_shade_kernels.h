@@ -442,6 +442,338 @@ __device__ __forceinline__ int32_t texturizeMat(const DevScene& sc, Mat<S>& mm, 
     return mt.w;
 }
 
+// One visit of k_logic to one slot: everything between the state loads and the state stores.  A device function so that the
+// tail kernel (pt_tail_kernels.h) runs the very same code on the last paths of a render call.
+template <class S, bool LDS_TABLES, bool MF, bool MULTI, bool TEX>
+__device__ __forceinline__ void logicSlot(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, const ShadeLds<S::N != 3>& lds,
+                                          const float* lightPMF, const float* lightCDF, uint32_t slot, uint32_t flags, bool leader, uint32_t parity,
+                                          bool& emitExt, bool& emitShadow, bool& emitRegen) {
+    // ---- all state loads up front: one memory round trip instead of a dependent chain (flags: read above) -----------
+    const uint4 r4 = pb.rng[slot];
+    // The path's radiance sum (Kahan pair) and the pending light sample: RGB keeps them in registers (3 x 16 B,
+    // requested with everything else); in spectral mode they are 3 x 64 B that most visits never touch, so they
+    // stay in HBM and SpAcc updates them in place when a contribution actually arrives.
+    S alpha;
+    SpAcc<S> sp;
+    float bsdfPDFprev;
+    SpecIO<S>::load(pb.alpha, pb.pdfPrev, slot, rp.numSlots, alpha, bsdfPDFprev);
+    sp.begin(pb, slot, rp.numSlots);
+    const float4 h = pb.hit[slot];
+    const float4 o4 = pb.rayOrg[slot], d4 = pb.rayDir[slot];
+    const uint32_t vis = pb.visible[slot];
+    const float wlOffset = S::N == 3 ? 0.0f : __uint_as_float(pb.hdr[slot].z);
+
+    const uint32_t state = F_STATE(flags);
+    if (state == ST_FIRST_HIT || state == ST_NEXT_HIT || state == ST_FINISH) {
+        // a path's first visit: throughput 1, no previous PDF, empty radiance sum (k_regen writes none of them)
+        if (state == ST_FIRST_HIT) { alpha = S(1.0f); bsdfPDFprev = 0.0f; }
+        sp.startPath(state == ST_FIRST_HIT, flags);
+        Rng rng;
+        rng.s0 = r4.x; rng.s1 = r4.y; rng.s2 = r4.z; rng.s3 = r4.w;
+        uint32_t pathLength = F_PATHLEN(flags), wlSel = F_WLSEL(flags);
+        const uint32_t wl = F_WL(flags);
+        V3 rayOrg(o4.x, o4.y, o4.z), rayDir(d4.x, d4.y, d4.z);
+        float rayTmin = 0.0f;
+        SurfPt surf;
+        V3 dirOut_sn;
+        bool haveSurf = false;
+        bool finish = false;
+        const uint32_t tri = __float_as_uint(h.x);
+
+        // the hit triangle's shading record: issued before anything else is computed
+        float4 q0, q1, q2, q3, q4, q5;
+        const bool hasHit = state != ST_FINISH && tri != 0xFFFFFFFFu;
+        if (hasHit) {
+            const float4* st = reinterpret_cast<const float4*>(sc.shadeTris) + (size_t)tri * 6;
+            q0 = st[0]; q1 = st[1]; q2 = st[2]; q3 = st[3]; q4 = st[4]; q5 = st[5];
+        }
+
+        // ---- 1. resolve the pending next-event estimate (:180,202) ---------------------------------
+        if (F_SHADOW(flags) && vis) sp.addPendingNee(pb, slot, rp.numSlots);
+
+        // ---- 2. the hit that just came back ------------------------------------------------------------
+        Mat<S> m;
+        float texU = 0.0f, texV = 0.0f;
+        int32_t normalMap = -1;
+        const auto texturize = [&](Mat<S>& mm, uint32_t matIndex) -> int32_t { return texturizeMat<S>(sc, mm, matIndex, texU, texV, wlOffset); };
+        if (!hasHit) {
+            finish = true;                      // ST_FINISH, or a miss: :148 return Zero / :226 break
+            if (state != ST_FINISH && sc.hasEnv) {
+                // the ray left the scene: Scene::intersect falls through to the environment sphere (SurfaceObject.cpp:411-414).
+                // InfiniteSphere::intersect / getSurfacePoint (Surface/InfiniteSphere.cpp:34-59), Vector3::toPolarYUp (Vector3.h:72-75)
+                float theta = acosf(fminf(1.0f, fmaxf(-1.0f, rayDir.y)));
+                float phi = fmodf((float)((double)atan2f(-rayDir.x, rayDir.z) + 2 * kPi), (float)(2 * kPi));
+                float texU = (float)((double)phi / (2 * kPi)), texV = (float)((double)theta / kPi);
+                // emittance x IBLEDF::evaluate = 1 / pi (EDFs/IBLEDF.cpp:19-23)
+                S Le = envEmittanceS<S>(sc, texU, texV, wlOffset) * S((float)(1.0 / kPi));
+                if (state == ST_FIRST_HIT) {
+                    sp.add(pb, slot, rp.numSlots, alpha * Le);             // :152-157, atInfinity -> return sp
+                }
+                else {
+                    // implicit light sampling :232-250; the path ends at infinity before Russian roulette
+                    float sumImps = sc.aggImportance + 1.0f;
+                    float lightProb = 1.0f / sumImps;                        // Scene::evaluateProb SurfaceObject.cpp:456-457
+                    V3 gN = -rayDir;
+                    float lightPDF = lightProb * envAreaPDF(sc, phi, theta) * 1.0f / absDot(rayDir, gN);
+                    float MISWeight = 1.0f;
+                    if (!F_DELTA(flags))
+                        MISWeight = (bsdfPDFprev * bsdfPDFprev) / (lightPDF * lightPDF + bsdfPDFprev * bsdfPDFprev);
+                    sp.add(pb, slot, rp.numSlots, alpha * Le * MISWeight);
+                }
+            }
+        }
+        else {
+            // Triangle::getSurfacePoint, Surface/TriangleMesh.cpp:180-215.  isect.p = org + dir * t (:170)
+            surf.p = rayOrg + rayDir * h.y;
+            surf.gNormal = V3(q3.w, q4.w, q5.w);
+            surf.material = __float_as_uint(q0.w);
+            surf.light = (int32_t)__float_as_uint(q1.w);
+            surf.areaPDF = q2.w;
+            m = MatIO<S>::template load<LDS_TABLES>(sc, lds.mats, surf.material, wlOffset);
+            // the hit record carries Moller-Trumbore's (b1, b2); Intersection::u = b0 = 1 - b1 - b2 as Triangle::intersect
+            // computes it (TriangleMesh.cpp:159), and getSurfacePoint re-derives ITS b2 from (u, v) (:190-191)
+            const float b1 = h.z, b2hit = h.w;
+            const float b0 = 1.0f - b1 - b2hit;
+            const float b2 = 1.0f - b0 - b1;
+            if constexpr (TEX) {
+                // texCoord from the original barycentrics (TriangleMesh.cpp:160-161), then the textures of this material
+                const float4 uvA = sc.triUV[(size_t)tri * 2], uvB = sc.triUV[(size_t)tri * 2 + 1];
+                hitTexCoord(uvA, uvB, b1, b2hit, &texU, &texV);
+                if (m.type & kMatTexturedBit) normalMap = texturize(m, surf.material);
+            }
+            surf.frame.z = normalize(b0 * xyz(q0) + b1 * xyz(q1) + b2 * xyz(q2));
+            surf.frame.x = normalize(b0 * xyz(q3) + b1 * xyz(q4) + b2 * xyz(q5));
+            const float dotNT = dot(surf.frame.z, surf.frame.x);
+            if (fabsf(dotNT) >= 0.01f) surf.frame.x = normalize(surf.frame.x - dotNT * surf.frame.z);
+            surf.frame.y = cross(surf.frame.z, surf.frame.x);
+            if constexpr (TEX) {
+                if (normalMap >= 0) {
+                    // BumpSingleSurfaceObject::getSurfacePoint, Core/SurfaceObject.cpp:123-134
+                    const DevTexture nt = loadTexture(sc.textures, (uint32_t)normalMap);
+                    float uc, vc;
+                    checkerNormalComponents(nt, texU, texV, &uc, &vc);
+                    const V3 nLocal = normalize(V3(uc, vc, 1.0f));
+                    const V3 tLocal = V3(1.0f, 0.0f, 0.0f) - dot(nLocal, V3(1.0f, 0.0f, 0.0f)) * nLocal;
+                    const V3 bLocal = V3(0.0f, 1.0f, 0.0f) - dot(nLocal, V3(0.0f, 1.0f, 0.0f)) * nLocal;
+                    const V3 tt = normalize(surf.frame.fromLocal(tLocal));
+                    const V3 bb = normalize(surf.frame.fromLocal(bLocal));
+                    const V3 nn = normalize(surf.frame.fromLocal(nLocal));
+                    surf.frame.x = tt; surf.frame.y = bb; surf.frame.z = nn;
+                }
+            }
+            haveSurf = true;
+            dirOut_sn = surf.frame.toLocal(-rayDir);
+            if (surf.light >= 0) {
+                S Le = MatIO<S>::template emittance<LDS_TABLES>(sc, lds.mats, surf.material, wlOffset) * S(diffuseEDF(dirOut_sn));
+                if (state == ST_FIRST_HIT) {
+                    sp.add(pb, slot, rp.numSlots, alpha * Le);             // :152-156
+                }
+                else {
+                    // implicit light sampling with MIS :232-249
+                    float lightProb = lightPMF[surf.light] * 1.0f;          // SurfaceObject.cpp:295-298, :78-80
+                    if (sc.hasEnv) lightProb = sc.aggImportance / (sc.aggImportance + 1.0f) * lightProb;   // Scene::evaluateProb :459
+                    float dist2 = sqLength(rayOrg - surf.p);
+                    float lightPDF = lightProb * surf.areaPDF * dist2 / absDot(rayDir, surf.gNormal);
+                    float MISWeight = 1.0f;
+                    if (!F_DELTA(flags))
+                        MISWeight = (bsdfPDFprev * bsdfPDFprev) / (lightPDF * lightPDF + bsdfPDFprev * bsdfPDFprev);
+                    sp.add(pb, slot, rp.numSlots, alpha * Le * MISWeight);
+                }
+            }
+            if (state == ST_NEXT_HIT) {
+                // Russian roulette :254-258 (initY = importance(One) evaluated like the reference)
+                float initY = importance(S(1.0f), wl);
+                float continueProb = fminf(importance(alpha, wl) / initY, 1.0f);
+                if (rng.nextFloat() < continueProb) alpha = alpha / continueProb;
+                else finish = true;
+            }
+        }
+
+        // ---- 3. next bounce: NEE + BSDF sampling (:161-221) ----------------------------------------------
+        if (!finish && haveSurf) {
+            ++pathLength;
+            if (pathLength >= 100) {
+                finish = true;
+            }
+            else {
+                V3 gNorm_sn = surf.frame.toLocal(surf.gNormal);
+                uint32_t type = bsdfType(m.type, wlSel);
+                // SLRHIP_MATERIAL_MULTI: a MultiBSDF whose components are fetched from the material table on demand
+                const auto loadComponent = [&](uint32_t idx) {
+                    Mat<S> cm = MatIO<S>::template load<LDS_TABLES>(sc, lds.mats, idx, wlOffset);
+                    if constexpr (TEX) { if (cm.type & kMatTexturedBit) (void)texturize(cm, idx); }
+                    return cm;
+                };
+                const bool isMulti = MULTI && m.type == SLRHIP_MATERIAL_MULTI;
+                MultiRec multiRec = {};
+                if constexpr (MULTI) {
+                    if (isMulti) {
+                        multiRec = decodeMulti(m);
+                        type = multiType(multiRec, wlSel);
+                    }
+                }
+                if (dtMatches(type, DT_WholeSphere | DT_NonDelta)) {
+                    // Scene::selectLight, SurfaceObject.cpp:432-450 (+ aggregate :279-286)
+                    float lightProb;
+                    float uSel = rng.nextFloat();
+                    bool pickEnv = false;
+                    if (sc.hasEnv) {
+                        float sumImps = sc.aggImportance + 1.0f;
+                        float su = sumImps * uSel;
+                        if (su < sc.aggImportance) uSel = uSel / (sc.aggImportance / sumImps);
+                        else pickEnv = true;
+                    }
+                    float lu0 = rng.nextFloat();
+                    float lu1 = rng.nextFloat();
+                    V3 lp, lgn;
+                    Frame lf;
+                    float areaPDF;
+                    S M;
+                    float shadowTmax;
+                    V3 sdir;
+                    if (pickEnv) {
+                        lightProb = 1.0f * (1.0f / (sc.aggImportance + 1.0f));
+                        // InfiniteSphereSurfaceObject::sample, SurfaceObject.cpp:158-185
+                        float topPDF, rowPDF;
+                        float d1 = sampleContinuous1D(sc.envTopCDF, sc.envTopPDF, sc.envMapHeight, lu1, &topPDF);
+                        uint32_t idx1D = min((uint32_t)((float)sc.envMapHeight * d1), sc.envMapHeight - 1);
+                        float d0 = sampleContinuous1D(sc.envRowCDF + (size_t)idx1D * (sc.envMapWidth + 1), sc.envRowPDF + (size_t)idx1D * sc.envMapWidth,
+                                                      sc.envMapWidth, lu0, &rowPDF);
+                        float uvPDF = rowPDF * topPDF;
+                        float phi = (float)((double)d0 * (2 * kPi));
+                        float theta = (float)((double)d1 * kPi);
+                        lp = V3(-sinf(phi) * sinf(theta), cosf(theta), cosf(phi) * sinf(theta));
+                        lgn = -lp;
+                        lf.x = normalize(V3(-cosf(phi), 0.0f, -sinf(phi)));
+                        lf.z = lgn;
+                        lf.y = cross(lf.z, lf.x);
+                        areaPDF = (float)((double)uvPDF / (2 * kPi * kPi * (double)sinf(theta)));
+                        M = envEmittanceS<S>(sc, (float)((double)phi / (2 * kPi)), (float)((double)theta / kPi), wlOffset);
+                        sdir = normalize(lp);                              // Scene::testVisibility :421-423: [eps, FLT_MAX]
+                        shadowTmax = 3.402823466e+38f;
+                    }
+                    else {
+                        uint32_t li = selectLight(sc, lightCDF, lightPMF, uSel, &lightProb);
+                        lightProb *= 1.0f;
+                        if (sc.hasEnv) lightProb *= sc.aggImportance / (sc.aggImportance + 1.0f);
+                        // Triangle::sample TriangleMesh.cpp:224-255
+                        const float4* lt = (LDS_TABLES ? lds.lights : reinterpret_cast<const float4*>(sc.lightTris)) + (size_t)li * 9;
+                        float4 l0 = lt[0], l1 = lt[1], l2 = lt[2], l3 = lt[3], l4 = lt[4], l5 = lt[5], l6 = lt[6], l7 = lt[7], l8 = lt[8];
+                        float su1 = sqrtf(lu0);
+                        float b0 = 1.0f - su1;
+                        float b1 = lu1 * su1;
+                        float b2 = 1.0f - b0 - b1;
+                        lp = b0 * xyz(l0) + b1 * xyz(l1) + b2 * xyz(l2);
+                        lgn = V3(l3.w, l4.w, l5.w);
+                        lf.z = normalize(b0 * xyz(l3) + b1 * xyz(l4) + b2 * xyz(l5));
+                        lf.x = normalize(b0 * xyz(l6) + b1 * xyz(l7) + b2 * xyz(l8));
+                        lf.y = cross(lf.z, lf.x);
+                        areaPDF = l2.w;
+                        const uint32_t lmat = __float_as_uint(l1.w);
+                        M = MatIO<S>::template emittance<LDS_TABLES>(sc, lds.mats, lmat, wlOffset);
+                        // shadow ray of Scene::testVisibility SurfaceObject.cpp:425-426
+                        float dist = length(surf.p - lp);
+                        sdir = (lp - surf.p) / dist;
+                        shadowTmax = dist * (1 - kRayEpsilon);
+                    }
+                    if (leader) pb.shadowDir[slot] = make_float4(sdir.x, sdir.y, sdir.z, shadowTmax);
+                    emitShadow = true;
+                    // contribution if visible :181-202
+                    float dist2;
+                    V3 shadowDir;
+                    if (pickEnv) { dist2 = 1.0f; shadowDir = normalize(lp); }   // SurfacePoint::getDirectionFrom geometry.cpp:32-37
+                    else {
+                        V3 dvec = lp - surf.p;
+                        dist2 = sqLength(dvec);
+                        shadowDir = dvec / sqrtf(dist2);
+                    }
+                    V3 shadowDir_l = lf.toLocal(-shadowDir);
+                    V3 shadowDir_sn = surf.frame.toLocal(shadowDir);
+                    S Le = M * S(pickEnv ? (float)(1.0 / kPi) : diffuseEDF(shadowDir_l));
+                    float lightPDF = lightProb * areaPDF;
+                    float pdfDir = 0.0f;
+                    S fs;
+                    bool evaluated = false;
+                    if constexpr (MULTI) {
+                        if (isMulti) {
+                            const MultiBSDF<S, decltype(loadComponent)> multi = {multiRec, wlSel, loadComponent};
+                            fs = multi.evaluate(type, dirOut_sn, gNorm_sn, shadowDir_sn, wl, &pdfDir);
+                            evaluated = true;
+                        }
+                    }
+                    if (!evaluated) fs = bsdfEvaluate<S, MF>(m, type, dirOut_sn, gNorm_sn, shadowDir_sn, wl, &pdfDir);
+                    float cosLight = absDot(-shadowDir, lgn);
+                    float bsdfPDF = pdfDir * cosLight / dist2;
+                    float MISWeight = 1.0f;
+                    if (!isinf(areaPDF))
+                        MISWeight = (lightPDF * lightPDF) / (lightPDF * lightPDF + bsdfPDF * bsdfPDF);
+                    float G = absDot(shadowDir_sn, gNorm_sn) * cosLight / dist2;
+                    S contrib = alpha * Le * fs * (G * MISWeight / lightPDF);
+                    SpecIO<S>::store(pb.nee, nullptr, slot, rp.numSlots, contrib, 0.0f);
+                }
+                float uComp = rng.nextFloat();
+                float u0 = rng.nextFloat();
+                float u1 = rng.nextFloat();
+                BsdfSample bs;
+                S fs;
+                bool sampled = false;
+                if constexpr (MULTI) {
+                    if (isMulti) {
+                        const MultiBSDF<S, decltype(loadComponent)> multi = {multiRec, wlSel, loadComponent};
+                        fs = multi.sample(type, dirOut_sn, gNorm_sn, wl, uComp, u0, u1, &bs);
+                        sampled = true;
+                    }
+                }
+                if (!sampled) fs = bsdfSample<S, MF>(m, type, dirOut_sn, gNorm_sn, wl, uComp, u0, u1, &bs);
+                if (fs.isZero() || bs.dirPDF == 0.0f) {
+                    finish = true;                                         // :209
+                }
+                else {
+                    if (bs.dirType & DT_Dispersive) {                      // :211-214
+                        bs.dirPDF /= S::N;                                 // WavelengthSamples::NumComponents
+                        wlSel = 1;
+                    }
+                    alpha = alpha * (fs * absDot(bs.dir_sn, gNorm_sn) / bs.dirPDF);     // :215
+                    rayDir = surf.frame.fromLocal(bs.dir_sn);
+                    rayOrg = surf.p;                                       // :221 Ray(p, dirIn, time, eps)
+                    rayTmin = kRayEpsilon;
+                    bsdfPDFprev = bs.dirPDF;
+                    flags = F_MAKE((uint32_t)ST_NEXT_HIT, pathLength, wl, wlSel, dtIsDelta(bs.dirType) ? 1u : 0u, emitShadow ? 1u : 0u);
+                    emitExt = true;
+                }
+                // the shadow ray starts at the shading point, which is also the next ray's origin
+                if (emitShadow && !emitExt && leader) pb.rayOrg[slot] = make_float4(surf.p.x, surf.p.y, surf.p.z, kRayEpsilon);
+            }
+        }
+
+        // ---- 4. path finished ----------------------------------------------------------------------------
+        if (finish && emitShadow) {
+            // the NEE of this bounce is still in flight: finish next iteration
+            flags = F_MAKE((uint32_t)ST_FINISH, pathLength, wl, wlSel, 0u, 1u);
+        }
+        else if (finish) {
+            flags = F_MAKE((uint32_t)ST_REGEN, 0u, 0u, 0u, 0u, 0u) | (1u << 15);
+            emitRegen = true;
+        }
+
+        // ---- store path state ---------------------------------------------------------------------------
+        if (leader) pb.flags[slot] = flags | sp.validBits();
+        if (emitRegen && leader) {
+            const uint32_t stripe = slot / rp.numPixels;
+            atomicOr(pb.finishedMask + (size_t)(parity ^ 1) * rp.numPixels + (slot - stripe * rp.numPixels), 1ull << stripe);
+        }
+        sp.end(pb, slot, rp.numSlots, !emitRegen);
+        if (!emitRegen) {
+            if (leader) pb.rng[slot] = make_uint4(rng.s0, rng.s1, rng.s2, rng.s3);
+            SpecIO<S>::store(pb.alpha, pb.pdfPrev, slot, rp.numSlots, alpha, bsdfPDFprev);
+        }
+        if (emitExt && leader) {
+            pb.rayOrg[slot] = make_float4(rayOrg.x, rayOrg.y, rayOrg.z, rayTmin);
+            pb.rayDir[slot] = make_float4(rayDir.x, rayDir.y, rayDir.z, INFINITY);
+        }
+    }
+}
+
 template <class S, bool LDS_TABLES, bool MF, bool MULTI = false, bool TEX = false>
 __global__ __launch_bounds__(kShadeBlock)
 __attribute__((amdgpu_waves_per_eu(S::N == 3 ? SLR_WAVES_RGB : (MF ? SLR_WAVES_SPECTRAL_GLOSSY : SLR_WAVES_SPECTRAL)))) void k_logic(DevScene sc, PathBuffers pb, RenderParams rp, uint32_t parity) {
@@ -454,7 +786,7 @@ __attribute__((amdgpu_waves_per_eu(S::N == 3 ? SLR_WAVES_RGB : (MF ? SLR_WAVES_S
     const bool leader = L == 1 || (threadIdx.x & (L - 1)) == 0;
 
     // ---- the end of a render: nothing left anywhere / nothing left in this block ------------------------------------------
-    if (pb.activeSlots[0] == 0) return;                                   // every slot is out of passes (uniform)
+    if (pb.activeSlots[0] == 0 || pb.tailMode[0]) return;                 // every slot is out of passes / the tail kernel takes over (uniform)
     const uint32_t deadIdx = (blockIdx.x * kShadeBlock / L) / kShadeBlock;   // 256-slot block of this workgroup's first slot
     if (pb.blockDead[deadIdx]) return;
     uint32_t flags = slot < rp.numSlots ? pb.flags[slot] : (uint32_t)ST_IDLE;
@@ -507,332 +839,8 @@ __attribute__((amdgpu_waves_per_eu(S::N == 3 ? SLR_WAVES_RGB : (MF ? SLR_WAVES_S
         }
     }
 
-    if (slot < rp.numSlots) {
-        // ---- all state loads up front: one memory round trip instead of a dependent chain (flags: read above) -----------
-        const uint4 r4 = pb.rng[slot];
-        // The path's radiance sum (Kahan pair) and the pending light sample: RGB keeps them in registers (3 x 16 B,
-        // requested with everything else); in spectral mode they are 3 x 64 B that most visits never touch, so they
-        // stay in HBM and SpAcc updates them in place when a contribution actually arrives.
-        S alpha;
-        SpAcc<S> sp;
-        float bsdfPDFprev;
-        SpecIO<S>::load(pb.alpha, pb.pdfPrev, slot, rp.numSlots, alpha, bsdfPDFprev);
-        sp.begin(pb, slot, rp.numSlots);
-        const float4 h = pb.hit[slot];
-        const float4 o4 = pb.rayOrg[slot], d4 = pb.rayDir[slot];
-        const uint32_t vis = pb.visible[slot];
-        const float wlOffset = S::N == 3 ? 0.0f : __uint_as_float(pb.hdr[slot].z);
-
-        const uint32_t state = F_STATE(flags);
-        if (state == ST_FIRST_HIT || state == ST_NEXT_HIT || state == ST_FINISH) {
-            // a path's first visit: throughput 1, no previous PDF, empty radiance sum (k_regen writes none of them)
-            if (state == ST_FIRST_HIT) { alpha = S(1.0f); bsdfPDFprev = 0.0f; }
-            sp.startPath(state == ST_FIRST_HIT, flags);
-            Rng rng;
-            rng.s0 = r4.x; rng.s1 = r4.y; rng.s2 = r4.z; rng.s3 = r4.w;
-            uint32_t pathLength = F_PATHLEN(flags), wlSel = F_WLSEL(flags);
-            const uint32_t wl = F_WL(flags);
-            V3 rayOrg(o4.x, o4.y, o4.z), rayDir(d4.x, d4.y, d4.z);
-            float rayTmin = 0.0f;
-            SurfPt surf;
-            V3 dirOut_sn;
-            bool haveSurf = false;
-            bool finish = false;
-            const uint32_t tri = __float_as_uint(h.x);
-
-            // the hit triangle's shading record: issued before anything else is computed
-            float4 q0, q1, q2, q3, q4, q5;
-            const bool hasHit = state != ST_FINISH && tri != 0xFFFFFFFFu;
-            if (hasHit) {
-                const float4* st = reinterpret_cast<const float4*>(sc.shadeTris) + (size_t)tri * 6;
-                q0 = st[0]; q1 = st[1]; q2 = st[2]; q3 = st[3]; q4 = st[4]; q5 = st[5];
-            }
-
-            // ---- 1. resolve the pending next-event estimate (:180,202) ---------------------------------
-            if (F_SHADOW(flags) && vis) sp.addPendingNee(pb, slot, rp.numSlots);
-
-            // ---- 2. the hit that just came back ------------------------------------------------------------
-            Mat<S> m;
-            float texU = 0.0f, texV = 0.0f;
-            int32_t normalMap = -1;
-            const auto texturize = [&](Mat<S>& mm, uint32_t matIndex) -> int32_t { return texturizeMat<S>(sc, mm, matIndex, texU, texV, wlOffset); };
-            if (!hasHit) {
-                finish = true;                      // ST_FINISH, or a miss: :148 return Zero / :226 break
-                if (state != ST_FINISH && sc.hasEnv) {
-                    // the ray left the scene: Scene::intersect falls through to the environment sphere (SurfaceObject.cpp:411-414).
-                    // InfiniteSphere::intersect / getSurfacePoint (Surface/InfiniteSphere.cpp:34-59), Vector3::toPolarYUp (Vector3.h:72-75)
-                    float theta = acosf(fminf(1.0f, fmaxf(-1.0f, rayDir.y)));
-                    float phi = fmodf((float)((double)atan2f(-rayDir.x, rayDir.z) + 2 * kPi), (float)(2 * kPi));
-                    float texU = (float)((double)phi / (2 * kPi)), texV = (float)((double)theta / kPi);
-                    // emittance x IBLEDF::evaluate = 1 / pi (EDFs/IBLEDF.cpp:19-23)
-                    S Le = envEmittanceS<S>(sc, texU, texV, wlOffset) * S((float)(1.0 / kPi));
-                    if (state == ST_FIRST_HIT) {
-                        sp.add(pb, slot, rp.numSlots, alpha * Le);             // :152-157, atInfinity -> return sp
-                    }
-                    else {
-                        // implicit light sampling :232-250; the path ends at infinity before Russian roulette
-                        float sumImps = sc.aggImportance + 1.0f;
-                        float lightProb = 1.0f / sumImps;                        // Scene::evaluateProb SurfaceObject.cpp:456-457
-                        V3 gN = -rayDir;
-                        float lightPDF = lightProb * envAreaPDF(sc, phi, theta) * 1.0f / absDot(rayDir, gN);
-                        float MISWeight = 1.0f;
-                        if (!F_DELTA(flags))
-                            MISWeight = (bsdfPDFprev * bsdfPDFprev) / (lightPDF * lightPDF + bsdfPDFprev * bsdfPDFprev);
-                        sp.add(pb, slot, rp.numSlots, alpha * Le * MISWeight);
-                    }
-                }
-            }
-            else {
-                // Triangle::getSurfacePoint, Surface/TriangleMesh.cpp:180-215.  isect.p = org + dir * t (:170)
-                surf.p = rayOrg + rayDir * h.y;
-                surf.gNormal = V3(q3.w, q4.w, q5.w);
-                surf.material = __float_as_uint(q0.w);
-                surf.light = (int32_t)__float_as_uint(q1.w);
-                surf.areaPDF = q2.w;
-                m = MatIO<S>::template load<LDS_TABLES>(sc, lds.mats, surf.material, wlOffset);
-                // the hit record carries Moller-Trumbore's (b1, b2); Intersection::u = b0 = 1 - b1 - b2 as Triangle::intersect
-                // computes it (TriangleMesh.cpp:159), and getSurfacePoint re-derives ITS b2 from (u, v) (:190-191)
-                const float b1 = h.z, b2hit = h.w;
-                const float b0 = 1.0f - b1 - b2hit;
-                const float b2 = 1.0f - b0 - b1;
-                if constexpr (TEX) {
-                    // texCoord from the original barycentrics (TriangleMesh.cpp:160-161), then the textures of this material
-                    const float4 uvA = sc.triUV[(size_t)tri * 2], uvB = sc.triUV[(size_t)tri * 2 + 1];
-                    hitTexCoord(uvA, uvB, b1, b2hit, &texU, &texV);
-                    if (m.type & kMatTexturedBit) normalMap = texturize(m, surf.material);
-                }
-                surf.frame.z = normalize(b0 * xyz(q0) + b1 * xyz(q1) + b2 * xyz(q2));
-                surf.frame.x = normalize(b0 * xyz(q3) + b1 * xyz(q4) + b2 * xyz(q5));
-                const float dotNT = dot(surf.frame.z, surf.frame.x);
-                if (fabsf(dotNT) >= 0.01f) surf.frame.x = normalize(surf.frame.x - dotNT * surf.frame.z);
-                surf.frame.y = cross(surf.frame.z, surf.frame.x);
-                if constexpr (TEX) {
-                    if (normalMap >= 0) {
-                        // BumpSingleSurfaceObject::getSurfacePoint, Core/SurfaceObject.cpp:123-134
-                        const DevTexture nt = loadTexture(sc.textures, (uint32_t)normalMap);
-                        float uc, vc;
-                        checkerNormalComponents(nt, texU, texV, &uc, &vc);
-                        const V3 nLocal = normalize(V3(uc, vc, 1.0f));
-                        const V3 tLocal = V3(1.0f, 0.0f, 0.0f) - dot(nLocal, V3(1.0f, 0.0f, 0.0f)) * nLocal;
-                        const V3 bLocal = V3(0.0f, 1.0f, 0.0f) - dot(nLocal, V3(0.0f, 1.0f, 0.0f)) * nLocal;
-                        const V3 tt = normalize(surf.frame.fromLocal(tLocal));
-                        const V3 bb = normalize(surf.frame.fromLocal(bLocal));
-                        const V3 nn = normalize(surf.frame.fromLocal(nLocal));
-                        surf.frame.x = tt; surf.frame.y = bb; surf.frame.z = nn;
-                    }
-                }
-                haveSurf = true;
-                dirOut_sn = surf.frame.toLocal(-rayDir);
-                if (surf.light >= 0) {
-                    S Le = MatIO<S>::template emittance<LDS_TABLES>(sc, lds.mats, surf.material, wlOffset) * S(diffuseEDF(dirOut_sn));
-                    if (state == ST_FIRST_HIT) {
-                        sp.add(pb, slot, rp.numSlots, alpha * Le);             // :152-156
-                    }
-                    else {
-                        // implicit light sampling with MIS :232-249
-                        float lightProb = lightPMF[surf.light] * 1.0f;          // SurfaceObject.cpp:295-298, :78-80
-                        if (sc.hasEnv) lightProb = sc.aggImportance / (sc.aggImportance + 1.0f) * lightProb;   // Scene::evaluateProb :459
-                        float dist2 = sqLength(rayOrg - surf.p);
-                        float lightPDF = lightProb * surf.areaPDF * dist2 / absDot(rayDir, surf.gNormal);
-                        float MISWeight = 1.0f;
-                        if (!F_DELTA(flags))
-                            MISWeight = (bsdfPDFprev * bsdfPDFprev) / (lightPDF * lightPDF + bsdfPDFprev * bsdfPDFprev);
-                        sp.add(pb, slot, rp.numSlots, alpha * Le * MISWeight);
-                    }
-                }
-                if (state == ST_NEXT_HIT) {
-                    // Russian roulette :254-258 (initY = importance(One) evaluated like the reference)
-                    float initY = importance(S(1.0f), wl);
-                    float continueProb = fminf(importance(alpha, wl) / initY, 1.0f);
-                    if (rng.nextFloat() < continueProb) alpha = alpha / continueProb;
-                    else finish = true;
-                }
-            }
-
-            // ---- 3. next bounce: NEE + BSDF sampling (:161-221) ----------------------------------------------
-            if (!finish && haveSurf) {
-                ++pathLength;
-                if (pathLength >= 100) {
-                    finish = true;
-                }
-                else {
-                    V3 gNorm_sn = surf.frame.toLocal(surf.gNormal);
-                    uint32_t type = bsdfType(m.type, wlSel);
-                    // SLRHIP_MATERIAL_MULTI: a MultiBSDF whose components are fetched from the material table on demand
-                    const auto loadComponent = [&](uint32_t idx) {
-                        Mat<S> cm = MatIO<S>::template load<LDS_TABLES>(sc, lds.mats, idx, wlOffset);
-                        if constexpr (TEX) { if (cm.type & kMatTexturedBit) (void)texturize(cm, idx); }
-                        return cm;
-                    };
-                    const bool isMulti = MULTI && m.type == SLRHIP_MATERIAL_MULTI;
-                    MultiRec multiRec = {};
-                    if constexpr (MULTI) {
-                        if (isMulti) {
-                            multiRec = decodeMulti(m);
-                            type = multiType(multiRec, wlSel);
-                        }
-                    }
-                    if (dtMatches(type, DT_WholeSphere | DT_NonDelta)) {
-                        // Scene::selectLight, SurfaceObject.cpp:432-450 (+ aggregate :279-286)
-                        float lightProb;
-                        float uSel = rng.nextFloat();
-                        bool pickEnv = false;
-                        if (sc.hasEnv) {
-                            float sumImps = sc.aggImportance + 1.0f;
-                            float su = sumImps * uSel;
-                            if (su < sc.aggImportance) uSel = uSel / (sc.aggImportance / sumImps);
-                            else pickEnv = true;
-                        }
-                        float lu0 = rng.nextFloat();
-                        float lu1 = rng.nextFloat();
-                        V3 lp, lgn;
-                        Frame lf;
-                        float areaPDF;
-                        S M;
-                        float shadowTmax;
-                        V3 sdir;
-                        if (pickEnv) {
-                            lightProb = 1.0f * (1.0f / (sc.aggImportance + 1.0f));
-                            // InfiniteSphereSurfaceObject::sample, SurfaceObject.cpp:158-185
-                            float topPDF, rowPDF;
-                            float d1 = sampleContinuous1D(sc.envTopCDF, sc.envTopPDF, sc.envMapHeight, lu1, &topPDF);
-                            uint32_t idx1D = min((uint32_t)((float)sc.envMapHeight * d1), sc.envMapHeight - 1);
-                            float d0 = sampleContinuous1D(sc.envRowCDF + (size_t)idx1D * (sc.envMapWidth + 1), sc.envRowPDF + (size_t)idx1D * sc.envMapWidth,
-                                                          sc.envMapWidth, lu0, &rowPDF);
-                            float uvPDF = rowPDF * topPDF;
-                            float phi = (float)((double)d0 * (2 * kPi));
-                            float theta = (float)((double)d1 * kPi);
-                            lp = V3(-sinf(phi) * sinf(theta), cosf(theta), cosf(phi) * sinf(theta));
-                            lgn = -lp;
-                            lf.x = normalize(V3(-cosf(phi), 0.0f, -sinf(phi)));
-                            lf.z = lgn;
-                            lf.y = cross(lf.z, lf.x);
-                            areaPDF = (float)((double)uvPDF / (2 * kPi * kPi * (double)sinf(theta)));
-                            M = envEmittanceS<S>(sc, (float)((double)phi / (2 * kPi)), (float)((double)theta / kPi), wlOffset);
-                            sdir = normalize(lp);                              // Scene::testVisibility :421-423: [eps, FLT_MAX]
-                            shadowTmax = 3.402823466e+38f;
-                        }
-                        else {
-                            uint32_t li = selectLight(sc, lightCDF, lightPMF, uSel, &lightProb);
-                            lightProb *= 1.0f;
-                            if (sc.hasEnv) lightProb *= sc.aggImportance / (sc.aggImportance + 1.0f);
-                            // Triangle::sample TriangleMesh.cpp:224-255
-                            const float4* lt = (LDS_TABLES ? lds.lights : reinterpret_cast<const float4*>(sc.lightTris)) + (size_t)li * 9;
-                            float4 l0 = lt[0], l1 = lt[1], l2 = lt[2], l3 = lt[3], l4 = lt[4], l5 = lt[5], l6 = lt[6], l7 = lt[7], l8 = lt[8];
-                            float su1 = sqrtf(lu0);
-                            float b0 = 1.0f - su1;
-                            float b1 = lu1 * su1;
-                            float b2 = 1.0f - b0 - b1;
-                            lp = b0 * xyz(l0) + b1 * xyz(l1) + b2 * xyz(l2);
-                            lgn = V3(l3.w, l4.w, l5.w);
-                            lf.z = normalize(b0 * xyz(l3) + b1 * xyz(l4) + b2 * xyz(l5));
-                            lf.x = normalize(b0 * xyz(l6) + b1 * xyz(l7) + b2 * xyz(l8));
-                            lf.y = cross(lf.z, lf.x);
-                            areaPDF = l2.w;
-                            const uint32_t lmat = __float_as_uint(l1.w);
-                            M = MatIO<S>::template emittance<LDS_TABLES>(sc, lds.mats, lmat, wlOffset);
-                            // shadow ray of Scene::testVisibility SurfaceObject.cpp:425-426
-                            float dist = length(surf.p - lp);
-                            sdir = (lp - surf.p) / dist;
-                            shadowTmax = dist * (1 - kRayEpsilon);
-                        }
-                        if (leader) pb.shadowDir[slot] = make_float4(sdir.x, sdir.y, sdir.z, shadowTmax);
-                        emitShadow = true;
-                        // contribution if visible :181-202
-                        float dist2;
-                        V3 shadowDir;
-                        if (pickEnv) { dist2 = 1.0f; shadowDir = normalize(lp); }   // SurfacePoint::getDirectionFrom geometry.cpp:32-37
-                        else {
-                            V3 dvec = lp - surf.p;
-                            dist2 = sqLength(dvec);
-                            shadowDir = dvec / sqrtf(dist2);
-                        }
-                        V3 shadowDir_l = lf.toLocal(-shadowDir);
-                        V3 shadowDir_sn = surf.frame.toLocal(shadowDir);
-                        S Le = M * S(pickEnv ? (float)(1.0 / kPi) : diffuseEDF(shadowDir_l));
-                        float lightPDF = lightProb * areaPDF;
-                        float pdfDir = 0.0f;
-                        S fs;
-                        bool evaluated = false;
-                        if constexpr (MULTI) {
-                            if (isMulti) {
-                                const MultiBSDF<S, decltype(loadComponent)> multi = {multiRec, wlSel, loadComponent};
-                                fs = multi.evaluate(type, dirOut_sn, gNorm_sn, shadowDir_sn, wl, &pdfDir);
-                                evaluated = true;
-                            }
-                        }
-                        if (!evaluated) fs = bsdfEvaluate<S, MF>(m, type, dirOut_sn, gNorm_sn, shadowDir_sn, wl, &pdfDir);
-                        float cosLight = absDot(-shadowDir, lgn);
-                        float bsdfPDF = pdfDir * cosLight / dist2;
-                        float MISWeight = 1.0f;
-                        if (!isinf(areaPDF))
-                            MISWeight = (lightPDF * lightPDF) / (lightPDF * lightPDF + bsdfPDF * bsdfPDF);
-                        float G = absDot(shadowDir_sn, gNorm_sn) * cosLight / dist2;
-                        S contrib = alpha * Le * fs * (G * MISWeight / lightPDF);
-                        SpecIO<S>::store(pb.nee, nullptr, slot, rp.numSlots, contrib, 0.0f);
-                    }
-                    float uComp = rng.nextFloat();
-                    float u0 = rng.nextFloat();
-                    float u1 = rng.nextFloat();
-                    BsdfSample bs;
-                    S fs;
-                    bool sampled = false;
-                    if constexpr (MULTI) {
-                        if (isMulti) {
-                            const MultiBSDF<S, decltype(loadComponent)> multi = {multiRec, wlSel, loadComponent};
-                            fs = multi.sample(type, dirOut_sn, gNorm_sn, wl, uComp, u0, u1, &bs);
-                            sampled = true;
-                        }
-                    }
-                    if (!sampled) fs = bsdfSample<S, MF>(m, type, dirOut_sn, gNorm_sn, wl, uComp, u0, u1, &bs);
-                    if (fs.isZero() || bs.dirPDF == 0.0f) {
-                        finish = true;                                         // :209
-                    }
-                    else {
-                        if (bs.dirType & DT_Dispersive) {                      // :211-214
-                            bs.dirPDF /= S::N;                                 // WavelengthSamples::NumComponents
-                            wlSel = 1;
-                        }
-                        alpha = alpha * (fs * absDot(bs.dir_sn, gNorm_sn) / bs.dirPDF);     // :215
-                        rayDir = surf.frame.fromLocal(bs.dir_sn);
-                        rayOrg = surf.p;                                       // :221 Ray(p, dirIn, time, eps)
-                        rayTmin = kRayEpsilon;
-                        bsdfPDFprev = bs.dirPDF;
-                        flags = F_MAKE((uint32_t)ST_NEXT_HIT, pathLength, wl, wlSel, dtIsDelta(bs.dirType) ? 1u : 0u, emitShadow ? 1u : 0u);
-                        emitExt = true;
-                    }
-                    // the shadow ray starts at the shading point, which is also the next ray's origin
-                    if (emitShadow && !emitExt && leader) pb.rayOrg[slot] = make_float4(surf.p.x, surf.p.y, surf.p.z, kRayEpsilon);
-                }
-            }
-
-            // ---- 4. path finished ----------------------------------------------------------------------------
-            if (finish && emitShadow) {
-                // the NEE of this bounce is still in flight: finish next iteration
-                flags = F_MAKE((uint32_t)ST_FINISH, pathLength, wl, wlSel, 0u, 1u);
-            }
-            else if (finish) {
-                flags = F_MAKE((uint32_t)ST_REGEN, 0u, 0u, 0u, 0u, 0u) | (1u << 15);
-                emitRegen = true;
-            }
-
-            // ---- store path state ---------------------------------------------------------------------------
-            if (leader) pb.flags[slot] = flags | sp.validBits();
-            if (emitRegen && leader) {
-                const uint32_t stripe = slot / rp.numPixels;
-                atomicOr(pb.finishedMask + (size_t)(parity ^ 1) * rp.numPixels + (slot - stripe * rp.numPixels), 1ull << stripe);
-            }
-            sp.end(pb, slot, rp.numSlots, !emitRegen);
-            if (!emitRegen) {
-                if (leader) pb.rng[slot] = make_uint4(rng.s0, rng.s1, rng.s2, rng.s3);
-                SpecIO<S>::store(pb.alpha, pb.pdfPrev, slot, rp.numSlots, alpha, bsdfPDFprev);
-            }
-            if (emitExt && leader) {
-                pb.rayOrg[slot] = make_float4(rayOrg.x, rayOrg.y, rayOrg.z, rayTmin);
-                pb.rayDir[slot] = make_float4(rayDir.x, rayDir.y, rayDir.z, INFINITY);
-            }
-        }
-    }
+    if (slot < rp.numSlots)
+        logicSlot<S, LDS_TABLES, MF, MULTI, TEX>(sc, pb, rp, lds, lightPMF, lightCDF, slot, flags, leader, parity, emitExt, emitShadow, emitRegen);
 
     // ---- stream compaction of the shadow rays and of the finished slots -----------------------------------------
     (void)emitExt;     // extension rays need no queue: the traversal kernel reads the state flag
@@ -883,9 +891,77 @@ __device__ __forceinline__ Spec16 storageAddend(const Spec16& val, float wlOffse
     return addend;
 }
 
+// Job::kernel's camera half (PathTracingRenderer.cpp:100-120): seeds the sample's stream, draws in source (left-to-right)
+// order and leaves the slot with a camera ray in flight (k_regen; the tail kernel for the passes left when it takes over).
+template <class S>
+__device__ __forceinline__ void startSample(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t slot, uint32_t pix, uint32_t pass,
+                                            uint4& newHdr) {
+    // Job::kernel PathTracingRenderer.cpp:100-120, draws in source (left-to-right) order
+    const uint32_t xy = pb.pixelXY[pix];
+    const uint32_t px = xy & 0xFFFFu, py = xy >> 16;
+    Rng rng;
+    rng.seed(sampleSeed(rp.rngSeed, px, py, pass));
+    float v = rng.nextFloat();
+    float time = rp.timeStart * (1 - v) + rp.timeEnd * v;
+    (void)time;
+    float pxx = px + rng.nextFloat();
+    float pyy = py + rng.nextFloat();
+    // createWithEqualOffsets: RGBTypes.h:37-45 (offset unused, PDF 1) / SpectrumTypes.h:54-64 (PDF N / 470)
+    const float wlOffset = rng.nextFloat();
+    float uLambda = rng.nextFloat();
+    const uint32_t wl = min((uint32_t)(uint16_t)(S::N * uLambda), (uint32_t)(S::N - 1));
+    const float selectWLPDF = S::N == 3 ? 1.0f : S::N / (830.0f - 360.0f);
+    float lu0 = rng.nextFloat();
+    float lu1 = rng.nextFloat();
+    // PerspectiveCamera::sample PerspectiveCamera.cpp:33-57
+    float lx, ly;
+    concentricSampleDisk(lu0, lu1, &lx, &ly);
+    V3 orgLocal(sc.camera.lensRadius * lx, sc.camera.lensRadius * ly, 0.0f);
+    V3 lensP = mulPoint(sc.camera.mat, orgLocal);
+    V3 lensN = mulNormal(sc.camera.matInv, V3(0, 0, 1));
+    Frame lf;
+    lf.z = lensN;
+    lf.x = mulVector(sc.camera.mat, V3(1, 0, 0));
+    lf.y = cross(lf.z, lf.x);
+    // PerspectiveIDF::sample :63-74 with IDFSample(p.x / W, p.y / H)
+    float sx = pxx / (float)rp.imageWidth;
+    float sy = pyy / (float)rp.imageHeight;
+    V3 pFocus(sc.camera.opWidth * (0.5f - sx), sc.camera.opHeight * (0.5f - sy), sc.camera.objPlaneDistance);
+    V3 dirLocal = normalize(pFocus - orgLocal);
+    float dirPDF = sc.camera.imgPlaneDistance * sc.camera.imgPlaneDistance /
+                   ((dirLocal.z * dirLocal.z * dirLocal.z) * sc.camera.imgPlaneArea);
+    V3 rayDir = lf.fromLocal(dirLocal);
+    // weight :126
+    float camWeight = absDot(rayDir, lensN) / (sc.camera.areaPDF * dirPDF * selectWLPDF);
+    pb.flags[slot] = F_MAKE((uint32_t)ST_FIRST_HIT, 0u, wl, 0u, 0u, 0u);
+    pb.rng[slot] = make_uint4(rng.s0, rng.s1, rng.s2, rng.s3);
+    // alpha = 1, pdfPrev = 0 and sp = 0 are implied by ST_FIRST_HIT (see SpAcc): 48 B (RGB) / 196 B (spectral) not written
+    newHdr.y = __float_as_uint(camWeight);
+    newHdr.z = __float_as_uint(wlOffset);
+    pb.rayOrg[slot] = make_float4(lensP.x, lensP.y, lensP.z, 0.0f);
+    pb.rayDir[slot] = make_float4(rayDir.x, rayDir.y, rayDir.z, INFINITY);
+}
+
+// sensor->add(p.x, p.y, wls, weight * C)  PathTracingRenderer.cpp:126-130: the finished path's radiance sum, times the camera
+// weight of its sample, Kahan-added to the slot's pixel accumulator (k_regen; the tail kernel for the last paths of a call).
+template <class S>
+__device__ __forceinline__ void accumulateSample(const PathBuffers& pb, const RenderParams& rp, uint32_t slot, uint32_t flags, const uint4& hdr) {
+    S C, accR, accC;
+    float unusedW;
+    const float camW = __uint_as_float(hdr.y);
+    if (F_SPVALID(flags)) SpecIO<S>::load(pb.spR, nullptr, slot, rp.numSlots, C, unusedW);     // else the path gathered nothing: C = 0
+    // accR / accC interleave (pb.accC = pb.accR + 1, element stride 2): the pair is one 32-byte sector per slot
+    SpecIO<S>::load(pb.accR, nullptr, 2 * slot, 2 * rp.numSlots, accR, unusedW);
+    SpecIO<S>::load(pb.accC, nullptr, 2 * slot, 2 * rp.numSlots, accC, unusedW);
+    const S weight = (S(1.0f) * S(1.0f)) * camW;
+    kahanAdd(accR, accC, storageAddend(weight * C, S::N == 3 ? 0.0f : __uint_as_float(hdr.z)));
+    SpecIO<S>::store(pb.accR, nullptr, 2 * slot, 2 * rp.numSlots, accR, 0.0f);
+    SpecIO<S>::store(pb.accC, nullptr, 2 * slot, 2 * rp.numSlots, accC, 0.0f);
+}
+
 template <class S>
 __global__ __launch_bounds__(kShadeBlock) void k_regen(DevScene sc, PathBuffers pb, RenderParams rp, uint32_t parity) {
-    if (pb.activeSlots[0] == 0) return;            // every slot is out of passes: the remaining launches of this block of iterations are no-ops
+    if (pb.activeSlots[0] == 0 || pb.tailMode[0]) return;      // every slot is out of passes / the tail kernel takes over: the remaining launches of this block of iterations are no-ops
     const uint32_t shard = blockIdx.x % kShards;
     const uint32_t n = pb.queueCount[queueCounterIndex(parity, Q_REGEN, shard)];
     const uint32_t i = (blockIdx.x / kShards) * kShadeBlock + threadIdx.x;
@@ -898,18 +974,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_regen(DevScene sc, PathBuffers 
         const uint4 hdr = pb.hdr[slot];
         uint32_t sampleIdx = hdr.x;
         if (F_HASPATH(flags)) {
-            // sensor->add(p.x, p.y, wls, weight * C)  PathTracingRenderer.cpp:126-130
-            S C, accR, accC;
-            float unusedW;
-            const float camW = __uint_as_float(hdr.y);
-            if (F_SPVALID(flags)) SpecIO<S>::load(pb.spR, nullptr, slot, rp.numSlots, C, unusedW);     // else the path gathered nothing: C = 0
-            // accR / accC interleave (pb.accC = pb.accR + 1, element stride 2): the pair is one 32-byte sector per slot
-            SpecIO<S>::load(pb.accR, nullptr, 2 * slot, 2 * rp.numSlots, accR, unusedW);
-            SpecIO<S>::load(pb.accC, nullptr, 2 * slot, 2 * rp.numSlots, accC, unusedW);
-            const S weight = (S(1.0f) * S(1.0f)) * camW;
-            kahanAdd(accR, accC, storageAddend(weight * C, S::N == 3 ? 0.0f : __uint_as_float(hdr.z)));
-            SpecIO<S>::store(pb.accR, nullptr, 2 * slot, 2 * rp.numSlots, accR, 0.0f);
-            SpecIO<S>::store(pb.accC, nullptr, 2 * slot, 2 * rp.numSlots, accC, 0.0f);
+            accumulateSample<S>(pb, rp, slot, flags, hdr);
             ++sampleIdx;
         }
         const uint32_t stripe = slot / rp.numPixels;
@@ -926,50 +991,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_regen(DevScene sc, PathBuffers 
             becameIdle = true;
         }
         else {
-            // Job::kernel PathTracingRenderer.cpp:100-120, draws in source (left-to-right) order
-            const uint32_t xy = pb.pixelXY[pix];
-            const uint32_t px = xy & 0xFFFFu, py = xy >> 16;
-            Rng rng;
-            rng.seed(sampleSeed(rp.rngSeed, px, py, pass));
-            float v = rng.nextFloat();
-            float time = rp.timeStart * (1 - v) + rp.timeEnd * v;
-            (void)time;
-            float pxx = px + rng.nextFloat();
-            float pyy = py + rng.nextFloat();
-            // createWithEqualOffsets: RGBTypes.h:37-45 (offset unused, PDF 1) / SpectrumTypes.h:54-64 (PDF N / 470)
-            const float wlOffset = rng.nextFloat();
-            float uLambda = rng.nextFloat();
-            const uint32_t wl = min((uint32_t)(uint16_t)(S::N * uLambda), (uint32_t)(S::N - 1));
-            const float selectWLPDF = S::N == 3 ? 1.0f : S::N / (830.0f - 360.0f);
-            float lu0 = rng.nextFloat();
-            float lu1 = rng.nextFloat();
-            // PerspectiveCamera::sample PerspectiveCamera.cpp:33-57
-            float lx, ly;
-            concentricSampleDisk(lu0, lu1, &lx, &ly);
-            V3 orgLocal(sc.camera.lensRadius * lx, sc.camera.lensRadius * ly, 0.0f);
-            V3 lensP = mulPoint(sc.camera.mat, orgLocal);
-            V3 lensN = mulNormal(sc.camera.matInv, V3(0, 0, 1));
-            Frame lf;
-            lf.z = lensN;
-            lf.x = mulVector(sc.camera.mat, V3(1, 0, 0));
-            lf.y = cross(lf.z, lf.x);
-            // PerspectiveIDF::sample :63-74 with IDFSample(p.x / W, p.y / H)
-            float sx = pxx / (float)rp.imageWidth;
-            float sy = pyy / (float)rp.imageHeight;
-            V3 pFocus(sc.camera.opWidth * (0.5f - sx), sc.camera.opHeight * (0.5f - sy), sc.camera.objPlaneDistance);
-            V3 dirLocal = normalize(pFocus - orgLocal);
-            float dirPDF = sc.camera.imgPlaneDistance * sc.camera.imgPlaneDistance /
-                           ((dirLocal.z * dirLocal.z * dirLocal.z) * sc.camera.imgPlaneArea);
-            V3 rayDir = lf.fromLocal(dirLocal);
-            // weight :126
-            float camWeight = absDot(rayDir, lensN) / (sc.camera.areaPDF * dirPDF * selectWLPDF);
-            pb.flags[slot] = F_MAKE((uint32_t)ST_FIRST_HIT, 0u, wl, 0u, 0u, 0u);
-            pb.rng[slot] = make_uint4(rng.s0, rng.s1, rng.s2, rng.s3);
-            // alpha = 1, pdfPrev = 0 and sp = 0 are implied by ST_FIRST_HIT (see SpAcc): 48 B (RGB) / 196 B (spectral) not written
-            newHdr.y = __float_as_uint(camWeight);
-            newHdr.z = __float_as_uint(wlOffset);
-            pb.rayOrg[slot] = make_float4(lensP.x, lensP.y, lensP.z, 0.0f);
-            pb.rayDir[slot] = make_float4(rayDir.x, rayDir.y, rayDir.z, INFINITY);
+            startSample<S>(sc, pb, rp, slot, pix, pass, newHdr);
         }
         pb.hdr[slot] = newHdr;
     }
@@ -1016,7 +1038,10 @@ __global__ void k_reset_slots(PathBuffers pb, RenderParams rp, uint32_t clearAcc
             }
             pb.queueCount[queueCounterIndex(0, Q_REGEN, r)] = cnt;
         }
-        if (threadIdx.x == 0) { pb.activeSlots[0] = rp.numSlots; pb.errorWord[0] = rp.injectError ? ERR_QUEUE_OVERFLOW : 0u; }
+        if (threadIdx.x == 0) {
+            pb.activeSlots[0] = rp.numSlots; pb.errorWord[0] = rp.injectError ? ERR_QUEUE_OVERFLOW : 0u;
+            pb.tailMode[0] = 0u; pb.tailWords[0] = 0u; pb.tailWords[1] = 0u;
+        }
     }
 }
 

@@ -405,9 +405,11 @@ __device__ __forceinline__ void wsConsume(const DevScene& sc, const PathBuffers&
 //   phase 2, shadow rays: Scene::testVisibility (SurfaceObject.cpp:418-430) = "no hit in [eps, d(1-eps)]"; workgroup b
 //            serves queue region b % kShards (gridDim is a multiple of kShards).
 template <bool COUNT, int NC, bool QUANT>
-__global__ __launch_bounds__(64 * (NC + 1)) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_trace_ws(DevScene sc, PathBuffers pb, uint32_t numSlots, uint32_t shardCapacity, uint32_t parity, uint32_t refill) {
+__global__ __launch_bounds__(64 * (NC + 1)) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_trace_ws(DevScene sc, PathBuffers pb, uint32_t numSlots, uint32_t shardCapacity, uint32_t parity, uint32_t refill,
+                                                                                                              uint32_t tailSlots) {
     __shared__ WsLds<NC> lds;
     if (pb.activeSlots[0] == 0) return;            // every slot is out of passes (uniform): nothing to trace
+    if (tailModeBegins(pb, tailSlots, parity)) return;      // the last paths go to the tail kernel (uniform over the grid, pt_kernels.h)
     if (blockIdx.x == 0 && threadIdx.x < Q_KINDS * kShards) {
         // clear the counter set the logic kernel of this iteration fills
         pb.queueCount[queueCounterIndex(parity ^ 1, threadIdx.x / kShards, threadIdx.x % kShards)] = 0;
@@ -528,8 +530,8 @@ __global__ __launch_bounds__(64 * (NC + 1)) __attribute__((amdgpu_waves_per_eu(8
 template <bool COUNT, int NC>
 static void launchTraceWsT(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, uint32_t blocks, hipStream_t stream) {
     const dim3 grid(blocks), block(64 * (NC + 1));
-    if (sc.nodesQ) hipLaunchKernelGGL((k_trace_ws<COUNT, NC, true>), grid, block, 0, stream, sc, pb, rp.numSlots, rp.shardCapacity, parity, g_refill);
-    else hipLaunchKernelGGL((k_trace_ws<COUNT, NC, false>), grid, block, 0, stream, sc, pb, rp.numSlots, rp.shardCapacity, parity, g_refill);
+    if (sc.nodesQ) hipLaunchKernelGGL((k_trace_ws<COUNT, NC, true>), grid, block, 0, stream, sc, pb, rp.numSlots, rp.shardCapacity, parity, g_refill, rp.tailSlots);
+    else hipLaunchKernelGGL((k_trace_ws<COUNT, NC, false>), grid, block, 0, stream, sc, pb, rp.numSlots, rp.shardCapacity, parity, g_refill, rp.tailSlots);
 }
 void launchTraceWs(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, uint32_t blocks, bool count,
                    hipStream_t stream) {

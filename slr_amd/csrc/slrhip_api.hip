@@ -26,6 +26,9 @@ using namespace slrhip;
 
 namespace {
 
+const uint32_t kStatusWords = 8;               // PathBuffers::activeSlots .. tailWords: one small array, read back in one copy
+const uint32_t kDefaultTailSlots = 1u << 18;   // SLRHIP_TAIL_SLOTS: measured on the headline frame and its N = 8 shard
+
 thread_local std::string g_lastError;
 
 int fail(int code, const std::string& msg) {
@@ -154,8 +157,8 @@ struct slrhip_ctx {
     // hipGraph of one block of iterations (slrhip_render): captured on the context's own stream, replayed until no slot is live
     hipStream_t workStream = nullptr;
     hipEvent_t userReady = nullptr;
-    uint64_t profLaunches[SLRHIP_KERNEL_COUNT] = {0, 0, 0, 0};
-    double profMs[SLRHIP_KERNEL_COUNT] = {0, 0, 0, 0};
+    uint64_t profLaunches[SLRHIP_KERNEL_COUNT] = {};
+    double profMs[SLRHIP_KERNEL_COUNT] = {};
     ~slrhip_ctx() {
         for (hipEvent_t e : events) (void)hipEventDestroy(e);
         if (userReady) (void)hipEventDestroy(userReady);
@@ -738,7 +741,7 @@ int slrhip_render_begin(slrhip_ctx* ctx, const slrhip_render_settings* st, slrhi
     const uint32_t shardCapacity = ((numBlocks + kShards - 1) / kShards) * 256;
     HIP_TRY(ctx->shadowQueue.alloc((size_t)shardCapacity * kShards, true)); HIP_TRY(ctx->regenQueue.alloc((size_t)shardCapacity * kShards, true));
     HIP_TRY(ctx->blockDead.alloc(numBlocks));
-    HIP_TRY(ctx->queueCount.alloc(2 * kQueueSetWords)); HIP_TRY(ctx->activeSlots.alloc(2));      // [0] live slots, [1] device error word
+    HIP_TRY(ctx->queueCount.alloc(2 * kQueueSetWords)); HIP_TRY(ctx->activeSlots.alloc(kStatusWords));      // [0] live slots, [1] device error word, [2] unused, [3] tail mode (1 + parity), [4..5] tail list length / cursor
     HIP_TRY(ctx->totals.alloc((size_t)T_KINDS * kShards * kTotalStride));
     // The statistics restart here.  A memset of device memory is only ordered on the null stream, and slrhip_render may be
     // given a NON-BLOCKING stream, which the null stream does not wait for and which does not wait for it: the memset has to
@@ -747,7 +750,7 @@ int slrhip_render_begin(slrhip_ctx* ctx, const slrhip_render_settings* st, slrhi
     // counts into queueCount — could run BEFORE that memset landed, the counts were wiped, no slot ever started a sample and
     // slrhip_render ran into its iteration bound.  queueCount is now written by k_reset_slots alone, in stream order.)
     HIP_TRY(hipMemsetAsync(ctx->totals.ptr, 0, ctx->totals.count * sizeof(uint64_t), nullptr));
-    HIP_TRY(hipMemsetAsync(ctx->activeSlots.ptr, 0, 2 * sizeof(uint32_t), nullptr));
+    HIP_TRY(hipMemsetAsync(ctx->activeSlots.ptr, 0, kStatusWords * sizeof(uint32_t), nullptr));
     HIP_TRY(hipStreamSynchronize(nullptr));
 
     PathBuffers& pb = ctx->buffers;
@@ -756,7 +759,7 @@ int slrhip_render_begin(slrhip_ctx* ctx, const slrhip_render_settings* st, slrhi
     pb.nee = ctx->nee.ptr;
     pb.pdfPrev = spectral ? ctx->pdfPrev.ptr : nullptr; pb.hdr = ctx->hdr.ptr; pb.finishedMask = ctx->finishedMask.ptr; pb.nextSample = ctx->nextSample.ptr; pb.shadowDir = ctx->shadowDir.ptr; pb.flags = ctx->flags.ptr;
     pb.visible = ctx->visible.ptr; pb.shadowQueue = ctx->shadowQueue.ptr; pb.regenQueue = ctx->regenQueue.ptr;
-    pb.queueCount = ctx->queueCount.ptr; pb.activeSlots = ctx->activeSlots.ptr; pb.errorWord = ctx->activeSlots.ptr + 1; pb.blockDead = ctx->blockDead.ptr; pb.totals = ctx->totals.ptr;
+    pb.queueCount = ctx->queueCount.ptr; pb.activeSlots = ctx->activeSlots.ptr; pb.errorWord = ctx->activeSlots.ptr + 1; pb.tailMode = ctx->activeSlots.ptr + 3; pb.tailWords = ctx->activeSlots.ptr + 4; pb.blockDead = ctx->blockDead.ptr; pb.totals = ctx->totals.ptr;
     pb.pixelXY = ctx->pixelXY.ptr;
 
     RenderParams& rp = ctx->params;
@@ -801,7 +804,39 @@ int slrhip_render(slrhip_ctx* ctx, uint32_t sppBegin, uint32_t sppCount, void* s
 
     uint32_t parity = 0;
     uint32_t active = rp.numSlots;
-    uint32_t status[2] = {rp.numSlots, 0u};       // device words: live slots, error bits (PathBuffers::activeSlots / errorWord)
+    uint32_t status[4] = {rp.numSlots, 0u, 0u, 0u};       // device words: live slots, error bits, -, tail mode (PathBuffers)
+    // The end of the call (pt_tail_kernels.h): once at most tailSlots slots are alive, the traversal kernel raises the tail-mode
+    // word instead of tracing, the rest of the block of iterations is no-ops, and the tail kernel finishes every remaining
+    // path and pass in one launch.  Not for more than an eighth of the slots (the wavefront kernels are the efficient way to
+    // advance many paths), not in the counting build (its per-ray figures come from the wavefront kernels) and not for the
+    // four-lanes-per-slot spectral variant.  SLRHIP_TAIL_SLOTS overrides the absolute bound, 0 disables.
+    static const long envTail = [] { const char* e = getenv("SLRHIP_TAIL_SLOTS"); return e ? atol(e) : -1L; }();
+    static const bool envQuadLanes = [] { const char* e = getenv("SLRHIP_SPECTRAL_LANES"); return e && std::string(e) == "4"; }();
+    {
+        const uint32_t bound = envTail >= 0 ? (uint32_t)std::min<long>(envTail, 0x7FFFFFFFL) : kDefaultTailSlots;
+        const bool off = (ctx->config.flags & (SLRHIP_FLAG_NO_TAIL | SLRHIP_FLAG_COUNT_TRAVERSAL)) != 0 || (rp.spectral && (rp.spectralQuad || envQuadLanes));
+        rp.tailSlots = off ? 0u : std::min(bound, std::max(rp.numSlots / 8u, 1u));
+    }
+    // tail mode seen in the status words: list the live slots, finish them, read the words again (live slots must be 0 then)
+    const auto runTail = [&](hipStream_t s, bool timed) -> int {
+        hipEvent_t t0 = nullptr, t1 = nullptr;
+        if (timed) { HIP_TRY(hipEventCreate(&t0)); HIP_TRY(hipEventCreate(&t1)); HIP_TRY(hipEventRecord(t0, s)); }
+        launchTail(ctx->scene, ctx->buffers, rp, status[0], status[3] - 1u, ctx->numCUs, s);
+        if (timed) HIP_TRY(hipEventRecord(t1, s));
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(status, ctx->activeSlots.ptr, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (timed) {
+            float ms = 0.0f;
+            HIP_TRY(hipEventElapsedTime(&ms, t0, t1));
+            ctx->profMs[SLRHIP_KERNEL_TAIL] += ms;
+            ++ctx->profLaunches[SLRHIP_KERNEL_TAIL];
+            (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
+        }
+        if (status[1]) return deviceError(status[1]);
+        if (status[0] != 0) return fail(SLRHIP_ERR_HIP, "slrhip_render: the tail kernel left live slots (internal error)");
+        return SLRHIP_OK;
+    };
     // Each check costs one small copy + stream sync; 16 iterations between checks keeps it < 1 %.
     const int kCheckEvery = 16;
     const int kEv = 5;    // events per iteration: before regen, after regen, after closest, after shadow, after logic
@@ -849,12 +884,13 @@ int slrhip_render(slrhip_ctx* ctx, uint32_t sppBegin, uint32_t sppCount, void* s
         int rc = SLRHIP_OK;
         while (active > 0 && rc == SLRHIP_OK) {
             hipError_t e = hipGraphLaunch(exec, ws);
-            if (e == hipSuccess) e = hipMemcpyAsync(status, ctx->activeSlots.ptr, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, ws);
+            if (e == hipSuccess) e = hipMemcpyAsync(status, ctx->activeSlots.ptr, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, ws);
             if (e == hipSuccess) e = hipStreamSynchronize(ws);
             if (e != hipSuccess) rc = fail(SLRHIP_ERR_HIP, std::string("slrhip_render: ") + hipGetErrorString(e));
-            active = status[0];
             it += kCheckEvery;
             if (rc == SLRHIP_OK && status[1]) rc = deviceError(status[1]);
+            if (rc == SLRHIP_OK && status[3] && status[0]) rc = runTail(ws, false);
+            active = status[0];
             if (rc == SLRHIP_OK && it > maxIterations) rc = fail(SLRHIP_ERR_HIP, "slrhip_render: iteration bound exceeded (internal error)");
         }
         (void)hipGraphExecDestroy(exec);
@@ -895,7 +931,7 @@ int slrhip_render(slrhip_ctx* ctx, uint32_t sppBegin, uint32_t sppCount, void* s
             ++it;
         }
         HIP_TRY(hipGetLastError());                  // a failed launch surfaces here, not at the end of the render
-        HIP_TRY(hipMemcpyAsync(status, ctx->activeSlots.ptr, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(status, ctx->activeSlots.ptr, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         active = status[0];
         if (status[1]) return deviceError(status[1]);
@@ -913,6 +949,11 @@ int slrhip_render(slrhip_ctx* ctx, uint32_t sppBegin, uint32_t sppCount, void* s
                 }
                 if (iterLog) iterActive.push_back(active);
             }
+        }
+        if (status[3] && status[0]) {
+            const int rc = runTail(stream, timeKernels);
+            if (rc != SLRHIP_OK) return rc;
+            active = status[0];
         }
         if (it > maxIterations) return fail(SLRHIP_ERR_HIP, "slrhip_render: iteration bound exceeded (internal error)");
     }

@@ -35,7 +35,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 def test_version(lib):
     text = open(os.path.join(ROOT, "include", "slrhip.h")).read()
-    assert lib.slrhip_version() == int(re.search(r"#define SLRHIP_VERSION (\d+)", text).group(1)) == 5
+    assert lib.slrhip_version() == int(re.search(r"#define SLRHIP_VERSION (\d+)", text).group(1)) == 6
 
 
 def test_create_fails_loudly_without_gpu(lib):

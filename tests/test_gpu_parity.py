@@ -889,3 +889,39 @@ def test_sample_pool_is_reproducible_and_complete(oracle_rgb):
     assert c.counters().samples == 48 * 40 * 96      # sample totals run from slrhip_render_begin
     c.close()
     assert np.allclose(two, want, rtol=5e-6, atol=1e-9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [abi.MODE_RGB, abi.MODE_SPECTRAL])
+def test_tail_kernel_gives_the_frame_of_the_wavefront_iterations(mode):
+    """Once few slots are live the rest of a render call is ONE launch (k_tail: each remaining slot taken to its end by one lane,
+    through the same logicSlot / accumulateSample / startSample code as k_logic / k_regen and the one-lane-per-ray traversal).
+    Against the pure wavefront schedule (SLRHIP_FLAG_NO_TAIL): the same samples (sample and ray counts equal), with one stripe
+    the same frame bit for bit; with more stripes only the grouping of a pixel's float sum over its stripes may differ.  Also
+    for a render continued in a second call, more stripes than passes, and the batch traversal kernels; and reproducible."""
+    sc = scenes.cornell_box_spheres(1.0, 16, 8, "glass")
+    st = ob.settings(64, 48, seed=21)
+
+    def run(flags, stripes, calls):
+        c = Context(mode=mode, stripes=stripes, flags=flags | abi.FLAG_TIME_KERNELS)
+        c.upload_scene(sc)
+        c.render_begin(st)
+        for begin, count in calls:
+            c.render(begin, count)
+        fb = c.read_framebuffer()
+        ctr, prof = c.counters(), c.profile()
+        c.close()
+        return fb, (int(ctr.samples), int(ctr.extension_rays), int(ctr.shadow_rays)), int(prof.launches[4])
+
+    for stripes, calls, extra in ((1, ((0, 24),), 0), (8, ((0, 40),), 0), (8, ((0, 24), (24, 16)), 0), (64, ((0, 16),), 0), (8, ((0, 40),), abi.FLAG_TRACE_BATCH)):
+        want, counts_w, tails_w = run(abi.FLAG_NO_TAIL | extra, stripes, calls)
+        got, counts_g, tails_g = run(extra, stripes, calls)
+        again, counts_a, _ = run(extra, stripes, calls)
+        assert tails_w == 0 and tails_g == len(calls), (tails_w, tails_g)      # the tail ran once per render call, and only when allowed
+        assert counts_g == counts_w == counts_a, (counts_g, counts_w)
+        assert counts_g[0] == 64 * 48 * sum(n for _, n in calls)
+        assert_bit_equal(got, again, "two runs with the tail kernel (stripes %d)" % stripes)
+        if stripes == 1:
+            assert_bit_equal(got, want, "tail kernel vs wavefront iterations, one stripe")
+        else:
+            assert np.allclose(got, want, rtol=5e-6, atol=1e-9), (stripes, calls)

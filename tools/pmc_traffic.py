@@ -13,7 +13,7 @@ import json
 import os
 import sys
 
-CLASSES = {"k_trace_closest": "trace_closest", "k_trace_shadow": "trace_shadow", "k_trace_ws": "trace", "k_logic": "shade", "k_regen": "regen"}
+CLASSES = {"k_trace_closest": "trace_closest", "k_trace_shadow": "trace_shadow", "k_trace_ws": "trace", "k_logic": "shade", "k_regen": "regen", "k_tail<": "tail"}
 
 
 def collect(d, counter):
