@@ -123,8 +123,13 @@ def main():
     args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # Rehearsal of the N-rank flow on a box with ONE GPU (SLRHIP_BENCH_SHARE_GPU=1): every rank renders its shard on device 0 and
+    # the frames meet over gloo.  It checks the launch, sharding, reduce, barrier and reporting code; its timings mean nothing.
+    rehearsal = os.environ.get("SLRHIP_BENCH_SHARE_GPU") == "1" and world > 1
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
-    distributed.init("nccl")
+    distributed.init("gloo" if rehearsal else "nccl")
 
     W, H = args.width, args.height
     mode, ref_name = abi.MODE_RGB, "ref_rgb"
@@ -194,6 +199,8 @@ def main():
                    "sharding": "8x8 tiles round-robin over %d rank(s), one RCCL reduce of the framebuffer per step" % world,
                    "stripes": int(args.stripes)},
     }
+    if rehearsal:
+        out["config"]["rehearsal"] = "all %d ranks share GPU 0, frames reduced over gloo: timings are not a measurement" % world
 
     if rank == 0:
         # ---- per-kernel timing over the timed region (HIP events on the render stream) ------------

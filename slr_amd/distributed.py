@@ -36,7 +36,13 @@ def shard_for(rank, world):
 def reduce_framebuffer(fb, world, dst=0):
     """Sum the per-rank framebuffers (disjoint tile supports) onto rank `dst`; in place."""
     if world > 1:
-        dist.reduce(fb, dst=dst, op=dist.ReduceOp.SUM)
+        if fb.is_cuda and dist.get_backend() == "gloo":
+            # gloo has no device-side reduce: host round trip (the CPU tests and bench.py's one-GPU rehearsal; RCCL never gets here)
+            host = fb.cpu()
+            dist.reduce(host, dst=dst, op=dist.ReduceOp.SUM)
+            fb.copy_(host)
+        else:
+            dist.reduce(fb, dst=dst, op=dist.ReduceOp.SUM)
     return fb
 
 
