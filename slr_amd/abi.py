@@ -91,7 +91,7 @@ class Profile(C.Structure):
                 ("nodes", C.c_uint64 * 2), ("triangles", C.c_uint64 * 2), ("slot_visits", C.c_uint64)]
 
 
-FLAG_TIME_KERNELS, FLAG_COUNT_TRAVERSAL, FLAG_TRACE_BATCH, FLAG_SPECTRAL_QUAD, FLAG_TEST_DEVICE_ERROR, FLAG_QUAD_LAYOUT, FLAG_BVH_SPATIAL_SPLITS, FLAG_NO_TAIL = 1, 2, 4, 8, 16, 32, 64, 128
+FLAG_TIME_KERNELS, FLAG_COUNT_TRAVERSAL, FLAG_TRACE_BATCH, FLAG_SPECTRAL_QUAD, FLAG_TEST_DEVICE_ERROR, FLAG_QUAD_LAYOUT, FLAG_BVH_SPATIAL_SPLITS, FLAG_TAIL_KERNEL, FLAG_TRACE_POOL = 1, 2, 4, 8, 16, 32, 64, 128, 256
 MAX_STRIPES = 64
 KERNEL_NAMES = ("trace_closest", "trace_shadow", "shade", "regen", "tail")
 

@@ -175,5 +175,10 @@ void launchTraceQuad(const DevScene& sc, const float4* nodes4, const float4* pac
 void launchTraceWs(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, uint32_t blocks, bool count,
                    hipStream_t stream);
 int traceWsBlocksPerCU();
+// pool schedule of the same file (experiment, SLRHIP_TRACE=pool): rays resident in LDS, dense node / triangle phases
+void launchTracePool(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, uint32_t blocks, bool count, uint32_t* spill,
+                     hipStream_t stream);
+int tracePoolBlocksPerCU();
+size_t tracePoolSpillWords(uint32_t blocks);
 
 } // namespace slrhip

@@ -16,8 +16,10 @@
 // Passes in the tail: a slot goes idle only when its pixel has run out of passes, so a pixel that still has some has all its K
 // stripes alive; stripe s takes the passes next + s, next + s + K, ... of its pixel (next = the pixel's counter when the tail
 // took over).  Which stripe renders which pass therefore still depends on path lengths only: frames stay reproducible, every
-// pass is rendered once, and the image differs from the pure wavefront schedule (SLRHIP_FLAG_NO_TAIL) only in the grouping
-// of a pixel's float sum over its stripes — not at all with one stripe.
+// pass is rendered once, and the image differs from the pure wavefront schedule only in the grouping of a pixel's float sum
+// over its stripes — not at all with one stripe.  But when the tail takes over depends on the number of live slots, hence on
+// the shard size: with it the sum of the shards of a frame no longer equals the unsharded frame to the last bit at a fixed
+// stripe count (tests/test_gpu_parity.py::test_eight_tile_shards_...), which is why it is opt-in (SLRHIP_FLAG_TAIL_KERNEL).
 #pragma once
 #include "pt_shade_kernels.h"
 #include "pt_traverse.h"

@@ -146,6 +146,7 @@ struct slrhip_ctx {
     DevArray<unsigned long long> finishedMask;
     DevArray<uint32_t> nextSample;
     DevArray<uint32_t> flags, visible, shadowQueue, regenQueue, queueCount, activeSlots, blockDead;
+    DevArray<uint32_t> poolSpill;       // SLRHIP_TRACE=pool: stack entries beyond the LDS rows
     DevArray<uint64_t> totals;
     DevArray<float> resolveScratch;
     PathBuffers buffers;
@@ -799,22 +800,29 @@ int slrhip_render(slrhip_ctx* ctx, uint32_t sppBegin, uint32_t sppCount, void* s
     // Traversal schedule: wave-specialised (pt_trace_ws.hip) unless SLRHIP_TRACE=batch asks for the 64-ray-batch kernels
     // of pt_trace.hip, and so does SLRHIP_FLAG_TRACE_BATCH per context (kept for A/B checks; results are identical)
     static const bool envBatch = [] { const char* e = getenv("SLRHIP_TRACE"); return e && std::string(e) == "batch"; }();
+    static const bool envPool = [] { const char* e = getenv("SLRHIP_TRACE"); return e && std::string(e) == "pool"; }();
     const bool useWs = !envBatch && !(ctx->config.flags & SLRHIP_FLAG_TRACE_BATCH);
-    const uint32_t traceBlocks = (uint32_t)ctx->numCUs * (uint32_t)(useWs ? traceWsBlocksPerCU() : traceBlocksPerCU());
+    const bool usePool = useWs && (envPool || (ctx->config.flags & SLRHIP_FLAG_TRACE_POOL) != 0);
+    const uint32_t traceBlocks = (uint32_t)ctx->numCUs * (uint32_t)(usePool ? tracePoolBlocksPerCU() : useWs ? traceWsBlocksPerCU() : traceBlocksPerCU());
+    if (usePool) {
+        const size_t words = tracePoolSpillWords((traceBlocks + kShards - 1) / kShards * kShards);
+        if (ctx->poolSpill.count < words) HIP_TRY(ctx->poolSpill.alloc(words));
+    }
 
     uint32_t parity = 0;
     uint32_t active = rp.numSlots;
     uint32_t status[4] = {rp.numSlots, 0u, 0u, 0u};       // device words: live slots, error bits, -, tail mode (PathBuffers)
-    // The end of the call (pt_tail_kernels.h): once at most tailSlots slots are alive, the traversal kernel raises the tail-mode
-    // word instead of tracing, the rest of the block of iterations is no-ops, and the tail kernel finishes every remaining
-    // path and pass in one launch.  Not for more than an eighth of the slots (the wavefront kernels are the efficient way to
-    // advance many paths), not in the counting build (its per-ray figures come from the wavefront kernels) and not for the
-    // four-lanes-per-slot spectral variant.  SLRHIP_TAIL_SLOTS overrides the absolute bound, 0 disables.
+    // The end of the call (pt_tail_kernels.h), on request (SLRHIP_FLAG_TAIL_KERNEL or SLRHIP_TAIL_SLOTS=n): once at most tailSlots
+    // slots are alive the traversal kernel raises the tail-mode word instead of tracing, the rest of the block of iterations is
+    // no-ops, and the tail kernel finishes every remaining path and pass in one launch.  Never for more than an eighth of the
+    // slots (the wavefront kernels are the efficient way to advance many paths), not in the counting build (its per-ray
+    // figures come from the wavefront kernels) and not for the four-lanes-per-slot spectral variant.
     static const long envTail = [] { const char* e = getenv("SLRHIP_TAIL_SLOTS"); return e ? atol(e) : -1L; }();
     static const bool envQuadLanes = [] { const char* e = getenv("SLRHIP_SPECTRAL_LANES"); return e && std::string(e) == "4"; }();
     {
-        const uint32_t bound = envTail >= 0 ? (uint32_t)std::min<long>(envTail, 0x7FFFFFFFL) : kDefaultTailSlots;
-        const bool off = (ctx->config.flags & (SLRHIP_FLAG_NO_TAIL | SLRHIP_FLAG_COUNT_TRAVERSAL)) != 0 || (rp.spectral && (rp.spectralQuad || envQuadLanes));
+        const bool asked = (ctx->config.flags & SLRHIP_FLAG_TAIL_KERNEL) != 0 || envTail > 0;
+        const uint32_t bound = envTail > 0 ? (uint32_t)std::min<long>(envTail, 0x7FFFFFFFL) : kDefaultTailSlots;
+        const bool off = !asked || envTail == 0 || (ctx->config.flags & SLRHIP_FLAG_COUNT_TRAVERSAL) != 0 || (rp.spectral && (rp.spectralQuad || envQuadLanes));
         rp.tailSlots = off ? 0u : std::min(bound, std::max(rp.numSlots / 8u, 1u));
     }
     // tail mode seen in the status words: list the live slots, finish them, read the words again (live slots must be 0 then)
@@ -842,6 +850,10 @@ int slrhip_render(slrhip_ctx* ctx, uint32_t sppBegin, uint32_t sppCount, void* s
     const int kEv = 5;    // events per iteration: before regen, after regen, after closest, after shadow, after logic
     const bool timeKernels = (ctx->config.flags & SLRHIP_FLAG_TIME_KERNELS) != 0;
     const bool count = (ctx->config.flags & SLRHIP_FLAG_COUNT_TRAVERSAL) != 0;
+    const auto launchTrace = [&](uint32_t par, hipStream_t s) {
+        if (usePool) launchTracePool(ctx->scene, ctx->buffers, rp, par, traceBlocks, count, ctx->poolSpill.ptr, s);
+        else launchTraceWs(ctx->scene, ctx->buffers, rp, par, traceBlocks, count, s);
+    };
     if (timeKernels && ctx->events.empty()) {
         ctx->events.resize((size_t)kCheckEvery * kEv);
         for (hipEvent_t& e : ctx->events) HIP_TRY(hipEventCreate(&e));
@@ -868,7 +880,7 @@ int slrhip_render(slrhip_ctx* ctx, uint32_t sppBegin, uint32_t sppCount, void* s
         HIP_TRY(hipStreamBeginCapture(ws, hipStreamCaptureModeThreadLocal));
         for (int k = 0; k < kCheckEvery; ++k) {
             launchRegen(ctx->scene, ctx->buffers, rp, (uint32_t)(k & 1), ws);
-            if (useWs) launchTraceWs(ctx->scene, ctx->buffers, rp, (uint32_t)(k & 1), traceBlocks, count, ws);
+            if (useWs) launchTrace((uint32_t)(k & 1), ws);
             else {
                 launchTraceClosest(ctx->scene, ctx->buffers, rp, (uint32_t)(k & 1), traceBlocks, count, ws);
                 launchTraceShadow(ctx->scene, ctx->buffers, rp, (uint32_t)(k & 1), traceBlocks, count, ws);
@@ -916,7 +928,7 @@ int slrhip_render(slrhip_ctx* ctx, uint32_t sppBegin, uint32_t sppCount, void* s
             if (ev) HIP_TRY(hipEventRecord(ev[1], stream));
             if (useWs) {
                 // both ray kinds in one launch: its time is booked under TRACE_CLOSEST, TRACE_SHADOW counts no launches
-                launchTraceWs(ctx->scene, ctx->buffers, rp, parity, traceBlocks, count, stream);
+                launchTrace(parity, stream);
                 if (ev) { HIP_TRY(hipEventRecord(ev[2], stream)); HIP_TRY(hipEventRecord(ev[3], stream)); }
             }
             else {

@@ -896,7 +896,7 @@ def test_sample_pool_is_reproducible_and_complete(oracle_rgb):
 def test_tail_kernel_gives_the_frame_of_the_wavefront_iterations(mode):
     """Once few slots are live the rest of a render call is ONE launch (k_tail: each remaining slot taken to its end by one lane,
     through the same logicSlot / accumulateSample / startSample code as k_logic / k_regen and the one-lane-per-ray traversal).
-    Against the pure wavefront schedule (SLRHIP_FLAG_NO_TAIL): the same samples (sample and ray counts equal), with one stripe
+    On request (SLRHIP_FLAG_TAIL_KERNEL).  Against the pure wavefront schedule: the same samples (sample and ray counts equal), with one stripe
     the same frame bit for bit; with more stripes only the grouping of a pixel's float sum over its stripes may differ.  Also
     for a render continued in a second call, more stripes than passes, and the batch traversal kernels; and reproducible."""
     sc = scenes.cornell_box_spheres(1.0, 16, 8, "glass")
@@ -914,9 +914,9 @@ def test_tail_kernel_gives_the_frame_of_the_wavefront_iterations(mode):
         return fb, (int(ctr.samples), int(ctr.extension_rays), int(ctr.shadow_rays)), int(prof.launches[4])
 
     for stripes, calls, extra in ((1, ((0, 24),), 0), (8, ((0, 40),), 0), (8, ((0, 24), (24, 16)), 0), (64, ((0, 16),), 0), (8, ((0, 40),), abi.FLAG_TRACE_BATCH)):
-        want, counts_w, tails_w = run(abi.FLAG_NO_TAIL | extra, stripes, calls)
-        got, counts_g, tails_g = run(extra, stripes, calls)
-        again, counts_a, _ = run(extra, stripes, calls)
+        want, counts_w, tails_w = run(extra, stripes, calls)
+        got, counts_g, tails_g = run(abi.FLAG_TAIL_KERNEL | extra, stripes, calls)
+        again, counts_a, _ = run(abi.FLAG_TAIL_KERNEL | extra, stripes, calls)
         assert tails_w == 0 and tails_g == len(calls), (tails_w, tails_g)      # the tail ran once per render call, and only when allowed
         assert counts_g == counts_w == counts_a, (counts_g, counts_w)
         assert counts_g[0] == 64 * 48 * sum(n for _, n in calls)
@@ -925,3 +925,27 @@ def test_tail_kernel_gives_the_frame_of_the_wavefront_iterations(mode):
             assert_bit_equal(got, want, "tail kernel vs wavefront iterations, one stripe")
         else:
             assert np.allclose(got, want, rtol=5e-6, atol=1e-9), (stripes, calls)
+
+
+@pytest.mark.gpu
+def test_ldsresident_pool_traversal_gives_the_same_frames():
+    """SLRHIP_FLAG_TRACE_POOL: the experimental traversal schedule that keeps a consumer wave's rays in LDS and runs dense node and
+    triangle phases (hits merged by a 64-bit LDS atomic min on (t, ~index): the same closest hit and the same tie rule).  Same
+    hits => the same frame bit for bit, the same ray counts, the same node / triangle counts per ray — on a float-node tree with
+    an alpha-tested, textured scene and on a quantized-node tree (>= 64 Ki nodes)."""
+    cases = [(scenes.cornell_textured(1.0, 10, 5), ob.settings(96, 72, seed=5), 8, abi.MODE_RGB),
+             (scenes.cornell_box_spheres(1.0, 16, 8, "glass"), ob.settings(64, 48, seed=6), 8, abi.MODE_SPECTRAL),
+             (scenes.displaced_grid(400, 4.0 / 3.0), ob.settings(96, 72, seed=7), 4, abi.MODE_RGB)]
+    for sc, st, spp, mode in cases:
+        out = []
+        for flags in (0, abi.FLAG_TRACE_POOL):
+            c = Context(mode=mode, flags=flags | abi.FLAG_COUNT_TRAVERSAL)
+            fb = c.render_image(sc, st, spp)
+            ctr, prof = c.counters(), c.profile()
+            out.append((fb, (int(ctr.extension_rays), int(ctr.shadow_rays)), (int(prof.nodes[0]), int(prof.nodes[1])), (int(prof.triangles[0]), int(prof.triangles[1]))))
+            c.close()
+        assert out[0][1] == out[1][1] and out[0][2] == out[1][2], (out[0][1:], out[1][1:])
+        # a shadow ray stops at its first accepted triangle in the default schedule; the pool tests a whole leaf at once
+        assert out[0][3][0] == out[1][3][0] and out[1][3][1] >= out[0][3][1]
+        assert_bit_equal(out[1][0], out[0][0], "LDS-resident pool traversal vs the default schedule")
+        assert out[0][0].sum() > 0

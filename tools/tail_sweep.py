@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Where to hand the last paths of a frame to the tail kernel: the headline frame (world 1) and the shard a rank owns at world
-size 8, timed for several SLRHIP_TAIL_SLOTS bounds (0 = pure wavefront).  One process per bound (the bound is read once).
+size 8, timed for several SLRHIP_TAIL_SLOTS bounds (0 = pure wavefront, the default).  One process per bound (the bound is read once).
 
     python tools/tail_sweep.py            # driver: runs itself once per bound
     python tools/tail_sweep.py BOUND      # worker"""
