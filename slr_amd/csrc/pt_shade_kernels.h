@@ -315,8 +315,8 @@ template <> struct SpAcc<RGB> {
     RGB r, c, nee;
     __device__ __forceinline__ void begin(const PathBuffers& pb, uint32_t slot, uint32_t n) {
         float unused;
-        SpecIO<RGB>::load(pb.spR, nullptr, slot, n, r, unused);
-        SpecIO<RGB>::load(pb.spC, nullptr, slot, n, c, unused);
+        SpecIO<RGB>::load(pb.spR, nullptr, slot * pb.spStride, n * pb.spStride, r, unused);
+        SpecIO<RGB>::load(pb.spC, nullptr, slot * pb.spStride, n * pb.spStride, c, unused);
         SpecIO<RGB>::load(pb.nee, nullptr, slot, n, nee, unused);
     }
     __device__ __forceinline__ void startPath(bool first, uint32_t) { if (first) { r = RGB(); c = RGB(); } }
@@ -324,8 +324,8 @@ template <> struct SpAcc<RGB> {
     __device__ __forceinline__ void addPendingNee(const PathBuffers&, uint32_t, uint32_t) { kahanAdd(r, c, nee); }
     __device__ __forceinline__ void add(const PathBuffers&, uint32_t, uint32_t, const RGB& v) { kahanAdd(r, c, v); }
     __device__ __forceinline__ void end(const PathBuffers& pb, uint32_t slot, uint32_t n, bool pathContinues) {
-        SpecIO<RGB>::store(pb.spR, nullptr, slot, n, r, 0.0f);
-        if (pathContinues) SpecIO<RGB>::store(pb.spC, nullptr, slot, n, c, 0.0f);       // a finished path only hands over the sum
+        SpecIO<RGB>::store(pb.spR, nullptr, slot * pb.spStride, n * pb.spStride, r, 0.0f);
+        if (pathContinues) SpecIO<RGB>::store(pb.spC, nullptr, slot * pb.spStride, n * pb.spStride, c, 0.0f);       // a finished path only hands over the sum
     }
 };
 template <> struct SpAcc<Spec16> {
@@ -339,11 +339,11 @@ template <> struct SpAcc<Spec16> {
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             float4 r = zero, c = zero;
-            if (valid) { r = pb.spR[(size_t)p * n + slot]; c = pb.spC[(size_t)p * n + slot]; }
+            if (valid) { r = pb.spR[((size_t)p * n + slot) * pb.spStride]; c = pb.spC[((size_t)p * n + slot) * pb.spStride]; }
             kahanAdd(r.x, c.x, v.c[4 * p]); kahanAdd(r.y, c.y, v.c[4 * p + 1]);
             kahanAdd(r.z, c.z, v.c[4 * p + 2]); kahanAdd(r.w, c.w, v.c[4 * p + 3]);
-            pb.spR[(size_t)p * n + slot] = r;
-            pb.spC[(size_t)p * n + slot] = c;
+            pb.spR[((size_t)p * n + slot) * pb.spStride] = r;
+            pb.spC[((size_t)p * n + slot) * pb.spStride] = c;
         }
         valid = true;
     }
@@ -353,10 +353,10 @@ template <> struct SpAcc<Spec16> {
         for (int p = 0; p < 4; ++p) {
             const float4 v = pb.nee[(size_t)p * n + slot];
             float4 r = zero, c = zero;
-            if (valid) { r = pb.spR[(size_t)p * n + slot]; c = pb.spC[(size_t)p * n + slot]; }
+            if (valid) { r = pb.spR[((size_t)p * n + slot) * pb.spStride]; c = pb.spC[((size_t)p * n + slot) * pb.spStride]; }
             kahanAdd(r.x, c.x, v.x); kahanAdd(r.y, c.y, v.y); kahanAdd(r.z, c.z, v.z); kahanAdd(r.w, c.w, v.w);
-            pb.spR[(size_t)p * n + slot] = r;
-            pb.spC[(size_t)p * n + slot] = c;
+            pb.spR[((size_t)p * n + slot) * pb.spStride] = r;
+            pb.spC[((size_t)p * n + slot) * pb.spStride] = c;
         }
         valid = true;
     }
@@ -369,7 +369,7 @@ template <> struct SpAcc<SpecQ> {
     __device__ __forceinline__ void startPath(bool first, uint32_t flags) { valid = !first && F_SPVALID(flags); }
     __device__ __forceinline__ uint32_t validBits() const { return valid ? 1u << 10 : 0u; }
     __device__ __forceinline__ void add(const PathBuffers& pb, uint32_t slot, uint32_t n, const SpecQ& v) {
-        const size_t i = (size_t)SpecQ::q() * n + slot;
+        const size_t i = ((size_t)SpecQ::q() * n + slot) * pb.spStride;
         float4 r = make_float4(0.0f, 0.0f, 0.0f, 0.0f), c = r;
         if (valid) { r = pb.spR[i]; c = pb.spC[i]; }
         kahanAdd(r.x, c.x, v.c[0]); kahanAdd(r.y, c.y, v.c[1]); kahanAdd(r.z, c.z, v.c[2]); kahanAdd(r.w, c.w, v.c[3]);
@@ -378,8 +378,8 @@ template <> struct SpAcc<SpecQ> {
         valid = true;
     }
     __device__ __forceinline__ void addPendingNee(const PathBuffers& pb, uint32_t slot, uint32_t n) {
-        const size_t i = (size_t)SpecQ::q() * n + slot;
-        const float4 v = pb.nee[i];
+        const size_t i0 = (size_t)SpecQ::q() * n + slot, i = i0 * pb.spStride;
+        const float4 v = pb.nee[i0];
         float4 r = make_float4(0.0f, 0.0f, 0.0f, 0.0f), c = r;
         if (valid) { r = pb.spR[i]; c = pb.spC[i]; }
         kahanAdd(r.x, c.x, v.x); kahanAdd(r.y, c.y, v.y); kahanAdd(r.z, c.z, v.z); kahanAdd(r.w, c.w, v.w);
@@ -459,7 +459,7 @@ __device__ __forceinline__ void logicSlot(const DevScene& sc, const PathBuffers&
     SpecIO<S>::load(pb.alpha, pb.pdfPrev, slot, rp.numSlots, alpha, bsdfPDFprev);
     sp.begin(pb, slot, rp.numSlots);
     const float4 h = pb.hit[slot];
-    const float4 o4 = pb.rayOrg[slot], d4 = pb.rayDir[slot];
+    const float4 o4 = pb.rayOrg[(size_t)slot * pb.rayStride], d4 = pb.rayDir[(size_t)slot * pb.rayStride];
     const uint32_t vis = pb.visible[slot];
     const float wlOffset = S::N == 3 ? 0.0f : __uint_as_float(pb.hdr[slot].z);
 
@@ -742,7 +742,7 @@ __device__ __forceinline__ void logicSlot(const DevScene& sc, const PathBuffers&
                     emitExt = true;
                 }
                 // the shadow ray starts at the shading point, which is also the next ray's origin
-                if (emitShadow && !emitExt && leader) pb.rayOrg[slot] = make_float4(surf.p.x, surf.p.y, surf.p.z, kRayEpsilon);
+                if (emitShadow && !emitExt && leader) pb.rayOrg[(size_t)slot * pb.rayStride] = make_float4(surf.p.x, surf.p.y, surf.p.z, kRayEpsilon);
             }
         }
 
@@ -768,8 +768,8 @@ __device__ __forceinline__ void logicSlot(const DevScene& sc, const PathBuffers&
             SpecIO<S>::store(pb.alpha, pb.pdfPrev, slot, rp.numSlots, alpha, bsdfPDFprev);
         }
         if (emitExt && leader) {
-            pb.rayOrg[slot] = make_float4(rayOrg.x, rayOrg.y, rayOrg.z, rayTmin);
-            pb.rayDir[slot] = make_float4(rayDir.x, rayDir.y, rayDir.z, INFINITY);
+            pb.rayOrg[(size_t)slot * pb.rayStride] = make_float4(rayOrg.x, rayOrg.y, rayOrg.z, rayTmin);
+            pb.rayDir[(size_t)slot * pb.rayStride] = make_float4(rayDir.x, rayDir.y, rayDir.z, INFINITY);
         }
     }
 }
@@ -938,8 +938,8 @@ __device__ __forceinline__ void startSample(const DevScene& sc, const PathBuffer
     // alpha = 1, pdfPrev = 0 and sp = 0 are implied by ST_FIRST_HIT (see SpAcc): 48 B (RGB) / 196 B (spectral) not written
     newHdr.y = __float_as_uint(camWeight);
     newHdr.z = __float_as_uint(wlOffset);
-    pb.rayOrg[slot] = make_float4(lensP.x, lensP.y, lensP.z, 0.0f);
-    pb.rayDir[slot] = make_float4(rayDir.x, rayDir.y, rayDir.z, INFINITY);
+    pb.rayOrg[(size_t)slot * pb.rayStride] = make_float4(lensP.x, lensP.y, lensP.z, 0.0f);
+    pb.rayDir[(size_t)slot * pb.rayStride] = make_float4(rayDir.x, rayDir.y, rayDir.z, INFINITY);
 }
 
 // sensor->add(p.x, p.y, wls, weight * C)  PathTracingRenderer.cpp:126-130: the finished path's radiance sum, times the camera
@@ -949,7 +949,7 @@ __device__ __forceinline__ void accumulateSample(const PathBuffers& pb, const Re
     S C, accR, accC;
     float unusedW;
     const float camW = __uint_as_float(hdr.y);
-    if (F_SPVALID(flags)) SpecIO<S>::load(pb.spR, nullptr, slot, rp.numSlots, C, unusedW);     // else the path gathered nothing: C = 0
+    if (F_SPVALID(flags)) SpecIO<S>::load(pb.spR, nullptr, slot * pb.spStride, rp.numSlots * pb.spStride, C, unusedW);     // else the path gathered nothing: C = 0
     // accR / accC interleave (pb.accC = pb.accR + 1, element stride 2): the pair is one 32-byte sector per slot
     SpecIO<S>::load(pb.accR, nullptr, 2 * slot, 2 * rp.numSlots, accR, unusedW);
     SpecIO<S>::load(pb.accC, nullptr, 2 * slot, 2 * rp.numSlots, accC, unusedW);

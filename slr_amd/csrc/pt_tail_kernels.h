@@ -116,9 +116,9 @@ __global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(SLR
             continue;
         }
         // ---- one bounce: the two rays of this slot, then the logic visit -----------------------------------------------------
-        const float4 o = pb.rayOrg[slot];
+        const float4 o = pb.rayOrg[(size_t)slot * pb.rayStride];
         if (state != ST_FINISH) {
-            const float4 d = pb.rayDir[slot];
+            const float4 d = pb.rayDir[(size_t)slot * pb.rayStride];
             HitRec hit;
             traverse<false, false>(sc, sc.nodes, sc.leafTris, tlds.top, numTop, V3(o.x, o.y, o.z), V3(d.x, d.y, d.z), o.w, d.w, &hit, stack, &cnt,
                                    pb.errorWord);

@@ -52,8 +52,8 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace_closest(DevScene sc, Path
     for (uint32_t slot = blockIdx.x * kTraceBlock + threadIdx.x; slot < numSlots; slot += stride) {
         const uint32_t state = pb.flags[slot] & 7u;
         if (state == 2u || state == 3u) {
-            const float4 o = pb.rayOrg[slot];
-            const float4 d = pb.rayDir[slot];
+            const float4 o = pb.rayOrg[(size_t)slot * pb.rayStride];
+            const float4 d = pb.rayDir[(size_t)slot * pb.rayStride];
             HitRec hit;
             traverse<false, COUNT>(sc, sc.nodes, sc.leafTris, lds.top, numTop, V3(o.x, o.y, o.z), V3(d.x, d.y, d.z), o.w, d.w, &hit,
                                    lds.stack + threadIdx.x, &cnt, pb.errorWord);
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace_shadow(DevScene sc, PathB
     const uint32_t stride = (gridDim.x / kShards) * kTraceBlock;
     for (uint32_t i = (blockIdx.x / kShards) * kTraceBlock + threadIdx.x; i < n; i += stride) {
         const uint32_t slot = queue[i];
-        const float4 o = pb.rayOrg[slot];
+        const float4 o = pb.rayOrg[(size_t)slot * pb.rayStride];
         const float4 d = pb.shadowDir[slot];
         HitRec hit;
         const bool occluded = traverse<true, COUNT>(sc, sc.nodes, sc.leafTris, lds.top, numTop, V3(o.x, o.y, o.z), V3(d.x, d.y, d.z),

@@ -447,8 +447,8 @@ __device__ __forceinline__ void wsProduce(const PathBuffers& pb, LDS& lds, uint3
 #pragma unroll
                 for (int j = 0; j < kSub; ++j) {
                     const uint32_t s = c * chunk + j * 64 + lane;
-                    o[j] = live[j] ? ntLoad4(&pb.rayOrg[s]) : make_float4(0, 0, 0, 0);
-                    d[j] = live[j] ? ntLoad4(&pb.rayDir[s]) : make_float4(0, 0, 0, 0);
+                    o[j] = live[j] ? ntLoad4(&pb.rayOrg[(size_t)s * pb.rayStride]) : make_float4(0, 0, 0, 0);
+                    d[j] = live[j] ? ntLoad4(&pb.rayDir[(size_t)s * pb.rayStride]) : make_float4(0, 0, 0, 0);
                 }
                 ok = wsWaitSpace(lds, tailLocal, chunk, &dbg.producerWaits);
                 if (!ok) { if (lane == 0) atomicOr(pb.errorWord, ERR_RING_SPACE); break; }
@@ -475,7 +475,7 @@ __device__ __forceinline__ void wsProduce(const PathBuffers& pb, LDS& lds, uint3
 #pragma unroll
             for (int j = 0; j < kSub; ++j) {
                 const bool valid = sl[j] != kIdle;
-                o[j] = valid ? ntLoad4(&pb.rayOrg[sl[j]]) : make_float4(0, 0, 0, 0);
+                o[j] = valid ? ntLoad4(&pb.rayOrg[(size_t)sl[j] * pb.rayStride]) : make_float4(0, 0, 0, 0);
                 d[j] = valid ? ntLoad4(&pb.shadowDir[sl[j]]) : make_float4(0, 0, 0, 0);
                 o[j].w = kRayEpsilon;
             }

@@ -26,6 +26,7 @@ using namespace slrhip;
 
 namespace {
 
+const int kDefaultPairs = 1;                   // SLRHIP_PAIRS: the ray pair pays, the radiance-sum pair does not
 const uint32_t kStatusWords = 8;               // PathBuffers::activeSlots .. tailWords: one small array, read back in one copy
 const uint32_t kDefaultTailSlots = 1u << 18;   // SLRHIP_TAIL_SLOTS: measured on the headline frame and its N = 8 shard
 
@@ -729,8 +730,12 @@ int slrhip_render_begin(slrhip_ctx* ctx, const slrhip_render_settings* st, slrhi
     const size_t planes = spectral ? 4 : 1;
     HIP_TRY(ctx->pixelXY.upload(pixels));
     HIP_TRY(ctx->rng.alloc(numSlots, true));
-    HIP_TRY(ctx->rayOrg.alloc(numSlots, true)); HIP_TRY(ctx->rayDir.alloc(numSlots, true)); HIP_TRY(ctx->hit.alloc(numSlots, true));
-    HIP_TRY(ctx->alpha.alloc(numSlots * planes, true)); HIP_TRY(ctx->spR.alloc(numSlots * planes, true)); HIP_TRY(ctx->spC.alloc(numSlots * planes, true));
+    // SLRHIP_PAIRS (bit 0: ray origin + direction, bit 1: the path's radiance sum + its compensation): the two records of a pair
+    // interleaved in one array, one 32-byte sector per slot (PathBuffers::rayStride / spStride)
+    static const int envPairs = [] { const char* e = getenv("SLRHIP_PAIRS"); return e ? atoi(e) : kDefaultPairs; }();
+    const uint32_t rayStride = (envPairs & 1) ? 2u : 1u, spStride = (envPairs & 2) ? 2u : 1u;
+    HIP_TRY(ctx->rayOrg.alloc(numSlots * rayStride, true)); HIP_TRY(ctx->rayDir.alloc(rayStride == 2 ? 1 : numSlots, true)); HIP_TRY(ctx->hit.alloc(numSlots, true));
+    HIP_TRY(ctx->alpha.alloc(numSlots * planes, true)); HIP_TRY(ctx->spR.alloc(numSlots * planes * spStride, true)); HIP_TRY(ctx->spC.alloc(spStride == 2 ? 1 : numSlots * planes, true));
     HIP_TRY(ctx->accR.alloc(2 * numSlots * planes, true));      /* accR and accC interleaved */ HIP_TRY(ctx->nee.alloc(numSlots * planes, true));
     HIP_TRY(ctx->shadowDir.alloc(numSlots, true));
     HIP_TRY(ctx->pdfPrev.alloc(spectral ? numSlots : 1, true));
@@ -755,8 +760,9 @@ int slrhip_render_begin(slrhip_ctx* ctx, const slrhip_render_settings* st, slrhi
     HIP_TRY(hipStreamSynchronize(nullptr));
 
     PathBuffers& pb = ctx->buffers;
-    pb.rng = ctx->rng.ptr; pb.rayOrg = ctx->rayOrg.ptr; pb.rayDir = ctx->rayDir.ptr; pb.hit = ctx->hit.ptr;
-    pb.alpha = ctx->alpha.ptr; pb.spR = ctx->spR.ptr; pb.spC = ctx->spC.ptr; pb.accR = ctx->accR.ptr; pb.accC = ctx->accR.ptr + 1;
+    pb.rng = ctx->rng.ptr; pb.rayOrg = ctx->rayOrg.ptr; pb.rayDir = rayStride == 2 ? ctx->rayOrg.ptr + 1 : ctx->rayDir.ptr; pb.hit = ctx->hit.ptr;
+    pb.rayStride = rayStride; pb.spStride = spStride;
+    pb.alpha = ctx->alpha.ptr; pb.spR = ctx->spR.ptr; pb.spC = spStride == 2 ? ctx->spR.ptr + 1 : ctx->spC.ptr; pb.accR = ctx->accR.ptr; pb.accC = ctx->accR.ptr + 1;
     pb.nee = ctx->nee.ptr;
     pb.pdfPrev = spectral ? ctx->pdfPrev.ptr : nullptr; pb.hdr = ctx->hdr.ptr; pb.finishedMask = ctx->finishedMask.ptr; pb.nextSample = ctx->nextSample.ptr; pb.shadowDir = ctx->shadowDir.ptr; pb.flags = ctx->flags.ptr;
     pb.visible = ctx->visible.ptr; pb.shadowQueue = ctx->shadowQueue.ptr; pb.regenQueue = ctx->regenQueue.ptr;
@@ -1157,8 +1163,15 @@ int slrhip_debug_read_rays(slrhip_ctx* ctx, uint32_t first, uint32_t n, float* r
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipDeviceSynchronize());
     std::vector<float4> org(n), dir(n);
-    HIP_TRY(hipMemcpy(org.data(), ctx->rayOrg.ptr + first, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(dir.data(), ctx->rayDir.ptr + first, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost));
+    if (ctx->buffers.rayStride == 2) {
+        std::vector<float4> both((size_t)n * 2);
+        HIP_TRY(hipMemcpy(both.data(), ctx->rayOrg.ptr + (size_t)first * 2, both.size() * sizeof(float4), hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < n; ++i) { org[i] = both[(size_t)i * 2]; dir[i] = both[(size_t)i * 2 + 1]; }
+    }
+    else {
+        HIP_TRY(hipMemcpy(org.data(), ctx->rayOrg.ptr + first, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(dir.data(), ctx->rayDir.ptr + first, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost));
+    }
     for (uint32_t i = 0; i < n; ++i) {
         float* r = rays + (size_t)i * 8;
         r[0] = org[i].x; r[1] = org[i].y; r[2] = org[i].z; r[3] = dir[i].x; r[4] = dir[i].y; r[5] = dir[i].z; r[6] = org[i].w; r[7] = dir[i].w;
