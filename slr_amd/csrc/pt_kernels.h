@@ -130,7 +130,7 @@ struct PathBuffers {
     // Records that the same kernels touch at the same slots share a 32-byte sector when these strides are 2 (rayDir = rayOrg + 1,
     // spC = spR + 1, element index = slot x stride): a kernel that visits a fraction of the slots then moves one sector per
     // visited slot and pair instead of most sectors of two arrays.  1 = separate arrays.
-    uint32_t rayStride, spStride;
+    uint32_t rayStride, spStride, hdrStride;      // hdrStride 2: rng = hdr + 1 (sample header + RNG state of a slot in one sector)
 };
 
 struct RenderParams {

@@ -50,7 +50,7 @@ void launchBsdfQueries(const DevScene& sc, bool spectral, uint32_t material, uin
 __global__ __launch_bounds__(kShadeBlock) void k_count_samples(PathBuffers pb, RenderParams rp) {
     __shared__ uint32_t red[kShadeBlock / 64];
     uint32_t n = 0;
-    for (uint32_t slot = blockIdx.x * kShadeBlock + threadIdx.x; slot < rp.numSlots; slot += gridDim.x * kShadeBlock) n += pb.hdr[slot].x;
+    for (uint32_t slot = blockIdx.x * kShadeBlock + threadIdx.x; slot < rp.numSlots; slot += gridDim.x * kShadeBlock) n += pb.hdr[(size_t)slot * pb.hdrStride].x;
     for (int off = 32; off > 0; off >>= 1) n += __shfl_down(n, off);
     if ((threadIdx.x & 63u) == 0) red[threadIdx.x >> 6] = n;
     __syncthreads();

@@ -449,7 +449,7 @@ __device__ __forceinline__ void logicSlot(const DevScene& sc, const PathBuffers&
                                           const float* lightPMF, const float* lightCDF, uint32_t slot, uint32_t flags, bool leader, uint32_t parity,
                                           bool& emitExt, bool& emitShadow, bool& emitRegen) {
     // ---- all state loads up front: one memory round trip instead of a dependent chain (flags: read above) -----------
-    const uint4 r4 = pb.rng[slot];
+    const uint4 r4 = pb.rng[(size_t)slot * pb.hdrStride];
     // The path's radiance sum (Kahan pair) and the pending light sample: RGB keeps them in registers (3 x 16 B,
     // requested with everything else); in spectral mode they are 3 x 64 B that most visits never touch, so they
     // stay in HBM and SpAcc updates them in place when a contribution actually arrives.
@@ -461,7 +461,7 @@ __device__ __forceinline__ void logicSlot(const DevScene& sc, const PathBuffers&
     const float4 h = pb.hit[slot];
     const float4 o4 = pb.rayOrg[(size_t)slot * pb.rayStride], d4 = pb.rayDir[(size_t)slot * pb.rayStride];
     const uint32_t vis = pb.visible[slot];
-    const float wlOffset = S::N == 3 ? 0.0f : __uint_as_float(pb.hdr[slot].z);
+    const float wlOffset = S::N == 3 ? 0.0f : __uint_as_float(pb.hdr[(size_t)slot * pb.hdrStride].z);
 
     const uint32_t state = F_STATE(flags);
     if (state == ST_FIRST_HIT || state == ST_NEXT_HIT || state == ST_FINISH) {
@@ -764,7 +764,7 @@ __device__ __forceinline__ void logicSlot(const DevScene& sc, const PathBuffers&
         }
         sp.end(pb, slot, rp.numSlots, !emitRegen);
         if (!emitRegen) {
-            if (leader) pb.rng[slot] = make_uint4(rng.s0, rng.s1, rng.s2, rng.s3);
+            if (leader) pb.rng[(size_t)slot * pb.hdrStride] = make_uint4(rng.s0, rng.s1, rng.s2, rng.s3);
             SpecIO<S>::store(pb.alpha, pb.pdfPrev, slot, rp.numSlots, alpha, bsdfPDFprev);
         }
         if (emitExt && leader) {
@@ -934,7 +934,7 @@ __device__ __forceinline__ void startSample(const DevScene& sc, const PathBuffer
     // weight :126
     float camWeight = absDot(rayDir, lensN) / (sc.camera.areaPDF * dirPDF * selectWLPDF);
     pb.flags[slot] = F_MAKE((uint32_t)ST_FIRST_HIT, 0u, wl, 0u, 0u, 0u);
-    pb.rng[slot] = make_uint4(rng.s0, rng.s1, rng.s2, rng.s3);
+    pb.rng[(size_t)slot * pb.hdrStride] = make_uint4(rng.s0, rng.s1, rng.s2, rng.s3);
     // alpha = 1, pdfPrev = 0 and sp = 0 are implied by ST_FIRST_HIT (see SpAcc): 48 B (RGB) / 196 B (spectral) not written
     newHdr.y = __float_as_uint(camWeight);
     newHdr.z = __float_as_uint(wlOffset);
@@ -971,7 +971,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_regen(DevScene sc, PathBuffers 
     if (i < n) {
         slot = pb.regenQueue[(size_t)shard * rp.shardCapacity + i];
         const uint32_t flags = pb.flags[slot];
-        const uint4 hdr = pb.hdr[slot];
+        const uint4 hdr = pb.hdr[(size_t)slot * pb.hdrStride];
         uint32_t sampleIdx = hdr.x;
         if (F_HASPATH(flags)) {
             accumulateSample<S>(pb, rp, slot, flags, hdr);
@@ -993,7 +993,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_regen(DevScene sc, PathBuffers 
         else {
             startSample<S>(sc, pb, rp, slot, pix, pass, newHdr);
         }
-        pb.hdr[slot] = newHdr;
+        pb.hdr[(size_t)slot * pb.hdrStride] = newHdr;
     }
     // slots run out of samples only at the very end of a render() call, so this atomic is rare
     const uint64_t mi = __ballot(becameIdle);
@@ -1007,7 +1007,7 @@ __global__ void k_reset_slots(PathBuffers pb, RenderParams rp, uint32_t clearAcc
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;     // blockDim == kShadeBlock
     if (slot < rp.numSlots) {
         pb.flags[slot] = F_MAKE((uint32_t)ST_REGEN, 0u, 0u, 0u, 0u, 0u);
-        pb.hdr[slot] = make_uint4(0u, 0u, 0u, 0u);
+        pb.hdr[(size_t)slot * pb.hdrStride] = make_uint4(0u, 0u, 0u, 0u);
         if (slot < rp.numPixels) {
             pb.nextSample[slot] = rp.stripes;
             pb.finishedMask[slot] = 0ull;

@@ -92,7 +92,7 @@ __global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(SLR
         if (state == ST_IDLE) { slot = kTailNone; continue; }    // not expected (the list holds live slots): nothing to do
         if (state == ST_REGEN) {
             // the path ended (now, or in the last wavefront iteration): the two halves of k_regen for this slot
-            const uint4 hdr = pb.hdr[slot];
+            const uint4 hdr = pb.hdr[(size_t)slot * pb.hdrStride];
             uint32_t sampleIdx = hdr.x;
             if (F_HASPATH(flags)) {
                 accumulateSample<S>(pb, rp, slot, flags, hdr);
@@ -105,12 +105,12 @@ __global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(SLR
             if (pass >= rp.sppCount) {
                 pb.flags[slot] = F_MAKE((uint32_t)ST_IDLE, 0u, 0u, 0u, 0u, 0u);
                 ++wentIdle;
-                pb.hdr[slot] = newHdr;
+                pb.hdr[(size_t)slot * pb.hdrStride] = newHdr;
                 slot = kTailNone;
             }
             else {
                 startSample<S>(sc, pb, rp, slot, pix, rp.sppBegin + pass, newHdr);
-                pb.hdr[slot] = newHdr;
+                pb.hdr[(size_t)slot * pb.hdrStride] = newHdr;
                 ++taken;
             }
             continue;

@@ -729,17 +729,16 @@ int slrhip_render_begin(slrhip_ctx* ctx, const slrhip_render_settings* st, slrhi
     const bool spectral = ctx->config.mode == SLRHIP_MODE_SPECTRAL;
     const size_t planes = spectral ? 4 : 1;
     HIP_TRY(ctx->pixelXY.upload(pixels));
-    HIP_TRY(ctx->rng.alloc(numSlots, true));
-    // SLRHIP_PAIRS (bit 0: ray origin + direction, bit 1: the path's radiance sum + its compensation): the two records of a pair
+    // SLRHIP_PAIRS (bit 0: ray origin + direction, bit 1: the path's radiance sum + its compensation, bit 2: sample header + RNG state): the two records of a pair
     // interleaved in one array, one 32-byte sector per slot (PathBuffers::rayStride / spStride)
     static const int envPairs = [] { const char* e = getenv("SLRHIP_PAIRS"); return e ? atoi(e) : kDefaultPairs; }();
-    const uint32_t rayStride = (envPairs & 1) ? 2u : 1u, spStride = (envPairs & 2) ? 2u : 1u;
+    const uint32_t rayStride = (envPairs & 1) ? 2u : 1u, spStride = (envPairs & 2) ? 2u : 1u, hdrStride = (envPairs & 4) ? 2u : 1u;
     HIP_TRY(ctx->rayOrg.alloc(numSlots * rayStride, true)); HIP_TRY(ctx->rayDir.alloc(rayStride == 2 ? 1 : numSlots, true)); HIP_TRY(ctx->hit.alloc(numSlots, true));
     HIP_TRY(ctx->alpha.alloc(numSlots * planes, true)); HIP_TRY(ctx->spR.alloc(numSlots * planes * spStride, true)); HIP_TRY(ctx->spC.alloc(spStride == 2 ? 1 : numSlots * planes, true));
     HIP_TRY(ctx->accR.alloc(2 * numSlots * planes, true));      /* accR and accC interleaved */ HIP_TRY(ctx->nee.alloc(numSlots * planes, true));
     HIP_TRY(ctx->shadowDir.alloc(numSlots, true));
     HIP_TRY(ctx->pdfPrev.alloc(spectral ? numSlots : 1, true));
-    HIP_TRY(ctx->hdr.alloc(numSlots, true));
+    HIP_TRY(ctx->hdr.alloc(numSlots * hdrStride, true)); HIP_TRY(ctx->rng.alloc(hdrStride == 2 ? 1 : numSlots, true));
     HIP_TRY(ctx->finishedMask.alloc(2 * (size_t)numPixels + 2, true)); HIP_TRY(ctx->nextSample.alloc((size_t)numPixels + 1, true));
     HIP_TRY(ctx->flags.alloc(numSlots, true)); HIP_TRY(ctx->visible.alloc(numSlots, true));
     // queue regions: slot block b appends to region b % kShards, so a region holds at most ceil(numBlocks / kShards) blocks
@@ -760,7 +759,7 @@ int slrhip_render_begin(slrhip_ctx* ctx, const slrhip_render_settings* st, slrhi
     HIP_TRY(hipStreamSynchronize(nullptr));
 
     PathBuffers& pb = ctx->buffers;
-    pb.rng = ctx->rng.ptr; pb.rayOrg = ctx->rayOrg.ptr; pb.rayDir = rayStride == 2 ? ctx->rayOrg.ptr + 1 : ctx->rayDir.ptr; pb.hit = ctx->hit.ptr;
+    pb.rng = hdrStride == 2 ? ctx->hdr.ptr + 1 : ctx->rng.ptr; pb.hdrStride = hdrStride; pb.rayOrg = ctx->rayOrg.ptr; pb.rayDir = rayStride == 2 ? ctx->rayOrg.ptr + 1 : ctx->rayDir.ptr; pb.hit = ctx->hit.ptr;
     pb.rayStride = rayStride; pb.spStride = spStride;
     pb.alpha = ctx->alpha.ptr; pb.spR = ctx->spR.ptr; pb.spC = spStride == 2 ? ctx->spR.ptr + 1 : ctx->spC.ptr; pb.accR = ctx->accR.ptr; pb.accC = ctx->accR.ptr + 1;
     pb.nee = ctx->nee.ptr;
