@@ -212,7 +212,7 @@ def main():
                 ms = prof1.milliseconds[k] - prof0.milliseconds[k]
                 kernels[name] = {"launches": int(n), "ms_total": round(ms, 3), "avg_us": round(ms / n * 1e3, 3) if n else None}
             if kernels.get("tail", {}).get("launches") == 0:
-                kernels.pop("tail")       # the tail kernel is opt-in (SLRHIP_FLAG_TAIL_KERNEL): listed only when it ran
+                kernels.pop("tail")       # listed only when it ran (SLRHIP_TAIL_SLOTS=0 turns it off)
             # traversal statistics from an instrumented, untimed pass on this rank's shard
             cctx = Context(device=local_rank, mode=mode, stripes=args.stripes, flags=abi.FLAG_COUNT_TRAVERSAL)
             cctx.upload_scene(scene)

@@ -320,11 +320,13 @@ typedef struct slrhip_profile {
 #define SLRHIP_FLAG_TRACE_POOL 256u     /* experiment: the traversal kernel that keeps its rays resident in LDS and advances them in dense node /
                                          * triangle phases (pt_trace_ws.hip, wsConsumePool).  Identical results; measured 1.5x slower than the
                                          * default schedule on every BASELINE scene, kept with its parity test             */
-#define SLRHIP_FLAG_TAIL_KERNEL 128u    /* hand the last <= 2^18 live slots of a render call (never more than an eighth of the slots) to the
-                                         * tail kernel: one launch instead of the last ~80 wavefront iterations, 1 % (2.5 % at an eighth of
-                                         * the frame) faster.  Same samples, same frame with one stripe; with more stripes the passes the
-                                         * tail hands out go to other stripes than the wavefront schedule would pick, so the grouping of a
-                                         * pixel's float sum — and with it the last ulp — then depends on the shard size: off by default   */
+#define SLRHIP_FLAG_TAIL_KERNEL 128u    /* with a FIXED stripe count (slrhip_config::stripes > 0): also hand the last <= 2^18 live slots of a render
+                                         * call (never more than an eighth of the slots) to the tail kernel — one launch instead of the last
+                                         * ~80 wavefront iterations, 1 % (2.5 % at an eighth of the frame) faster.  Same samples, same frame
+                                         * with one stripe; with more stripes the passes the tail hands out go to other stripes than the
+                                         * wavefront schedule would pick, so the grouping of a pixel's float sum — the last ulp — then depends
+                                         * on the shard size.  With the AUTOMATIC stripe count (stripes = 0) that grouping depends on the shard
+                                         * size anyway, and the tail kernel is always on                                                    */
 #define SLRHIP_FLAG_BVH_SPATIAL_SPLITS 64u /* build the tree with spatial splits (sbvh.cpp; the reference's SBVH, Accelerator/SBVH.h:57-348):
                                          * a triangle straddling a split plane is referenced from both sides with clipped boxes.
                                          * Same hits; fewer triangle tests, more node visits: measured slower with these kernels on

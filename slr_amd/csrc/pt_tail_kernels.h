@@ -19,7 +19,8 @@
 // pass is rendered once, and the image differs from the pure wavefront schedule only in the grouping of a pixel's float sum
 // over its stripes — not at all with one stripe.  But when the tail takes over depends on the number of live slots, hence on
 // the shard size: with it the sum of the shards of a frame no longer equals the unsharded frame to the last bit at a fixed
-// stripe count (tests/test_gpu_parity.py::test_eight_tile_shards_...), which is why it is opt-in (SLRHIP_FLAG_TAIL_KERNEL).
+// stripe count (tests/test_gpu_parity.py::test_eight_tile_shards_...): with a fixed stripe count it is opt-in
+// (SLRHIP_FLAG_TAIL_KERNEL); with the automatic one — which itself depends on the shard size — it is always on.
 #pragma once
 #include "pt_shade_kernels.h"
 #include "pt_traverse.h"

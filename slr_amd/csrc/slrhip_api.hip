@@ -817,15 +817,18 @@ int slrhip_render(slrhip_ctx* ctx, uint32_t sppBegin, uint32_t sppCount, void* s
     uint32_t parity = 0;
     uint32_t active = rp.numSlots;
     uint32_t status[4] = {rp.numSlots, 0u, 0u, 0u};       // device words: live slots, error bits, -, tail mode (PathBuffers)
-    // The end of the call (pt_tail_kernels.h), on request (SLRHIP_FLAG_TAIL_KERNEL or SLRHIP_TAIL_SLOTS=n): once at most tailSlots
-    // slots are alive the traversal kernel raises the tail-mode word instead of tracing, the rest of the block of iterations is
-    // no-ops, and the tail kernel finishes every remaining path and pass in one launch.  Never for more than an eighth of the
-    // slots (the wavefront kernels are the efficient way to advance many paths), not in the counting build (its per-ray
-    // figures come from the wavefront kernels) and not for the four-lanes-per-slot spectral variant.
+    // The end of the call (pt_tail_kernels.h): once at most tailSlots slots are alive the traversal kernel raises the tail-mode
+    // word instead of tracing, the rest of the block of iterations is no-ops, and the tail kernel finishes every remaining path
+    // and pass in one launch.  ON when the stripe count is automatic (slrhip_config::stripes = 0: the grouping of a pixel's float
+    // sum over its stripes then depends on the shard size anyway), on request otherwise (SLRHIP_FLAG_TAIL_KERNEL,
+    // SLRHIP_TAIL_SLOTS=n): a caller who fixes the stripe count keeps the property that the shards of a frame sum to the
+    // unsharded frame bit for bit.  Never for more than an eighth of the slots (the wavefront kernels are the efficient way to
+    // advance many paths), not in the counting build (its per-ray figures come from the wavefront kernels) and not for the
+    // four-lanes-per-slot spectral variant.  SLRHIP_TAIL_SLOTS=0 turns it off.
     static const long envTail = [] { const char* e = getenv("SLRHIP_TAIL_SLOTS"); return e ? atol(e) : -1L; }();
     static const bool envQuadLanes = [] { const char* e = getenv("SLRHIP_SPECTRAL_LANES"); return e && std::string(e) == "4"; }();
     {
-        const bool asked = (ctx->config.flags & SLRHIP_FLAG_TAIL_KERNEL) != 0 || envTail > 0;
+        const bool asked = (ctx->config.flags & SLRHIP_FLAG_TAIL_KERNEL) != 0 || envTail > 0 || ctx->config.stripes == 0;
         const uint32_t bound = envTail > 0 ? (uint32_t)std::min<long>(envTail, 0x7FFFFFFFL) : kDefaultTailSlots;
         const bool off = !asked || envTail == 0 || (ctx->config.flags & SLRHIP_FLAG_COUNT_TRAVERSAL) != 0 || (rp.spectral && (rp.spectralQuad || envQuadLanes));
         rp.tailSlots = off ? 0u : std::min(bound, std::max(rp.numSlots / 8u, 1u));
