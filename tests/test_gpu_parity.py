@@ -949,3 +949,28 @@ def test_ldsresident_pool_traversal_gives_the_same_frames():
         assert out[0][3][0] == out[1][3][0] and out[1][3][1] >= out[0][3][1]
         assert_bit_equal(out[1][0], out[0][0], "LDS-resident pool traversal vs the default schedule")
         assert out[0][0].sum() > 0
+
+
+@pytest.mark.gpu
+def test_tail_kernel_variants_match_the_wavefront_iterations_bit_for_bit():
+    """Every k_tail instantiation against the wavefront schedule with ONE stripe (where the tail changes nothing but the
+    schedule, so the frames must be bit-identical): the glossy-lobe kernels (GGX boxes, both modes), the MultiBSDF and the
+    texture variants (tables in HBM), Ward / Ashikhmin lobes, and an environment light (paths that end at infinity)."""
+    cases = [("boxes ggx rgb", scenes.cornell_box_boxes(1.0), abi.MODE_RGB), ("boxes ggx spectral", scenes.cornell_box_boxes(1.0), abi.MODE_SPECTRAL),
+             ("multi rgb", scenes.cornell_multi(1.0, 10, 5), abi.MODE_RGB), ("multi spectral", scenes.cornell_multi(1.0, 10, 5), abi.MODE_SPECTRAL),
+             ("textured rgb", scenes.cornell_textured(1.0, 10, 5), abi.MODE_RGB), ("textured spectral", scenes.cornell_textured(1.0, 10, 5), abi.MODE_SPECTRAL),
+             ("ward", scenes.cornell_lobes("ward", segments=8, rings=4), abi.MODE_RGB),
+             ("environment light", scenes.ibl_test_scene(1.0, (64, 32), 8, 4), abi.MODE_RGB)]
+    st = ob.settings(48, 36, seed=33)
+    for name, sc, mode in cases:
+        out = []
+        for flags in (0, abi.FLAG_TAIL_KERNEL):
+            c = Context(mode=mode, stripes=1, flags=flags | abi.FLAG_TIME_KERNELS)
+            fb = c.render_image(sc, st, 6)
+            ctr, prof = c.counters(), c.profile()
+            out.append((fb, (int(ctr.samples), int(ctr.extension_rays), int(ctr.shadow_rays)), int(prof.launches[4])))
+            c.close()
+        assert out[0][2] == 0 and out[1][2] == 1, (name, out[0][2], out[1][2])
+        assert out[0][1] == out[1][1], (name, out[0][1], out[1][1])
+        assert_bit_equal(out[1][0], out[0][0], "tail kernel vs wavefront iterations, one stripe: " + name)
+        assert out[0][0].sum() > 0, name
