@@ -167,6 +167,7 @@ void launchLogic(const DevScene& sc, const PathBuffers& pb, const RenderParams& 
 void launchCountSamples(const PathBuffers& pb, const RenderParams& rp, hipStream_t stream);
 // the rest of a render call in one launch (after tailMode was raised): list the live slots, then one lane per path to its end
 void launchTail(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t liveSlots, uint32_t parity, int numCUs, hipStream_t stream);
+bool tailKernelAvailable(const DevScene& sc, bool spectral);      // not built for spectral scenes with MultiBSDF materials or textures
 void launchResolve(const PathBuffers& pb, const RenderParams& rp, float* dst, hipStream_t stream);
 void launchBsdfQueries(const DevScene& sc, bool spectral, uint32_t material, uint32_t n, const float* in, float wlOffset, uint32_t wl,
                        float4* geo, float4* misc, float4* fsSample, float4* fsEval, hipStream_t stream);

@@ -1,18 +1,23 @@
-// pt_shade_multi.hip — k_logic instantiations (see pt_shade_kernels.h)
+// pt_shade_multi.hip — dispatch to the all-lobes k_logic instantiations (MultiBSDF scenes, textured scenes); the instantiations
+// themselves are one per file (pt_shade_{multi,tex}_{rgb,spec}.hip): each takes a minute or more to compile
 #include "pt_shade_kernels.h"
 
 namespace slrhip {
 
+void launchLogicMultiRGB(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, hipStream_t stream);
+void launchLogicMultiSpec(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, hipStream_t stream);
+void launchLogicTexRGB(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, hipStream_t stream);
+void launchLogicTexSpec(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, hipStream_t stream);
+
 void launchLogicMulti(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, hipStream_t stream) {
-    const dim3 grid((rp.numSlots + kShadeBlock - 1) / kShadeBlock), block(kShadeBlock);
     if (sc.numTextures) {
         // textured scenes (checkerboard reflectances, bump): the same all-lobes kernel with the texture code
-        if (rp.spectral) hipLaunchKernelGGL((k_logic<Spec16, false, true, true, true>), grid, block, 0, stream, sc, pb, rp, parity);
-        else hipLaunchKernelGGL((k_logic<RGB, false, true, true, true>), grid, block, 0, stream, sc, pb, rp, parity);
+        if (rp.spectral) launchLogicTexSpec(sc, pb, rp, parity, stream);
+        else launchLogicTexRGB(sc, pb, rp, parity, stream);
         return;
     }
-    if (rp.spectral) hipLaunchKernelGGL((k_logic<Spec16, false, true, true>), grid, block, 0, stream, sc, pb, rp, parity);
-    else hipLaunchKernelGGL((k_logic<RGB, false, true, true>), grid, block, 0, stream, sc, pb, rp, parity);
+    if (rp.spectral) launchLogicMultiSpec(sc, pb, rp, parity, stream);
+    else launchLogicMultiRGB(sc, pb, rp, parity, stream);
 }
 
 } // namespace slrhip

@@ -1,5 +1,5 @@
 // pt_tail.hip — launcher of the tail kernel (pt_tail_kernels.h): picks the instantiation that matches the k_logic variant of the
-// scene (launchLogic, pt_shade.hip); the instantiations are in pt_tail_{rgb,spec16,multi}.hip.
+// scene (launchLogic, pt_shade.hip); the instantiations are in pt_tail_{rgb,spec16}.hip and pt_tail_{multi,tex}_rgb.hip.
 #include <algorithm>
 
 #include "pt_tail_kernels.h"
@@ -41,7 +41,10 @@ __global__ __launch_bounds__(kShadeBlock) void k_tail_collect(PathBuffers pb, Re
 
 void launchTailRGB(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, bool lds, bool glossy, uint32_t blocks, hipStream_t stream);
 void launchTailSpec16(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, bool lds, bool glossy, uint32_t blocks, hipStream_t stream);
-void launchTailMulti(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t blocks, hipStream_t stream);
+void launchTailMultiRGB(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t blocks, hipStream_t stream);
+void launchTailTexRGB(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t blocks, hipStream_t stream);
+
+bool tailKernelAvailable(const DevScene& sc, bool spectral) { return !(spectral && (sc.hasMulti || sc.numTextures)); }
 
 void launchTail(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t liveSlots, uint32_t parity, int numCUs, hipStream_t stream) {
     if (rp.numSlots == 0 || liveSlots == 0) return;
@@ -51,7 +54,10 @@ void launchTail(const DevScene& sc, const PathBuffers& pb, const RenderParams& r
     const bool ldsTables = sc.numMaterials <= (uint32_t)kLdsMaterials && sc.numLights <= (uint32_t)kLdsLights &&
                            (!rp.spectral || (sc.numSpectra <= (uint32_t)kLdsSpectra && sc.numSpectrumData <= (uint32_t)kLdsPoolFloats));
     const bool glossy = sc.hasMicrofacet != 0;
-    if (sc.hasMulti || sc.numTextures) launchTailMulti(sc, pb, rp, blocks, stream);
+    // (spectral scenes with MultiBSDF materials or textures never enter tail mode — tailKernelAvailable: that instantiation alone
+    // takes nine minutes to compile for a 1 % gain on scenes no BASELINE config has)
+    if (sc.numTextures) launchTailTexRGB(sc, pb, rp, blocks, stream);
+    else if (sc.hasMulti) launchTailMultiRGB(sc, pb, rp, blocks, stream);
     else if (rp.spectral) launchTailSpec16(sc, pb, rp, ldsTables, glossy, blocks, stream);
     else launchTailRGB(sc, pb, rp, ldsTables, glossy, blocks, stream);
 }

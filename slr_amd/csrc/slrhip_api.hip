@@ -830,7 +830,7 @@ int slrhip_render(slrhip_ctx* ctx, uint32_t sppBegin, uint32_t sppCount, void* s
     {
         const bool asked = (ctx->config.flags & SLRHIP_FLAG_TAIL_KERNEL) != 0 || envTail > 0 || ctx->config.stripes == 0;
         const uint32_t bound = envTail > 0 ? (uint32_t)std::min<long>(envTail, 0x7FFFFFFFL) : kDefaultTailSlots;
-        const bool off = !asked || envTail == 0 || (ctx->config.flags & SLRHIP_FLAG_COUNT_TRAVERSAL) != 0 || (rp.spectral && (rp.spectralQuad || envQuadLanes));
+        const bool off = !asked || envTail == 0 || !tailKernelAvailable(ctx->scene, rp.spectral != 0) || (ctx->config.flags & SLRHIP_FLAG_COUNT_TRAVERSAL) != 0 || (rp.spectral && (rp.spectralQuad || envQuadLanes));
         rp.tailSlots = off ? 0u : std::min(bound, std::max(rp.numSlots / 8u, 1u));
     }
     // tail mode seen in the status words: list the live slots, finish them, read the words again (live slots must be 0 then)
