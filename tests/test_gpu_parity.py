@@ -982,3 +982,24 @@ def test_tail_kernel_variants_match_the_wavefront_iterations_bit_for_bit():
         assert out[0][1] == out[1][1], (name, out[0][1], out[1][1])
         assert_bit_equal(out[1][0], out[0][0], "tail kernel vs wavefront iterations, one stripe: " + name)
         assert out[0][0].sum() > 0, name
+
+
+@pytest.mark.gpu
+def test_graph_replay_and_event_timed_launch_loops_give_the_same_frame():
+    """slrhip_render has two launch loops: blocks of 16 iterations captured once into a hipGraph and replayed (>= 2^18 slots, no
+    kernel timing) and plain launches bracketed by HIP events (SLRHIP_FLAG_TIME_KERNELS, what bench.py times).  Same kernels, same
+    order, the same tail-mode decision (it is taken on the device) => the same frame bit for bit, the same counters — with the
+    automatic stripe count (tail kernel on) and with a fixed one."""
+    sc = scenes.cornell_box_spheres(4.0 / 3.0, 16, 8, "matte")
+    st = ob.settings(640, 480, seed=77)
+    for stripes in (0, 2):
+        out = []
+        for flags in (0, abi.FLAG_TIME_KERNELS):
+            c = Context(stripes=stripes, flags=flags)
+            fb = c.render_image(sc, st, 48)
+            ctr = c.counters()
+            out.append((fb, (int(ctr.samples), int(ctr.extension_rays), int(ctr.shadow_rays), int(ctr.iterations))))
+            c.close()
+        assert out[0][1] == out[1][1], (stripes, out[0][1], out[1][1])
+        assert out[0][1][0] == 640 * 480 * 48
+        assert_bit_equal(out[0][0], out[1][0], "hipGraph replay vs event-timed launches (stripes %d)" % stripes)
