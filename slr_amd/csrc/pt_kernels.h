@@ -179,7 +179,7 @@ void launchTraceQuad(const DevScene& sc, const float4* nodes4, const float4* pac
 // wave-specialised traversal (pt_trace_ws.hip): same results, ONE launch for the extension and the shadow rays of an iteration
 void launchTraceWs(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, uint32_t blocks, bool count,
                    hipStream_t stream);
-int traceWsBlocksPerCU();
+int traceWsBlocksPerCU(bool quantizedTree);
 // pool schedule of the same file (experiment, SLRHIP_TRACE=pool): rays resident in LDS, dense node / triangle phases
 void launchTracePool(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, uint32_t blocks, bool count, uint32_t* spill,
                      hipStream_t stream);

@@ -26,7 +26,7 @@
 
 namespace slrhip {
 
-// NC = consumer waves per workgroup (3 -> 256 threads, 7 -> 512 threads); the ring holds 128 rays per wave of the group
+// NC = consumer waves per workgroup (3 -> 256 threads, 7 -> 512, 15 -> 1 024); the ring holds 64 x (NC + 1) rays (512 for NC = 15)
 static const int kWsLdsStack = 11;          // + 1 trash row = 12 rows of 64 lanes = 3 KiB per consumer wave
 static const int kWsSpill = 53;            // 11 + 53 = the reference's 64-entry stack (QBVH.h:299)
 static const int kSub = 2;                 // 64-slot sub-chunks the producer keeps in flight
@@ -35,7 +35,7 @@ static const int kSub = 2;                 // 64-slot sub-chunks the producer ke
 #endif
 static const int kAhead = SLR_WS_AHEAD;               // chunks whose state flags the producer reads in one round trip (see k_trace_ws)
 static uint32_t g_refill = 20;             // idle lanes that trigger a refill (SLRHIP_WS_REFILL)
-static int g_consumers = 3;                // SLRHIP_WS_NC
+static int g_consumers = 0;                // SLRHIP_WS_NC: consumer waves per workgroup (3, 7 or 15); 0 = by tree size: 15 on quantized (large) trees, else 7
 static const uint32_t kSpinLimit = 1u << 22;
 #ifndef SLR_WS_CHAIN
 #define SLR_WS_CHAIN 1
@@ -48,22 +48,25 @@ static const bool kNoSpill = false;
 #endif
 static const uint32_t kIdle = 0xFFFFFFFFu;
 
-int traceWsBlocksPerCU() {
+static int wsConsumers(bool quantized) { return g_consumers ? g_consumers : (quantized ? 15 : 7); }
+
+int traceWsBlocksPerCU(bool quantized) {
     static const bool init = [] {
         if (const char* e = getenv("SLRHIP_WS_REFILL")) g_refill = (uint32_t)atoi(e);
-        if (const char* e = getenv("SLRHIP_WS_NC")) g_consumers = atoi(e) == 7 ? 7 : 3;
+        if (const char* e = getenv("SLRHIP_WS_NC")) { const int n = atoi(e); g_consumers = n == 3 ? 3 : n == 15 ? 15 : n == 7 ? 7 : 0; }
         if (g_refill < 1) g_refill = 1;
         if (g_refill > 64) g_refill = 64;
         return true;
     }();
     (void)init;
     if (const char* e = getenv("SLRHIP_WS_BLOCKS_PER_CU")) { const int b = atoi(e); if (b >= 1 && b <= 8) return b; }   // experiments
-    return g_consumers == 7 ? 4 : 8;       // 18.5 KiB / 39.5 KiB of LDS per workgroup, 32 waves per CU either way (<= 64 VGPR)
+    const int nc = wsConsumers(quantized);
+    return nc == 15 ? 2 : nc == 7 ? 4 : 8;       // 18.5 / 39.5 / 64.5 KiB of LDS per workgroup, 32 waves per CU either way (<= 64 VGPR)
 }
 
 template <int NC>
 struct WsLds {
-    static constexpr uint32_t kRing = 64u * (NC + 1);      // ray ring entries (power of two)
+    static constexpr uint32_t kRing = NC == 15 ? 512u : 64u * (NC + 1);      // ray ring entries (power of two)
     float4 org[kRing];                     // xyz + tmin
     float4 dir[kRing];                     // xyz + tmax
     uint32_t slot[kRing];
@@ -914,7 +917,12 @@ static void launchTraceWsT(const DevScene& sc, const PathBuffers& pb, const Rend
 void launchTraceWs(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, uint32_t blocks, bool count,
                    hipStream_t stream) {
     blocks = (blocks + kShards - 1) / kShards * kShards;
-    if (g_consumers == 7) {
+    const int nc = wsConsumers(sc.nodesQ != nullptr);
+    if (nc == 15) {
+        if (count) launchTraceWsT<true, 15>(sc, pb, rp, parity, blocks, stream);
+        else launchTraceWsT<false, 15>(sc, pb, rp, parity, blocks, stream);
+    }
+    else if (nc == 7) {
         if (count) launchTraceWsT<true, 7>(sc, pb, rp, parity, blocks, stream);
         else launchTraceWsT<false, 7>(sc, pb, rp, parity, blocks, stream);
     }

@@ -808,7 +808,7 @@ int slrhip_render(slrhip_ctx* ctx, uint32_t sppBegin, uint32_t sppCount, void* s
     static const bool envPool = [] { const char* e = getenv("SLRHIP_TRACE"); return e && std::string(e) == "pool"; }();
     const bool useWs = !envBatch && !(ctx->config.flags & SLRHIP_FLAG_TRACE_BATCH);
     const bool usePool = useWs && (envPool || (ctx->config.flags & SLRHIP_FLAG_TRACE_POOL) != 0);
-    const uint32_t traceBlocks = (uint32_t)ctx->numCUs * (uint32_t)(usePool ? tracePoolBlocksPerCU() : useWs ? traceWsBlocksPerCU() : traceBlocksPerCU());
+    const uint32_t traceBlocks = (uint32_t)ctx->numCUs * (uint32_t)(usePool ? tracePoolBlocksPerCU() : useWs ? traceWsBlocksPerCU(ctx->scene.nodesQ != nullptr) : traceBlocksPerCU());
     if (usePool) {
         const size_t words = tracePoolSpillWords((traceBlocks + kShards - 1) / kShards * kShards);
         if (ctx->poolSpill.count < words) HIP_TRY(ctx->poolSpill.alloc(words));
