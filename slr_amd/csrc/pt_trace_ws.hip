@@ -10,7 +10,7 @@
 //
 //   wave 0      PRODUCER: streams the slot arrays in order (coalesced 1 KiB bursts, four 64-slot sub-chunks in flight),
 //               keeps the slots that have a ray, and appends them to a ring of rays in LDS.
-//   waves 1..3  CONSUMERS: one lane = one ray; whenever kRefill or more lanes are idle the wave reserves that many ring
+//   waves 1..NC CONSUMERS (NC = 7; 15 on large trees; SLRHIP_WS_NC): one lane = one ray; whenever kRefill or more lanes are idle the wave reserves that many ring
 //               entries (one LDS compare-and-swap by lane 0) and the idle lanes start on them, while the other lanes
 //               carry on mid-traversal.  A traversal step is one node (four slab tests) or ONE triangle, so lanes in
 //               different phases interleave at fine grain.
