@@ -34,10 +34,11 @@ TRI_BYTES = 48
 QUANT_NODE_THRESHOLD = 65536
 CLOSEST_RAY_BYTES = 4 + 16 + 16 + 16       # state flag, ray origin, ray direction, hit record written
 SHADOW_RAY_BYTES = 4 + 16 + 16 + 4         # queue entry, origin, direction+distMax, visibility written
-# k_logic per live slot.  RGB: state read 152 (flags 4, rng 16, alpha 16, sp pair 32, nee 16, hit 16, ray 32, visible 4, hdr 16)
-# + ShadeTri 96 + written ~140 + shadow entry ~20 + material 80 (LDS) + pixel/queue words ~100.  Spectral: read 156 (flags, rng,
-# alpha 64 + pdf 4, hit, ray, visible, hdr) + ShadeTri 96 + written 120 (flags, rng, alpha 68, ray 32) + pending light sample
-# 64 x 0.55 + radiance-sum read-modify-write 256 x 0.3 (only when a contribution arrives)
+# k_shade per live slot.  RGB: state read 136 (flags 4, rng 16, alpha 16, sp pair 32, nee 16, hit 16, ray 32, visible 4)
+# + ShadeTri 96 + written ~140 + shadow entry ~20 + material 80 (LDS) + per finished path (x 0.44 per visit) accumulator
+# read-modify-write 64 + header 32 + the restarted sample's state 68.  Spectral: read 156 (flags, rng, alpha 64 + pdf 4, hit, ray,
+# visible, hdr) + ShadeTri 96 + written 120 (flags, rng, alpha 68, ray 32) + pending light sample 64 x 0.55 + radiance-sum
+# read-modify-write 256 x 0.3 (only when a contribution arrives)
 SHADE_SLOT_BYTES = {"rgb": 588, "spectral": 484}
 
 
@@ -82,16 +83,11 @@ def parse():
 
 
 def traffic_entry(args, W, H, spp):
-    """PMC traffic per launch for this workload and image size: the entry collected at this spp, else at another spp of the same
-    workload (bytes per launch depend on the slots in flight, not on the pass count)."""
+    """PMC traffic per launch for EXACTLY this workload, image size and pass count (the share of nearly empty iterations at
+    the end of a render — and with it the average bytes per launch — changes with the pass count); {} when no pass covers it,
+    and the roofline figure is then a modelled one under its own key, never `frac`."""
     table = json.load(open(args.traffic_json))
-    exact = "%s_%dx%d_%dspp" % (args.workload, W, H, spp)
-    if exact in table:
-        return table[exact]
-    for key in sorted(table):
-        if key.startswith("%s_%dx%d_" % (args.workload, W, H)):
-            return table[key]
-    return {}
+    return table.get("%s_%dx%d_%dspp" % (args.workload, W, H, spp), {})
 
 
 def self_launch(args):
@@ -159,9 +155,16 @@ def main():
     fb = torch.zeros((H, W, comps), dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
 
+    shard_ms = []
+
     def step():
         # shard render -> resolve -> one RCCL sum-reduce to rank 0 (disjoint tile supports: sum == gather)
-        distributed.render_step(ctx, settings, spp, fb, rank, world, stream)
+        t = time.perf_counter()
+        ctx.render_begin(settings, shard=distributed.shard_for(rank, world))
+        ctx.render(0, spp, stream)             # blocks the host until this rank's passes are done
+        shard_ms.append((time.perf_counter() - t) * 1e3)
+        ctx.resolve_into(fb.data_ptr(), fb.numel(), stream)
+        distributed.reduce_framebuffer(fb, world)
 
     def fence():
         torch.cuda.synchronize()
@@ -172,6 +175,7 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    del shard_ms[:]
     prof0 = ctx.profile()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -180,10 +184,16 @@ def main():
     elapsed = time.perf_counter() - t0
     prof1 = ctx.profile()
     counters = ctx.counters()
+    rank_ms = [sum(shard_ms) / max(len(shard_ms), 1)]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # every rank's own shard-render time (host clock around slrhip_render), gathered so that rank 0 can report the spread
+        mine = torch.tensor(rank_ms, dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        rank_ms = [float(x.item()) for x in every]
 
     total_samples = float(W) * H * spp * args.steps
     value = total_samples / elapsed / 1e6
@@ -198,6 +208,10 @@ def main():
                        what, len(scene.triangles), "spectral" if mode == abi.MODE_SPECTRAL else "RGB", W, H, spp, abi.DEFAULT_SEED),
                    "sharding": "8x8 tiles round-robin over %d rank(s), one RCCL reduce of the framebuffer per step" % world,
                    "stripes": int(args.stripes)},
+        # evidence that the collective saw N ranks: the process group's backend and size as torch.distributed reports
+        # them, and each rank's own render time for its shard (ms per step, host clock around slrhip_render)
+        "backend": (dist.get_backend() if world > 1 else None), "rccl_ranks": (dist.get_world_size() if world > 1 else 1),
+        "shard_render_ms": {"min": round(min(rank_ms), 3), "max": round(max(rank_ms), 3), "per_rank": [round(x, 3) for x in rank_ms]},
     }
     if rehearsal:
         out["config"]["rehearsal"] = "all %d ranks share GPU 0, frames reduced over gloo: timings are not a measurement" % world
@@ -227,26 +241,18 @@ def main():
             shd_per_sample = cc.shadow_rays / max(cc.samples, 1)
             NODE_BYTES = node_bytes(int(counters.bvh_nodes))
             slot_bytes = SHADE_SLOT_BYTES["spectral" if comps == 16 else "rgb"]
-            per_ray = {"trace_closest": nodes_c * NODE_BYTES + tris_c * TRI_BYTES + CLOSEST_RAY_BYTES,
-                       "trace_shadow": nodes_s * NODE_BYTES + tris_s * TRI_BYTES + SHADOW_RAY_BYTES}
+            per_ray = {"closest": nodes_c * NODE_BYTES + tris_c * TRI_BYTES + CLOSEST_RAY_BYTES,
+                       "shadow": nodes_s * NODE_BYTES + tris_s * TRI_BYTES + SHADOW_RAY_BYTES}
             shard_samples = float(counters.samples) * args.steps     # sample totals restart at every render_begin
-            rays = {"trace_closest": shard_samples * ext_per_sample, "trace_shadow": shard_samples * shd_per_sample}
-            # the wave-specialised schedule traces both ray kinds in ONE launch, booked under trace_closest
-            merged = kernels["trace_shadow"]["launches"] == 0
-            if merged:
-                kernels["trace"] = kernels.pop("trace_closest")
-                kernels.pop("trace_shadow")
-                rays["trace"] = 1.0        # unit = one launch's worth of both kinds, bytes below
-                per_ray["trace"] = rays["trace_closest"] * per_ray["trace_closest"] + rays["trace_shadow"] * per_ray["trace_shadow"]
+            rays = {"closest": shard_samples * ext_per_sample, "shadow": shard_samples * shd_per_sample}
+            # algorithmic bytes of the timed region per kernel class: k_trace_ws traces both ray kinds in one launch;
+            # k_shade visits every live slot once per iteration = once per extension ray (+ idle tail ignored)
+            alg_bytes = {"trace": rays["closest"] * per_ray["closest"] + rays["shadow"] * per_ray["shadow"],
+                         "shade": rays["closest"] * slot_bytes}
             # the tail kernel (the last paths of a frame, one launch) is listed with the others but is not a roofline subject
             dom = max((n for n in kernels if n != "tail"), key=lambda n: kernels[n]["ms_total"])
-            if dom == "shade":
-                # every live slot is visited once per iteration = once per extension ray (+ idle tail ignored)
-                units, unit_bytes = rays["trace_closest"], slot_bytes
-            else:
-                units, unit_bytes = rays[dom], per_ray[dom]
             launches = max(kernels[dom]["launches"], 1)
-            bytes_per_launch = units * unit_bytes / launches
+            bytes_per_launch = alg_bytes[dom] / launches
             avg_s = kernels[dom]["ms_total"] / launches * 1e-3
             algorithmic = bytes_per_launch / avg_s / 1e9 if avg_s > 0 else 0.0
             # `achieved` / `frac` are HBM figures: bytes that reached HBM per launch (PMC, below) over the launch time.  The
@@ -261,44 +267,45 @@ def main():
                                 "tris_shadow": round(tris_s, 3), "extension_rays_per_sample": round(ext_per_sample, 4),
                                 "shadow_rays_per_sample": round(shd_per_sample, 4)}}
             # HBM bytes per launch of that kernel from the PMC passes (FETCH_SIZE x 2 + WRITE_SIZE, KiB; collected in their
-            # own rocprofv3 runs of this command and committed under profiles/) -- null when no pass covers this workload
+            # own rocprofv3 runs of THIS command line and committed under profiles/) -- null when no pass covers this exact workload
+            ent = {}
             try:
-                tr = traffic_entry(args, W, H, spp).get(dom)
-                if tr and world == 1:
-                    roof["traffic"] = round(tr["traffic_bytes_per_launch"])
-                    roof["traffic_source"] = os.path.relpath(args.traffic_json, ROOT)
-                    roof["achieved"] = round(tr["traffic_bytes_per_launch"] / avg_s / 1e9, 1)
-                    roof["basis"] = "pmc: (2 x FETCH_SIZE + WRITE_SIZE) KiB per launch of this kernel / its average launch time in THIS run"
+                ent = traffic_entry(args, W, H, spp) if world == 1 else {}
             except (OSError, ValueError):
                 pass
-            if roof["achieved"] is None:
-                # no PMC pass covers this workload / world size: HBM-side model = the per-ray and per-slot STATE records (which are
-                # streamed from HBM) plus the node and triangle bytes only when the tree exceeds the 256 MB Infinity Cache
+            if dom in ent:
+                tr = ent[dom]
+                roof["traffic"] = round(tr["traffic_bytes_per_launch"])
+                roof["traffic_source"] = os.path.relpath(args.traffic_json, ROOT)
+                roof["achieved"] = round(tr["traffic_bytes_per_launch"] / avg_s / 1e9, 1)
+                roof["frac"] = round(roof["achieved"] / HBM_PEAK_GBS, 5)
+                roof["basis"] = ("pmc: (2 x FETCH_SIZE + WRITE_SIZE) KiB per launch of this kernel from %s (separate rocprofv3 runs of "
+                                 "this command) / its average launch time in THIS run" % roof["traffic_source"])
+            else:
+                # no PMC pass covers this workload / pass count / world size: `frac` stays null.  A MODELLED figure under its own
+                # key: the per-ray and per-slot STATE records (which are streamed from HBM) plus the node and triangle bytes only
+                # when the tree exceeds the 256 MB Infinity Cache
                 tree_bytes = int(counters.bvh_nodes) * NODE_BYTES + len(scene.triangles) * TRI_BYTES
                 cached = tree_bytes < 256e6
                 if dom == "shade":
                     model = bytes_per_launch
                 else:
-                    state = (rays["trace_closest"] * CLOSEST_RAY_BYTES + rays["trace_shadow"] * SHADOW_RAY_BYTES) / launches
+                    state = (rays["closest"] * CLOSEST_RAY_BYTES + rays["shadow"] * SHADOW_RAY_BYTES) / launches
                     model = state if cached else bytes_per_launch
-                roof["achieved"] = round(model / avg_s / 1e9, 1)
-                roof["basis"] = "model: state records%s (no PMC entry for this workload)" % ("" if cached or dom == "shade" else " + node/triangle bytes")
-            roof["frac"] = round(roof["achieved"] / HBM_PEAK_GBS, 5)
+                roof["modelled_achieved"] = round(model / avg_s / 1e9, 1)
+                roof["modelled_frac"] = round(roof["modelled_achieved"] / HBM_PEAK_GBS, 5)
+                roof["basis"] = "no PMC entry for this exact workload: frac is null; modelled_frac = state records%s / launch time" % (
+                    "" if cached or dom == "shade" else " + node/triangle bytes")
             # whole-sample algorithmic bytes (SURVEY 8d formula) for reference
-            sample_bytes = (ext_per_sample * per_ray["trace_closest"] + shd_per_sample * per_ray["trace_shadow"] +
-                            ext_per_sample * slot_bytes)
+            sample_bytes = (ext_per_sample * per_ray["closest"] + shd_per_sample * per_ray["shadow"] + ext_per_sample * slot_bytes)
             roof["algorithmic_bytes_per_sample"] = round(sample_bytes, 1)
-            try:
-                # whole-iteration HBM figure: PMC traffic of all kernels of an iteration over their summed launch times
-                ent = traffic_entry(args, W, H, spp)
-                it_kernels = [k for k in kernels if k != "tail"]      # the three launches of a wavefront iteration
-                if ent and world == 1 and all(k in ent for k in it_kernels):
-                    tot_b = sum(ent[k]["traffic_bytes_per_launch"] for k in it_kernels)
-                    tot_s = sum(kernels[k]["ms_total"] / max(kernels[k]["launches"], 1) for k in it_kernels) * 1e-3
-                    roof["iteration_traffic_bytes"] = round(tot_b)
-                    roof["iteration_frac"] = round(tot_b / tot_s / 1e9 / HBM_PEAK_GBS, 5)
-            except (OSError, ValueError):
-                pass
+            # whole-iteration HBM figure: PMC traffic of both kernels of an iteration over their summed launch times
+            it_kernels = [k for k in kernels if k != "tail"]
+            if ent and all(k in ent for k in it_kernels):
+                tot_b = sum(ent[k]["traffic_bytes_per_launch"] for k in it_kernels)
+                tot_s = sum(kernels[k]["ms_total"] / max(kernels[k]["launches"], 1) for k in it_kernels) * 1e-3
+                roof["iteration_traffic_bytes"] = round(tot_b)
+                roof["iteration_frac"] = round(tot_b / tot_s / 1e9 / HBM_PEAK_GBS, 5)
         out["roofline"] = roof
         out["kernels"] = kernels
         out["counters"] = {"samples": int(counters.samples), "extension_rays": int(counters.extension_rays),

@@ -24,12 +24,16 @@
 extern "C" {
 #endif
 
-#define SLRHIP_VERSION 6   /* 2: slrhip_material::param2, slrhip_scene_desc::upsampling, Ward / Ashikhmin lobes;
+#define SLRHIP_VERSION 7   /* 2: slrhip_material::param2, slrhip_scene_desc::upsampling, Ward / Ashikhmin lobes;
                             * 3: SLRHIP_MATERIAL_MULTI, slrhip_bsdf_queries (additive: version-2 callers are unaffected);
                             * 4: stripes > 64 rejected, device error word, samples counted on the device (additive);
                             * 5: slrhip_texture (checkerboard textures, bump, alpha), appended to slrhip_scene_desc; host spectrum
                             *    construction; slrhip_reduce_framebuffer;
-                            * 6: SLRHIP_KERNEL_TAIL (slrhip_profile grows by one kernel class), SLRHIP_FLAG_TAIL_KERNEL, SLRHIP_FLAG_TRACE_POOL                  */
+                            * 6: SLRHIP_KERNEL_TAIL (slrhip_profile grows by one kernel class), SLRHIP_FLAG_TAIL_KERNEL;
+                            * 7: the measured-slower traversal / shading schedules, their flags and the measurement exports are gone
+                            *    (TRACE_BATCH, TRACE_POOL, SPECTRAL_QUAD, QUAD_LAYOUT, slrhip_trace_rays_timed, slrhip_debug_read_rays);
+                            *    kernel classes of slrhip_profile = {TRACE, SHADE, TAIL}: a wavefront iteration is two launches;
+                            *    slrhip_bsdf_queries moved to slrhip_debug.h.  The number is frozen here: later additions append.   */
 
 /* ---- status codes -------------------------------------------------------------- */
 enum {
@@ -299,27 +303,23 @@ typedef struct slrhip_counters {
 /* ---- per-kernel timing and traversal statistics (measurement) ------------- */
 /* Kernel classes of one wavefront iteration. */
 enum {
-    SLRHIP_KERNEL_TRACE_CLOSEST = 0,   /* Scene::intersect            */
-    SLRHIP_KERNEL_TRACE_SHADOW = 1,    /* Scene::testVisibility       */
-    SLRHIP_KERNEL_SHADE = 2,           /* k_logic: getSurfacePoint .. bsdf->sample (PathTracingRenderer.cpp:149-258) */
-    SLRHIP_KERNEL_REGEN = 3,           /* k_regen: sensor->add + Job::kernel's camera ray (:100-130)  */
-    SLRHIP_KERNEL_TAIL = 4,            /* k_tail: the last paths of a render call, each taken to its end by one lane (all of the above
+    SLRHIP_KERNEL_TRACE = 0,           /* k_trace_ws: Scene::intersect and Scene::testVisibility of an iteration, one launch */
+    SLRHIP_KERNEL_SHADE = 1,           /* k_shade: getSurfacePoint .. bsdf->sample (PathTracingRenderer.cpp:149-258) and, for a path that
+                                        * ends, sensor->add + Job::kernel's camera ray of the slot's next pass (:100-130)               */
+    SLRHIP_KERNEL_TAIL = 2,            /* k_tail: the last paths of a render call, each taken to its end by one lane (all of the above
                                         * in one launch, once no pixel has a pass left to hand out)      */
-    SLRHIP_KERNEL_COUNT = 5
+    SLRHIP_KERNEL_COUNT = 3
 };
 typedef struct slrhip_profile {
     uint64_t launches[SLRHIP_KERNEL_COUNT];
     double   milliseconds[SLRHIP_KERNEL_COUNT];   /* sum of HIP-event durations on the render stream  */
-    uint64_t rays[2];                             /* rays processed by TRACE_CLOSEST / TRACE_SHADOW    */
-    uint64_t nodes[2];                            /* 4-wide nodes fetched (128 B each)                 */
+    uint64_t rays[2];                             /* [0] extension (closest-hit), [1] shadow rays traced */
+    uint64_t nodes[2];                            /* 4-wide nodes fetched (128 B each; 64 B quantized)  */
     uint64_t triangles[2];                        /* leaf triangles tested (48 B each)                 */
     uint64_t slot_visits;                         /* live slots processed by SHADE                     */
 } slrhip_profile;
 
 /* config.flags */
-#define SLRHIP_FLAG_TRACE_POOL 256u     /* experiment: the traversal kernel that keeps its rays resident in LDS and advances them in dense node /
-                                         * triangle phases (pt_trace_ws.hip, wsConsumePool).  Identical results; measured 1.5x slower than the
-                                         * default schedule on every BASELINE scene, kept with its parity test             */
 #define SLRHIP_FLAG_TAIL_KERNEL 128u    /* with a FIXED stripe count (slrhip_config::stripes > 0): also hand the last <= 2^18 live slots of a render
                                          * call (never more than an eighth of the slots) to the tail kernel — one launch instead of the last
                                          * ~80 wavefront iterations, 1 % (2.5 % at an eighth of the frame) faster.  Same samples, same frame
@@ -331,16 +331,10 @@ typedef struct slrhip_profile {
                                          * a triangle straddling a split plane is referenced from both sides with clipped boxes.
                                          * Same hits; fewer triangle tests, more node visits: measured slower with these kernels on
                                          * every BASELINE scene, so the object-split SAH tree stays the default          */
-#define SLRHIP_FLAG_QUAD_LAYOUT   32u   /* also build the four-lanes-per-ray node / leaf layouts at slrhip_upload_scene
-                                         * (slrhip_trace_rays_timed, mapping 1): the lane-mapping experiment of DESIGN.md   */
 #define SLRHIP_FLAG_TEST_DEVICE_ERROR 16u /* test hook: the next slrhip_render raises the device-side error word, so that the
                                          * error path (SLRHIP_ERR_HIP + message) can be exercised; renders nothing useful */
 #define SLRHIP_FLAG_TIME_KERNELS   1u   /* bracket every launch with HIP events (a few us per launch)        */
 #define SLRHIP_FLAG_COUNT_TRAVERSAL 2u  /* count nodes / triangles per ray (instrumented kernels, slower)    */
-#define SLRHIP_FLAG_SPECTRAL_QUAD  8u   /* spectral shade kernel with the 16 samples spread over four lanes per path (a quarter of
-                                         * the registers, the scalar path work replicated); identical results, kept for A/B timing */
-#define SLRHIP_FLAG_TRACE_BATCH    4u   /* trace with the 64-ray-batch kernels (two launches per iteration) instead of
-                                         * the wave-specialised one; identical results, kept for A/B checks and timing   */
 
 typedef struct slrhip_ctx slrhip_ctx;
 
@@ -396,32 +390,11 @@ int slrhip_components(const slrhip_ctx* ctx);   /* 3 or 16 */
  * slrhip_render_begin.  Needs the matching config.flags.                                       */
 int slrhip_get_profile(slrhip_ctx* ctx, slrhip_profile* out);
 
-/* Diagnostic: closest-hit queries against the uploaded scene, the aggregate part of
+/* Closest-hit queries against the uploaded scene, the aggregate part of
  * Scene::intersect (SurfaceObject.cpp:267-269,408-416).  rays: n x {org[3], dir[3], dist_min,
  * dist_max}; hits: n x {triangle index as uint32 bits (0xFFFFFFFF = miss), dist, b0, b1}
  * (Intersection::dist, ::u, ::v; TriangleMesh.cpp:169-173).  Host arrays; synchronises.        */
 int slrhip_trace_rays(slrhip_ctx* ctx, const float* rays, uint32_t n, float* hits);
-
-/* Measurement (lane-mapping experiment): the same closest-hit queries, copied to the device once, run `repeats` times
- * under one lane mapping and timed with HIP events: mapping 0 = one lane per ray, 1 = four lanes per ray (one child box / one
- * leaf triangle per lane; context created with SLRHIP_FLAG_QUAD_LAYOUT).  Same hits either way.  Host arrays; synchronises.   */
-int slrhip_trace_rays_timed(slrhip_ctx* ctx, const float* rays, uint32_t n, float* hits, int32_t mapping, uint32_t repeats,
-                            float* avg_milliseconds);
-/* Diagnostic: the extension rays stored in path slots [first, first + n) — after a render, every slot's last ray — in the
- * layout slrhip_trace_rays takes: real secondary rays to measure traversal on.                                          */
-int slrhip_debug_read_rays(slrhip_ctx* ctx, uint32_t first, uint32_t n, float* rays);
-
-/* Diagnostic: function-level BSDF queries against material `material` of the uploaded scene,
- * through the same device functions the shading kernel calls: BSDF::sample / evaluate /
- * evaluatePDF (directional_distribution_functions.h:231-279; flags = All, non-adjoint) on the
- * BSDF that SurfaceMaterial::getBSDF (surface_material.h:22) builds for wavelengths
- * WavelengthSamples::createWithEqualOffsets(wl_offset, u_lambda) (SpectrumTypes.h:54-64).
- *   queries[12 i ..]     = dirOut_sn[3], gNormal_sn[3], dirIn_sn[3], uComponent, uDir[2]
- *   out[(6 + 2C) i ..]   = sampled dir_sn[3], dirPDF, dirType, fs(sample)[C], fs(evaluate)[C],
- *                          evaluatePDF        (C = slrhip_components; zeros when dirPDF == 0)
- * Directions are in the shading frame (z = shading normal).  Host arrays; synchronises.        */
-int slrhip_bsdf_queries(slrhip_ctx* ctx, uint32_t material, uint32_t n, const float* queries,
-                        float wl_offset, float u_lambda, float* out);
 
 /* The per-(pixel, sample) seeding contract (pure function, also used by the oracle).      */
 int32_t slrhip_sample_seed(int32_t rng_seed, uint32_t pixel_x, uint32_t pixel_y, uint32_t pass);

@@ -87,13 +87,13 @@ class Counters(C.Structure):
 
 
 class Profile(C.Structure):
-    _fields_ = [("launches", C.c_uint64 * 5), ("milliseconds", C.c_double * 5), ("rays", C.c_uint64 * 2),
+    _fields_ = [("launches", C.c_uint64 * 3), ("milliseconds", C.c_double * 3), ("rays", C.c_uint64 * 2),
                 ("nodes", C.c_uint64 * 2), ("triangles", C.c_uint64 * 2), ("slot_visits", C.c_uint64)]
 
 
-FLAG_TIME_KERNELS, FLAG_COUNT_TRAVERSAL, FLAG_TRACE_BATCH, FLAG_SPECTRAL_QUAD, FLAG_TEST_DEVICE_ERROR, FLAG_QUAD_LAYOUT, FLAG_BVH_SPATIAL_SPLITS, FLAG_TAIL_KERNEL, FLAG_TRACE_POOL = 1, 2, 4, 8, 16, 32, 64, 128, 256
+FLAG_TIME_KERNELS, FLAG_COUNT_TRAVERSAL, FLAG_TEST_DEVICE_ERROR, FLAG_BVH_SPATIAL_SPLITS, FLAG_TAIL_KERNEL = 1, 2, 16, 64, 128
 MAX_STRIPES = 64
-KERNEL_NAMES = ("trace_closest", "trace_shadow", "shade", "regen", "tail")
+KERNEL_NAMES = ("trace", "shade", "tail")
 
 DEFAULT_SEED = 1509761209  # libSLRSceneGraph/API.cpp:1080
 

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(CSRC, "libslrhip.so")
 
 EXPORTS = ["slrhip_create", "slrhip_destroy", "slrhip_upload_scene", "slrhip_render_begin", "slrhip_render",
            "slrhip_resolve_framebuffer", "slrhip_reduce_framebuffer", "slrhip_read_framebuffer", "slrhip_synchronize", "slrhip_get_counters",
-           "slrhip_components", "slrhip_get_profile", "slrhip_trace_rays", "slrhip_trace_rays_timed", "slrhip_debug_read_rays", "slrhip_bsdf_queries", "slrhip_sample_seed", "slrhip_upsample", "slrhip_resolve_upsampled", "slrhip_spectrum_to_rgb", "slrhip_tonemap_bgr8", "slrhip_save_bmp",
+           "slrhip_components", "slrhip_get_profile", "slrhip_trace_rays", "slrhip_bsdf_queries", "slrhip_sample_seed", "slrhip_upsample", "slrhip_resolve_upsampled", "slrhip_spectrum_to_rgb", "slrhip_tonemap_bgr8", "slrhip_save_bmp",
            "slrhip_last_error_string", "slrhip_version"]
 
 
@@ -53,8 +53,6 @@ def load_library():
     lib.slrhip_components.argtypes = [C.c_void_p]
     lib.slrhip_get_profile.argtypes = [C.c_void_p, C.POINTER(abi.Profile)]
     lib.slrhip_trace_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
-    lib.slrhip_trace_rays_timed.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int32, C.c_uint32, C.POINTER(C.c_float)]
-    lib.slrhip_debug_read_rays.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
     lib.slrhip_bsdf_queries.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_float, C.c_float, C.c_void_p]
     lib.slrhip_sample_seed.argtypes = [C.c_int32, C.c_uint32, C.c_uint32, C.c_uint32]
     lib.slrhip_sample_seed.restype = C.c_int32
@@ -135,20 +133,6 @@ class Context:
         hits = np.zeros((n, 4), np.float32)
         _check(self.lib, self.lib.slrhip_trace_rays(self.handle, rays.ctypes.data, n, hits.ctypes.data), "slrhip_trace_rays")
         return hits[:, 0].copy().view(np.uint32), hits[:, 1], hits[:, 2], hits[:, 3]
-
-    def trace_rays_timed(self, rays8, mapping, repeats=5):
-        """rays8 [n][8] (org, dir, dist_min, dist_max) -> (hits [n][4] float32, average milliseconds per launch)."""
-        rays8 = np.ascontiguousarray(rays8, np.float32).reshape(-1, 8)
-        hits = np.zeros((len(rays8), 4), np.float32)
-        ms = C.c_float(0.0)
-        _check(self.lib, self.lib.slrhip_trace_rays_timed(self.handle, rays8.ctypes.data, len(rays8), hits.ctypes.data, mapping, repeats, C.byref(ms)),
-               "slrhip_trace_rays_timed")
-        return hits, ms.value
-
-    def read_slot_rays(self, first, n):
-        rays = np.zeros((n, 8), np.float32)
-        _check(self.lib, self.lib.slrhip_debug_read_rays(self.handle, first, n, rays.ctypes.data), "slrhip_debug_read_rays")
-        return rays
 
     def bsdf_queries(self, material, queries, wl_offset=0.5, u_lambda=0.5):
         """Function-level BSDF queries (slrhip_bsdf_queries): queries [n][12] -> [n][6 + 2C]."""

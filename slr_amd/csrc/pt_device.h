@@ -144,83 +144,6 @@ SLR_DEV Spec16 operator/(const Spec16& a, float s) { float r = 1 / s; return Spe
 SLR_DEV Spec16 operator+(const Spec16& a, float s) { return a + Spec16(s); }
 SLR_DEV Spec16 operator-(const Spec16& a, float s) { return a - Spec16(s); }
 
-// ---- the same 16-sample spectrum spread over FOUR adjacent lanes (a "quad"): lane q = threadIdx.x & 3 holds components
-// 4q .. 4q+3.  Used by the spectral shade kernel: a quarter of the registers per lane, 4x the lanes, the per-path scalar
-// work replicated in the quad (all four lanes execute it identically).  Cross-lane steps use DPP quad permutes:
-//   comp(i)   i uniform in the quad (the selected wavelength): broadcast from the owning lane
-//   own(i)    i is one of this lane's own indices (what make() passes to its callback): local
-//   sum()     the reference's running sum c0 + c1 + ... + c15 in THAT order (SpectrumTypes.h:516-518): four rounds, in
-//             round k every lane continues the chain with its own four components and lane k's result is broadcast
-//   isZero()  AND over the quad
-template <int K>
-SLR_DEV float quadBroadcast(float v) {
-    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), K * 0x55, 0xF, 0xF, true));
-}
-template <int CTRL>
-SLR_DEV int quadPermute(int v) { return __builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, true); }
-
-struct SpecQ {
-    float c[4];
-    static constexpr int N = 16;
-    static constexpr int LANES = 4;
-    SLR_DEV static uint32_t q() { return threadIdx.x & 3u; }
-    SLR_DEV SpecQ() { c[0] = c[1] = c[2] = c[3] = 0.0f; }
-    SLR_DEV explicit SpecQ(float v) { c[0] = c[1] = c[2] = c[3] = v; }
-    template <class F> SLR_DEV static SpecQ make(F f) {
-        SpecQ r;
-        const int base = (int)(q() * 4u);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) r.c[j] = f(base + j);
-        return r;
-    }
-    SLR_DEV float local(uint32_t j) const {
-        float t[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { t[i] = c[i]; asm volatile("" : "+v"(t[i])); }        // see Spec16::comp
-        const bool b0 = j & 1u, b1 = j & 2u;
-        const float p0 = b0 ? t[1] : t[0], p1 = b0 ? t[3] : t[2];
-        return b1 ? p1 : p0;
-    }
-    SLR_DEV float own(int i) const { return local((uint32_t)i & 3u); }
-    SLR_DEV float comp(uint32_t idx) const {
-        const float mine = local(idx & 3u);
-        const float v0 = quadBroadcast<0>(mine), v1 = quadBroadcast<1>(mine), v2 = quadBroadcast<2>(mine), v3 = quadBroadcast<3>(mine);
-        const uint32_t owner = idx >> 2;
-        const float lo = (owner & 1u) ? v1 : v0, hi = (owner & 1u) ? v3 : v2;
-        return (owner & 2u) ? hi : lo;
-    }
-    SLR_DEV bool isZero() const {
-        int z = (c[0] == 0.0f && c[1] == 0.0f && c[2] == 0.0f && c[3] == 0.0f) ? 1 : 0;
-        z &= quadPermute<0xB1>(z);          // quad_perm [1,0,3,2]
-        z &= quadPermute<0x4E>(z);          // quad_perm [2,3,0,1]
-        return z != 0;
-    }
-    SLR_DEV float sum() const {
-        float s = 0.0f;
-        { const float t = (((s + c[0]) + c[1]) + c[2]) + c[3]; s = quadBroadcast<0>(t); }
-        { const float t = (((s + c[0]) + c[1]) + c[2]) + c[3]; s = quadBroadcast<1>(t); }
-        { const float t = (((s + c[0]) + c[1]) + c[2]) + c[3]; s = quadBroadcast<2>(t); }
-        { const float t = (((s + c[0]) + c[1]) + c[2]) + c[3]; s = quadBroadcast<3>(t); }
-        return s;
-    }
-};
-#define SLR_SPECQ_OP(op)                                                                                    \
-    SLR_DEV SpecQ operator op(const SpecQ& a, const SpecQ& b) {                                             \
-        SpecQ r;                                                                                            \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) r.c[i] = a.c[i] op b.c[i];                            \
-        return r;                                                                                           \
-    }
-SLR_SPECQ_OP(+)
-SLR_SPECQ_OP(-)
-SLR_SPECQ_OP(*)
-SLR_SPECQ_OP(/)
-#undef SLR_SPECQ_OP
-SLR_DEV SpecQ operator*(const SpecQ& a, float s) { SpecQ r; for (int i = 0; i < 4; ++i) r.c[i] = a.c[i] * s; return r; }
-SLR_DEV SpecQ operator*(float s, const SpecQ& a) { SpecQ r; for (int i = 0; i < 4; ++i) r.c[i] = a.c[i] * s; return r; }   // c.values[i] * s
-SLR_DEV SpecQ operator/(const SpecQ& a, float s) { float rc = 1 / s; SpecQ r; for (int i = 0; i < 4; ++i) r.c[i] = a.c[i] * rc; return r; }
-SLR_DEV SpecQ operator+(const SpecQ& a, float s) { return a + SpecQ(s); }
-SLR_DEV SpecQ operator-(const SpecQ& a, float s) { return a - SpecQ(s); }
-
 // importance(): RGBTypes.h:103-108 / SpectrumTypes.h:512-526 (marginal = (1 - primary) / (N - 1); N = 3 gives / 2)
 template <class S>
 SLR_DEV float importance(const S& s, uint32_t selectedLambda) {
@@ -233,11 +156,6 @@ SLR_DEV float importance(const S& s, uint32_t selectedLambda) {
 SLR_DEV RGB selectSpectrum(bool pick, const RGB& a, const RGB& b) { return RGB(pick ? a.r : b.r, pick ? a.g : b.g, pick ? a.b : b.b); }
 SLR_DEV Spec16 selectSpectrum(bool pick, const Spec16& a, const Spec16& b) {
     return Spec16::make([&](int i) { return pick ? a.c[i] : b.c[i]; });
-}
-SLR_DEV SpecQ selectSpectrum(bool pick, const SpecQ& a, const SpecQ& b) {
-    SpecQ r;
-    for (int i = 0; i < 4; ++i) r.c[i] = pick ? a.c[i] : b.c[i];
-    return r;
 }
 
 // BasicTypes/CompensatedSum.h:24-30

@@ -3,8 +3,6 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include <vector>
-
 #include "device_types.h"
 
 namespace slrhip {
@@ -57,14 +55,15 @@ struct DevScene {
 // Queue counters.  A counter word that every wave bumps saturates near 88 atomics/us on this chip
 // (MI355X_MICROARCH.md, rows "dequeue" / "fanin"), which made the first version of the shade kernel
 // atomic-bound (14 400 waves -> 164 us).  So: (1) there is NO extension-ray queue — nearly every live
-// slot has one, the traversal kernel walks all slots and reads the state flag; (2) the shadow and
-// regen queues are split into kShards regions, a workgroup appends to region (blockIdx % kShards) with
-// ONE atomic per workgroup, and every counter sits on its own 128-byte line.
-// One set of counters per iteration parity: kernels READ set `parity`; the logic kernel FILLS set
-// `parity ^ 1`, which k_trace_closest clears beforehand.
+// slot has one, the traversal kernel walks all slots and reads the state flag; (2) there is no queue of
+// finished paths either — the shade kernel restarts them itself (k_shade); (3) the shadow-ray queue is
+// split into kShards regions, a workgroup appends to region (blockIdx % kShards) with ONE atomic per
+// workgroup, and every counter sits on its own 128-byte line.
+// One set of counters per iteration parity: k_shade(parity) FILLS set `parity`, k_trace_ws(parity) READS it
+// and clears set `parity ^ 1` for the next k_shade.
 static const uint32_t kShards = 16;
 static const uint32_t kCounterStride = 32;                 // words: one 128-byte line per counter
-enum { Q_SHADOW = 0, Q_REGEN = 1, Q_KINDS = 2 };
+enum { Q_SHADOW = 0, Q_KINDS = 1 };
 static const uint32_t kQueueSetWords = Q_KINDS * kShards * kCounterStride;
 __host__ __device__ inline uint32_t queueCounterIndex(uint32_t parity, uint32_t kind, uint32_t shard) {
     return parity * kQueueSetWords + (kind * kShards + shard) * kCounterStride;
@@ -82,7 +81,10 @@ enum : uint32_t { ERR_RING_SPACE = 1u, ERR_RING_RELEASE = 2u, ERR_CONSUMER_IDLE 
 static const uint32_t kTotalStride = 16;                   // 64-bit words: one 128-byte line
 __host__ __device__ inline uint32_t totalIndex(uint32_t kind, uint32_t shard) { return (kind * kShards + shard) * kTotalStride; }
 
-// Path state, SoA, one record per slot (slot = stripe * numPixels + pixel-of-shard).
+// Path state, SoA, one record per slot.  Slot layout (slotAddr below): workgroup-local and pixel-major — the 256 slots of
+// shade workgroup b are the K stripes of pixelsPerBlock = 256 / K consecutive pixels of the shard, stripe fastest, so that the
+// stripes of a pixel sit in ONE workgroup: the pixel's sample pool (which stripe renders which pass) is settled inside k_shade
+// with an LDS mask and a barrier, in the same launch in which the paths end.
 struct PathBuffers {
     uint4* rng;                   // xorshift128 state
     float4* rayOrg;               // extension / shadow ray origin, w = distMin
@@ -97,23 +99,22 @@ struct PathBuffers {
     float4* nee;                  // pending next-event contribution
     float4* shadowDir;            // shadow ray direction, w = distMax
     float* pdfPrev;               // spectral mode only: the scalar that rides in alpha.w in RGB mode
-    // per-slot sample header, written by k_regen only: x = samples of this slot finished so far, y = the current sample's
+    // per-slot sample header, written when a sample starts: x = samples of this slot finished so far, y = the current sample's
     // camera weight (bits), z = its wavelength offset (bits; lambda_i = 360 + 470 (i + offset) / 16, spectral mode)
     uint4* hdr;
     uint32_t* flags;
-    // Per-pixel sample pool: the stripes of a pixel draw their next sample index from one counter, so that they all run
-    // out of samples at about the same iteration.  finishedMask[q][pixel] = stripes whose path ended in the iteration that
-    // filled queue set q (bit = stripe, OR-ed by k_logic: the result does not depend on arrival order); k_regen gives the
-    // finishing stripes the indices nextSample[pixel] + rank-in-mask; the pixel's stripe-0 slot advances the counter and
-    // clears the mask in the next k_logic.  Deterministic: which stripe gets which sample depends on path lengths only.
-    unsigned long long* finishedMask;
+    // Per-pixel sample pool: the stripes of a pixel draw their next pass from one counter, so that they all run out of
+    // passes at about the same iteration.  The stripes whose path ends in a k_shade launch set their bit in a 64-bit mask
+    // in LDS (the stripes of a pixel share a workgroup); after a barrier each of them takes the pass
+    // nextSample[pixel] + rank-in-mask and the lowest advances the counter.  Deterministic: which stripe renders which pass
+    // depends on path lengths only.
     uint32_t* nextSample;
     uint32_t* visible;            // result of the shadow ray
     uint32_t* shadowQueue;        // kShards regions of shardCapacity slot indices: shadow rays of this iteration
-    uint32_t* regenQueue;         // same layout: slots whose path ended (accumulate pixel, start next sample)
+    uint32_t* tailList;           // tail mode: the live slots, listed by k_tail_collect (numSlots entries)
     uint32_t* queueCount;         // [parity][kind][shard], see queueCounterIndex
     uint32_t* activeSlots;        // slots that still have samples to do
-    // one word per block of 256 consecutive slots: set by k_logic once every slot of the block has run out of passes (a slot
+    // one word per block of 256 consecutive slots: set by k_shade once every slot of the block has run out of passes (a slot
     // never leaves ST_IDLE within a render call), cleared by k_reset_slots; the scanning kernels skip such blocks without
     // touching their state — the last iterations of a render, in which a few long paths are left, then cost launch overhead
     uint32_t* blockDead;
@@ -134,7 +135,10 @@ struct PathBuffers {
 };
 
 struct RenderParams {
-    uint32_t numSlots, numPixels, stripes;
+    uint32_t numSlots;            // 256 x shade workgroups (the last lanes of a workgroup are padding when 256 % stripes != 0)
+    uint32_t numPixels, stripes;
+    uint32_t pixelsPerBlock;      // 256 / stripes
+    uint32_t stripesRecip;        // ceil(65536 / stripes): lane / stripes = (lane * stripesRecip) >> 16 for lane < 256 (exact: 256 x 64 < 65536)
     uint32_t sppBegin, sppCount;
     int32_t rngSeed;
     float timeStart, timeEnd;
@@ -142,13 +146,31 @@ struct RenderParams {
     uint32_t countSlots;          // SLRHIP_FLAG_COUNT_TRAVERSAL: also count live slots per logic launch
     uint32_t shardCapacity;       // entries per queue region = ceil(numBlocks / kShards) * 256
     uint32_t spectral;            // 0 = RGB (3 components), 1 = 16 wavelength samples
-    uint32_t spectralQuad;        // spectral shade kernel with four lanes per slot (SLRHIP_FLAG_SPECTRAL_QUAD)
     uint32_t injectError;         // SLRHIP_FLAG_TEST_DEVICE_ERROR: the reset kernel raises the device error word
     uint32_t tailSlots;           // enter tail mode once at most this many slots are live; 0 = never
 };
 
+// Where a slot sits: pixel of the shard, stripe, and whether the lane is a real slot (padding lanes are idle for ever).
+struct SlotAddr {
+    uint32_t pix, stripe, localPix;
+    bool valid;
+};
+__host__ __device__ inline SlotAddr slotAddr(const RenderParams& rp, uint32_t slot) {
+    const uint32_t lane = slot & 255u;
+    SlotAddr a;
+    a.localPix = (lane * rp.stripesRecip) >> 16;
+    a.stripe = lane - a.localPix * rp.stripes;
+    a.pix = (slot >> 8) * rp.pixelsPerBlock + a.localPix;
+    a.valid = a.localPix < rp.pixelsPerBlock && a.pix < rp.numPixels;
+    return a;
+}
+__host__ __device__ inline uint32_t slotOf(const RenderParams& rp, uint32_t pix, uint32_t stripe) {
+    const uint32_t b = pix / rp.pixelsPerBlock;
+    return b * 256u + (pix - b * rp.pixelsPerBlock) * rp.stripes + stripe;
+}
+
 // Evaluated by every workgroup of the traversal launch of an iteration: its input is stable during that launch (activeSlots
-// is written by k_regen only), so all workgroups agree; the first one records the decision for the kernels that follow.
+// is written by k_shade only), so all workgroups agree; the first one records the decision for the kernels that follow.
 __device__ __forceinline__ bool tailModeBegins(const PathBuffers& pb, uint32_t tailSlots, uint32_t parity) {
     if (tailSlots == 0u) return false;
     if (pb.tailMode[0]) return true;
@@ -158,32 +180,20 @@ __device__ __forceinline__ bool tailModeBegins(const PathBuffers& pb, uint32_t t
 }
 
 void launchResetSlots(const PathBuffers& pb, const RenderParams& rp, bool clearAccumulators, hipStream_t stream);
-void launchRegen(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, hipStream_t stream);
-void launchTraceClosest(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, uint32_t blocks, bool count,
-                        hipStream_t stream);
-void launchTraceShadow(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, uint32_t blocks, bool count,
-                       hipStream_t stream);
-void launchLogic(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, hipStream_t stream);
+// one wavefront iteration = launchShade(parity) then launchTraceWs(parity)
+void launchShade(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, hipStream_t stream);
 void launchCountSamples(const PathBuffers& pb, const RenderParams& rp, hipStream_t stream);
 // the rest of a render call in one launch (after tailMode was raised): list the live slots, then one lane per path to its end
-void launchTail(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t liveSlots, uint32_t parity, int numCUs, hipStream_t stream);
+void launchTail(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t liveSlots, int numCUs, hipStream_t stream);
 bool tailKernelAvailable(const DevScene& sc, bool spectral);      // not built for spectral scenes with MultiBSDF materials or textures
 void launchResolve(const PathBuffers& pb, const RenderParams& rp, float* dst, hipStream_t stream);
 void launchBsdfQueries(const DevScene& sc, bool spectral, uint32_t material, uint32_t n, const float* in, float wlOffset, uint32_t wl,
                        float4* geo, float4* misc, float4* fsSample, float4* fsEval, hipStream_t stream);
+// closest-hit ray queries (slrhip_trace_rays): one lane per ray, 64-ray batches (pt_trace.hip)
 void launchTraceBatch(const DevScene& sc, const float4* org, const float4* dir, float4* out, uint32_t n, hipStream_t stream);
-int traceBlocksPerCU();
-// four lanes per ray (pt_trace_quad.hip): the lane-mapping experiment; layouts built from the uploaded tree
-void buildQuadLayouts(const std::vector<QNode>& nodes, const std::vector<LeafTri>& leafTris, std::vector<float4>* nodes4, std::vector<float4>* packets);
-void launchTraceQuad(const DevScene& sc, const float4* nodes4, const float4* packets, const float4* org, const float4* dir, float4* out, uint32_t n, hipStream_t stream);
-// wave-specialised traversal (pt_trace_ws.hip): same results, ONE launch for the extension and the shadow rays of an iteration
+// wave-specialised traversal (pt_trace_ws.hip): ONE launch for the extension and the shadow rays of an iteration
 void launchTraceWs(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, uint32_t blocks, bool count,
                    hipStream_t stream);
 int traceWsBlocksPerCU(bool quantizedTree);
-// pool schedule of the same file (experiment, SLRHIP_TRACE=pool): rays resident in LDS, dense node / triangle phases
-void launchTracePool(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, uint32_t blocks, bool count, uint32_t* spill,
-                     hipStream_t stream);
-int tracePoolBlocksPerCU();
-size_t tracePoolSpillWords(uint32_t blocks);
 
 } // namespace slrhip

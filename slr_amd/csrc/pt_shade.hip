@@ -1,5 +1,5 @@
 // pt_shade.hip — launchers of the shading half of the wavefront path tracer (gfx950, wave64) and the instantiations of its
-// small kernels; the kernel templates are in pt_shade_kernels.h, the k_logic instantiations in pt_shade_{rgb,spec16,specq,multi}.hip.
+// small kernels; the kernel templates are in pt_shade_kernels.h, the k_shade instantiations in pt_shade_{rgb,spec16,multi*,tex*}.hip.
 #include <algorithm>
 
 #include "pt_shade_kernels.h"
@@ -7,36 +7,22 @@
 namespace slrhip {
 
 void launchResetSlots(const PathBuffers& pb, const RenderParams& rp, bool clearAcc, hipStream_t stream) {
-    const dim3 grid((rp.numSlots + kShadeBlock - 1) / kShadeBlock), block(kShadeBlock);
+    const dim3 grid(rp.numSlots / kShadeBlock), block(kShadeBlock);
     if (rp.spectral) hipLaunchKernelGGL(k_reset_slots<Spec16>, grid, block, 0, stream, pb, rp, clearAcc ? 1u : 0u);
     else hipLaunchKernelGGL(k_reset_slots<RGB>, grid, block, 0, stream, pb, rp, clearAcc ? 1u : 0u);
 }
-void launchRegen(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, hipStream_t stream) {
-    // queue lengths are only known on the device: launch for the worst case, surplus workgroups exit at once
-    const dim3 grid(rp.shardCapacity / kShadeBlock * kShards), block(kShadeBlock);
-    if (rp.spectral) hipLaunchKernelGGL(k_regen<Spec16>, grid, block, 0, stream, sc, pb, rp, parity);
-    else hipLaunchKernelGGL(k_regen<RGB>, grid, block, 0, stream, sc, pb, rp, parity);
-}
-void launchLogic(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, hipStream_t stream) {
+void launchShade(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, hipStream_t stream) {
     const bool ldsTables = sc.numMaterials <= (uint32_t)kLdsMaterials && sc.numLights <= (uint32_t)kLdsLights &&
                            (!rp.spectral || (sc.numSpectra <= (uint32_t)kLdsSpectra && sc.numSpectrumData <= (uint32_t)kLdsPoolFloats));
     // The microfacet (GGX) code costs ~45 VGPRs, so scenes without such lobes get kernels without it.
     const bool glossy = sc.hasMicrofacet != 0;
     if (sc.hasMulti || sc.numTextures) {
         // MultiBSDF scenes: one kernel per mode, tables in HBM (a component is re-read per use), all lobes compiled in
-        launchLogicMulti(sc, pb, rp, parity, stream);
+        launchShadeMulti(sc, pb, rp, parity, stream);
         return;
     }
-    if (rp.spectral) {
-        // One lane per slot (Spec16) unless the context asks for four (SpecQ: SLRHIP_FLAG_SPECTRAL_QUAD or SLRHIP_SPECTRAL_LANES=4).
-        // Measured on configs[2] after the LDS sample pool: 1 445 vs 1 487 us per launch — the quarter-size register footprint
-        // (125 vs 187 VGPR) does not pay for replicating the scalar path work four times.
-        static const bool envQuad = [] { const char* e = getenv("SLRHIP_SPECTRAL_LANES"); return e && std::string(e) == "4"; }();
-        if (!envQuad && !rp.spectralQuad) launchLogicSpec16(sc, pb, rp, parity, ldsTables, glossy, stream);
-        else launchLogicSpecQ(sc, pb, rp, parity, ldsTables, glossy, stream);
-        return;
-    }
-    launchLogicRGB(sc, pb, rp, parity, ldsTables, glossy, stream);
+    if (rp.spectral) launchShadeSpec16(sc, pb, rp, parity, ldsTables, glossy, stream);
+    else launchShadeRGB(sc, pb, rp, parity, ldsTables, glossy, stream);
 }
 void launchBsdfQueries(const DevScene& sc, bool spectral, uint32_t material, uint32_t n, const float* in, float wlOffset, uint32_t wl,
                        float4* geo, float4* misc, float4* fsSample, float4* fsEval, hipStream_t stream) {
@@ -44,7 +30,7 @@ void launchBsdfQueries(const DevScene& sc, bool spectral, uint32_t material, uin
     if (spectral) hipLaunchKernelGGL(k_bsdf_queries<Spec16>, grid, block, 0, stream, sc, material, n, in, wlOffset, wl, geo, misc, fsSample, fsEval);
     else hipLaunchKernelGGL(k_bsdf_queries<RGB>, grid, block, 0, stream, sc, material, n, in, wlOffset, wl, geo, misc, fsSample, fsEval);
 }
-// Samples accumulated into pixels by the render call that just ended = sum over the slots of the per-slot count k_regen keeps
+// Samples accumulated into pixels by the render call that just ended = sum over the slots of the per-slot count k_shade keeps
 // in the sample header (hdr.x, restarted by k_reset_slots).  This is the device's own account of the work done: the host's
 // numPixels x spp would be a tautology.  One atomic per workgroup on the sharded totals.
 __global__ __launch_bounds__(kShadeBlock) void k_count_samples(PathBuffers pb, RenderParams rp) {

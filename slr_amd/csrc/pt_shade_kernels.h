@@ -1,23 +1,25 @@
 // pt_shade_kernels.h — kernel templates of the shading half of the wavefront path tracer (gfx950, wave64).
 //
 // One path SLOT per (pixel, sample stripe).  A slot carries one light path at a time through the
-// reference's bounce loop (Renderers/PathTracingRenderer.cpp:137-262).  Per wavefront iteration:
+// reference's bounce loop (Renderers/PathTracingRenderer.cpp:137-262).  One wavefront iteration is two launches:
 //
-//   k_regen          finished slots (compacted queue): add weight*C to the slot's pixel accumulator in
-//                    pass order — the Kahan sum of RGBStorage::add (RGBTypes.h:176-179), so the
-//                    framebuffer needs no atomics — then start the next sample of the same pixel:
-//                    Job::kernel's camera-ray half (PathTracingRenderer.cpp:100-120).
-//   k_trace_ws       every slot with a ray in flight (state flag) + the shadow-ray queue, one launch (pt_trace_ws.hip;
-//                    or the two batch kernels of pt_trace.hip)
-//   k_logic          every live slot: resolve the pending next-event estimate, shade the hit
-//                    (getSurfacePoint, emission + MIS, Russian roulette), then the next bounce: light
-//                    sampling + BSDF sampling (:161-221).  Emits the next extension ray in place, a shadow ray
-//                    (slot index into the shadow queue) and/or the slot index into the regen queue.
+//   k_shade          every live slot: resolve the pending next-event estimate, shade the hit (getSurfacePoint, emission +
+//                    MIS, Russian roulette), then the next bounce: light sampling + BSDF sampling (:161-221); emits the next
+//                    extension ray in place and a shadow ray (slot index into the shadow queue).  A slot whose path ENDS
+//                    here is finished in the same launch: weight * C is Kahan-added to the slot's pixel accumulator in pass
+//                    order (RGBStorage::add, RGBTypes.h:176-179 — the framebuffer lives in the slot, no atomics), the
+//                    pixel's sample pool hands it its next pass (LDS mask + barrier: the stripes of a pixel share the
+//                    workgroup), and the new samples of the workgroup are started by its FIRST lanes, compacted
+//                    (Job::kernel's camera half, :100-120: the 50-draw stream seeding runs on full waves).
+//   k_trace_ws       every slot with a ray in flight (state flag) + the shadow-ray queue, one launch (pt_trace_ws.hip)
 //
-// Queues are slot-index lists in HBM, 16 regions (one per blockIdx % 16), filled by wave ballot + popcount prefix with ONE
-// atomic per workgroup per queue on a counter that has its own 128-byte line (per-wave atomics on one word were the
-// bottleneck of the first version).  All path state is SoA in 16-byte records so a wave's loads are 1 KiB bursts; the state
-// loads of k_logic are issued together at the top, and the material / light / spectrum tables live in LDS.
+// (Rounds 1-2 ran the restart as a third kernel, k_regen, over a queue of finished slots: a second pass over the state of
+// a fifth of the slots, every 16-byte record costing a 32-byte sector, plus the hand-over of flags, radiance sum and queue
+// entry through HBM — 24 % of an iteration.  DESIGN.md has the before / after.)
+//
+// The shadow queue is a slot-index list in HBM, 16 regions (one per blockIdx % 16), filled by wave ballot + popcount prefix
+// with ONE atomic per workgroup on a counter that has its own 128-byte line.  All path state is SoA in 16-byte records so a
+// wave's loads are 1 KiB bursts; the state loads are issued together at the top, the material / light / spectrum tables live in LDS.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
@@ -33,7 +35,7 @@ namespace slrhip {
 
 enum : uint32_t {
     ST_IDLE = 0,            // no more samples for this slot
-    ST_REGEN = 1,           // in the regen queue: accumulate (if a path just ended) and start the next sample
+    ST_REGEN = 1,           // start the next sample: every slot after k_reset_slots; in the tail kernel also "a path just ended" (bit 15)
     ST_FIRST_HIT = 2,       // camera ray in flight        (PathTracingRenderer.cpp:147)
     ST_NEXT_HIT = 3,        // BSDF-sampled ray in flight  (:225)
     ST_FINISH = 4           // path ended while a shadow ray was still pending
@@ -86,19 +88,6 @@ template <> struct SpecIO<Spec16> {
     }
 };
 
-template <> struct SpecIO<SpecQ> {
-    // lane q of the quad moves plane q (components 4q .. 4q+3); the scalar is read by all four lanes and written by lane 0
-    static __device__ __forceinline__ void load(const float4* a, const float* scalars, uint32_t slot, uint32_t n, SpecQ& v, float& w) {
-        const float4 t = a[(size_t)SpecQ::q() * n + slot];
-        v.c[0] = t.x; v.c[1] = t.y; v.c[2] = t.z; v.c[3] = t.w;
-        w = scalars ? scalars[slot] : 0.0f;
-    }
-    static __device__ __forceinline__ void store(float4* a, float* scalars, uint32_t slot, uint32_t n, const SpecQ& v, float w) {
-        a[(size_t)SpecQ::q() * n + slot] = make_float4(v.c[0], v.c[1], v.c[2], v.c[3]);
-        if (scalars && SpecQ::q() == 0) scalars[slot] = w;
-    }
-};
-
 // Material access per mode
 template <class S> struct MatIO;
 template <> struct MatIO<RGB> {
@@ -131,38 +120,30 @@ template <class S> struct MatIOSpectral {
     }
 };
 template <> struct MatIO<Spec16> : MatIOSpectral<Spec16> {};
-template <> struct MatIO<SpecQ> : MatIOSpectral<SpecQ> {};
 
-// Append `slot` to the workgroup's region of up to two queues: wave ballots + popcount prefixes, the four
-// wave counts meet in LDS, ONE atomic per queue per workgroup (on the region's own counter line).
+// Append `slot` to the workgroup's region of the shadow queue: wave ballots + popcount prefixes, the four wave counts meet
+// in LDS, ONE atomic per workgroup (on the region's own counter line).
 struct PushLds {
-    uint32_t count[Q_KINDS][4];
-    uint32_t base[Q_KINDS];
+    uint32_t count[4];
+    uint32_t base;
 };
-__device__ __forceinline__ void blockPush(PushLds& pl, bool emit0, bool emit1, uint32_t slot, uint32_t* queue0, uint32_t* queue1,
-                                          uint32_t* counters /* set being filled */, uint32_t shardCapacity, uint32_t* errorWord) {
+__device__ __forceinline__ void blockPush(PushLds& pl, bool emit, uint32_t slot, uint32_t* queue, uint32_t* counters /* set being filled */,
+                                          uint32_t shardCapacity, uint32_t* errorWord) {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t shard = blockIdx.x % kShards;
-    const uint64_t m0 = __ballot(emit0), m1 = __ballot(emit1);
-    if (lane == 0) { pl.count[0][wave] = (uint32_t)__popcll(m0); pl.count[1][wave] = (uint32_t)__popcll(m1); }
+    const uint64_t m = __ballot(emit);
+    if (lane == 0) pl.count[wave] = (uint32_t)__popcll(m);
     __syncthreads();
-    if (threadIdx.x < Q_KINDS) {
-        const uint32_t q = threadIdx.x;
-        const uint32_t total = pl.count[q][0] + pl.count[q][1] + pl.count[q][2] + pl.count[q][3];
-        pl.base[q] = total ? atomicAdd(&counters[(q * kShards + shard) * kCounterStride], total) : 0u;
-        if (pl.base[q] + total > shardCapacity) atomicOr(errorWord, ERR_QUEUE_OVERFLOW);     // cannot happen: a region holds every slot of its blocks
+    if (threadIdx.x == 0) {
+        const uint32_t total = pl.count[0] + pl.count[1] + pl.count[2] + pl.count[3];
+        pl.base = total ? atomicAdd(&counters[(Q_SHADOW * kShards + shard) * kCounterStride], total) : 0u;
+        if (pl.base + total > shardCapacity) atomicOr(errorWord, ERR_QUEUE_OVERFLOW);     // cannot happen: a region holds every slot of its blocks
     }
     __syncthreads();
-    const uint64_t below = (1ull << lane) - 1ull;
-    if (emit0) {
-        uint32_t off = pl.base[0];
-        for (uint32_t w = 0; w < wave; ++w) off += pl.count[0][w];
-        queue0[(size_t)shard * shardCapacity + off + __popcll(m0 & below)] = slot;
-    }
-    if (emit1) {
-        uint32_t off = pl.base[1];
-        for (uint32_t w = 0; w < wave; ++w) off += pl.count[1][w];
-        queue1[(size_t)shard * shardCapacity + off + __popcll(m1 & below)] = slot;
+    if (emit) {
+        uint32_t off = pl.base;
+        for (uint32_t w = 0; w < wave; ++w) off += pl.count[w];
+        queue[(size_t)shard * shardCapacity + off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = slot;
     }
 }
 
@@ -293,7 +274,6 @@ __device__ __forceinline__ S envEmittanceSpectral(const DevScene& sc, float tcU,
 template <class S> __device__ __forceinline__ S envEmittanceS(const DevScene& sc, float u, float v, float wlOffset);
 template <> __device__ __forceinline__ RGB envEmittanceS<RGB>(const DevScene& sc, float u, float v, float) { return envEmittance(sc, u, v); }
 template <> __device__ __forceinline__ Spec16 envEmittanceS<Spec16>(const DevScene& sc, float u, float v, float o) { return envEmittanceSpectral<Spec16>(sc, u, v, o); }
-template <> __device__ __forceinline__ SpecQ envEmittanceS<SpecQ>(const DevScene& sc, float u, float v, float o) { return envEmittanceSpectral<SpecQ>(sc, u, v, o); }
 // InfiniteSphereSurfaceObject::evaluateAreaPDF, SurfaceObject.cpp:217-222 (RegularConstantContinuous2D::evaluatePDF :218-224)
 __device__ __forceinline__ float envAreaPDF(const DevScene& sc, float phi, float theta) {
     float d0 = (float)((double)phi / (2 * kPi)), d1 = (float)((double)theta / kPi);
@@ -321,6 +301,7 @@ template <> struct SpAcc<RGB> {
     }
     __device__ __forceinline__ void startPath(bool first, uint32_t) { if (first) { r = RGB(); c = RGB(); } }
     __device__ __forceinline__ uint32_t validBits() const { return 1u << 10; }
+    __device__ __forceinline__ RGB total() const { return r; }
     __device__ __forceinline__ void addPendingNee(const PathBuffers&, uint32_t, uint32_t) { kahanAdd(r, c, nee); }
     __device__ __forceinline__ void add(const PathBuffers&, uint32_t, uint32_t, const RGB& v) { kahanAdd(r, c, v); }
     __device__ __forceinline__ void end(const PathBuffers& pb, uint32_t slot, uint32_t n, bool pathContinues) {
@@ -333,6 +314,7 @@ template <> struct SpAcc<Spec16> {
     __device__ __forceinline__ void begin(const PathBuffers&, uint32_t, uint32_t) {}
     __device__ __forceinline__ void startPath(bool first, uint32_t flags) { valid = !first && F_SPVALID(flags); }
     __device__ __forceinline__ uint32_t validBits() const { return valid ? 1u << 10 : 0u; }
+    __device__ __forceinline__ Spec16 total() const { return Spec16(); }      // the sum is in HBM (flag bit 10 says whether it was ever written)
     __device__ __forceinline__ void add(const PathBuffers& pb, uint32_t slot, uint32_t n, const Spec16& v) {
         // plane by plane: 4 components of the Kahan pair in flight at a time
         const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -358,33 +340,6 @@ template <> struct SpAcc<Spec16> {
             pb.spR[((size_t)p * n + slot) * pb.spStride] = r;
             pb.spC[((size_t)p * n + slot) * pb.spStride] = c;
         }
-        valid = true;
-    }
-    __device__ __forceinline__ void end(const PathBuffers&, uint32_t, uint32_t, bool) {}
-};
-
-template <> struct SpAcc<SpecQ> {
-    bool valid;
-    __device__ __forceinline__ void begin(const PathBuffers&, uint32_t, uint32_t) {}
-    __device__ __forceinline__ void startPath(bool first, uint32_t flags) { valid = !first && F_SPVALID(flags); }
-    __device__ __forceinline__ uint32_t validBits() const { return valid ? 1u << 10 : 0u; }
-    __device__ __forceinline__ void add(const PathBuffers& pb, uint32_t slot, uint32_t n, const SpecQ& v) {
-        const size_t i = ((size_t)SpecQ::q() * n + slot) * pb.spStride;
-        float4 r = make_float4(0.0f, 0.0f, 0.0f, 0.0f), c = r;
-        if (valid) { r = pb.spR[i]; c = pb.spC[i]; }
-        kahanAdd(r.x, c.x, v.c[0]); kahanAdd(r.y, c.y, v.c[1]); kahanAdd(r.z, c.z, v.c[2]); kahanAdd(r.w, c.w, v.c[3]);
-        pb.spR[i] = r;
-        pb.spC[i] = c;
-        valid = true;
-    }
-    __device__ __forceinline__ void addPendingNee(const PathBuffers& pb, uint32_t slot, uint32_t n) {
-        const size_t i0 = (size_t)SpecQ::q() * n + slot, i = i0 * pb.spStride;
-        const float4 v = pb.nee[i0];
-        float4 r = make_float4(0.0f, 0.0f, 0.0f, 0.0f), c = r;
-        if (valid) { r = pb.spR[i]; c = pb.spC[i]; }
-        kahanAdd(r.x, c.x, v.x); kahanAdd(r.y, c.y, v.y); kahanAdd(r.z, c.z, v.z); kahanAdd(r.w, c.w, v.w);
-        pb.spR[i] = r;
-        pb.spC[i] = c;
         valid = true;
     }
     __device__ __forceinline__ void end(const PathBuffers&, uint32_t, uint32_t, bool) {}
@@ -442,12 +397,16 @@ __device__ __forceinline__ int32_t texturizeMat(const DevScene& sc, Mat<S>& mm, 
     return mt.w;
 }
 
-// One visit of k_logic to one slot: everything between the state loads and the state stores.  A device function so that the
-// tail kernel (pt_tail_kernels.h) runs the very same code on the last paths of a render call.
-template <class S, bool LDS_TABLES, bool MF, bool MULTI, bool TEX>
+// One visit of the shade kernel to one slot: everything between the state loads and the state stores.  A device function so
+// that the tail kernel (pt_tail_kernels.h) runs the very same code on the last paths of a render call.
+// FUSED (k_shade): a path that ends here is accumulated and restarted by the caller in the same launch — the slot's flags and
+// radiance sum are handed back (`flags`, `radiance`; RGB keeps the sum in registers) instead of being stored.  Not FUSED
+// (k_tail): the slot is left in ST_REGEN with bit 15 set and its sum in HBM, for the lane's next turn.
+template <class S, bool LDS_TABLES, bool MF, bool MULTI, bool TEX, bool FUSED>
 __device__ __forceinline__ void logicSlot(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, const ShadeLds<S::N != 3>& lds,
-                                          const float* lightPMF, const float* lightCDF, uint32_t slot, uint32_t flags, bool leader, uint32_t parity,
+                                          const float* lightPMF, const float* lightCDF, uint32_t slot, uint32_t& flags, S& radiance,
                                           bool& emitExt, bool& emitShadow, bool& emitRegen) {
+    constexpr bool leader = true;
     // ---- all state loads up front: one memory round trip instead of a dependent chain (flags: read above) -----------
     const uint4 r4 = pb.rng[(size_t)slot * pb.hdrStride];
     // The path's radiance sum (Kahan pair) and the pending light sample: RGB keeps them in registers (3 x 16 B,
@@ -757,103 +716,25 @@ __device__ __forceinline__ void logicSlot(const DevScene& sc, const PathBuffers&
         }
 
         // ---- store path state ---------------------------------------------------------------------------
-        if (leader) pb.flags[slot] = flags | sp.validBits();
-        if (emitRegen && leader) {
-            const uint32_t stripe = slot / rp.numPixels;
-            atomicOr(pb.finishedMask + (size_t)(parity ^ 1) * rp.numPixels + (slot - stripe * rp.numPixels), 1ull << stripe);
+        flags |= sp.validBits();
+        if (FUSED && emitRegen) {
+            radiance = sp.total();                 // accumulated by the caller: nothing of this path needs to reach HBM any more
         }
-        sp.end(pb, slot, rp.numSlots, !emitRegen);
+        else {
+            pb.flags[slot] = flags;
+            sp.end(pb, slot, rp.numSlots, !emitRegen);
+        }
         if (!emitRegen) {
-            if (leader) pb.rng[(size_t)slot * pb.hdrStride] = make_uint4(rng.s0, rng.s1, rng.s2, rng.s3);
+            pb.rng[(size_t)slot * pb.hdrStride] = make_uint4(rng.s0, rng.s1, rng.s2, rng.s3);
             SpecIO<S>::store(pb.alpha, pb.pdfPrev, slot, rp.numSlots, alpha, bsdfPDFprev);
         }
-        if (emitExt && leader) {
+        if (emitExt) {
             pb.rayOrg[(size_t)slot * pb.rayStride] = make_float4(rayOrg.x, rayOrg.y, rayOrg.z, rayTmin);
             pb.rayDir[(size_t)slot * pb.rayStride] = make_float4(rayDir.x, rayDir.y, rayDir.z, INFINITY);
         }
     }
 }
 
-template <class S, bool LDS_TABLES, bool MF, bool MULTI = false, bool TEX = false>
-__global__ __launch_bounds__(kShadeBlock)
-__attribute__((amdgpu_waves_per_eu(S::N == 3 ? SLR_WAVES_RGB : (MF ? SLR_WAVES_SPECTRAL_GLOSSY : SLR_WAVES_SPECTRAL)))) void k_logic(DevScene sc, PathBuffers pb, RenderParams rp, uint32_t parity) {
-    __shared__ ShadeLds<S::N != 3> lds;
-    __shared__ PushLds pushLds;
-    // S::LANES adjacent lanes share one slot (SpecQ: 4, each holding a quarter of the spectrum; the per-path scalar work is
-    // replicated, identically, in all of them); the first of them ("leader") writes the scalar state and the queue entries
-    constexpr uint32_t L = S::LANES;
-    const uint32_t slot = (blockIdx.x * kShadeBlock + threadIdx.x) / L;
-    const bool leader = L == 1 || (threadIdx.x & (L - 1)) == 0;
-
-    // ---- the end of a render: nothing left anywhere / nothing left in this block ------------------------------------------
-    if (pb.activeSlots[0] == 0 || pb.tailMode[0]) return;                 // every slot is out of passes / the tail kernel takes over (uniform)
-    const uint32_t deadIdx = (blockIdx.x * kShadeBlock / L) / kShadeBlock;   // 256-slot block of this workgroup's first slot
-    if (pb.blockDead[deadIdx]) return;
-    uint32_t flags = slot < rp.numSlots ? pb.flags[slot] : (uint32_t)ST_IDLE;
-    {
-        const uint32_t st = F_STATE(flags);
-        // the stripe-0 slots of a pixel retire the pixel's sample-pool mask whether or not they have a path themselves
-        const bool poolDuty = blockIdx.x * kShadeBlock / L < rp.numPixels;
-        const int anyPath = __syncthreads_or(st == ST_FIRST_HIT || st == ST_NEXT_HIT || st == ST_FINISH);
-        if (!anyPath && !poolDuty) {
-            // no path to advance here (slots waiting in the regen queue are not this kernel's).  If all of them are idle the
-            // block is finished for the rest of this render call: say so, and the scanning kernels stop reading its state.
-            const int anyBusy = __syncthreads_or(st != ST_IDLE);
-            if (L == 1 && !anyBusy && threadIdx.x == 0) pb.blockDead[deadIdx] = 1u;
-            return;
-        }
-    }
-    if (LDS_TABLES) {
-        if (S::N == 3) {
-            const float4* gm = reinterpret_cast<const float4*>(sc.materials);
-            for (uint32_t i = threadIdx.x; i < sc.numMaterials * 5; i += kShadeBlock) lds.mats[i] = gm[i];
-        }
-        else {
-            const float4* gm = reinterpret_cast<const float4*>(sc.materialsS);
-            const float4* gs = reinterpret_cast<const float4*>(sc.spectra);
-            for (uint32_t i = threadIdx.x; i < sc.numMaterials * 2; i += kShadeBlock) lds.mats[i] = gm[i];
-            for (uint32_t i = threadIdx.x; i < sc.numSpectra * 2; i += kShadeBlock) lds.mats[2 * kLdsMaterials + i] = gs[i];
-            const float4* gp = reinterpret_cast<const float4*>(sc.spectrumPool);
-            for (uint32_t i = threadIdx.x; i < (sc.numSpectrumData + 3) / 4; i += kShadeBlock) lds.mats[2 * kLdsMaterials + 2 * kLdsSpectra + i] = gp[i];
-        }
-        const float4* gl = reinterpret_cast<const float4*>(sc.lightTris);
-        for (uint32_t i = threadIdx.x; i < sc.numLights * 9; i += kShadeBlock) lds.lights[i] = gl[i];
-        if (threadIdx.x < sc.numLights) lds.lightPMF[threadIdx.x] = sc.lightPMF[threadIdx.x];
-        if (threadIdx.x <= sc.numLights) lds.lightCDF[threadIdx.x] = sc.lightCDF[threadIdx.x];
-        __syncthreads();
-    }
-    const float* lightPMF = LDS_TABLES ? lds.lightPMF : sc.lightPMF;
-    const float* lightCDF = LDS_TABLES ? lds.lightCDF : sc.lightCDF;
-
-    bool emitExt = false, emitShadow = false, emitRegen = false;
-    uint32_t* qw = pb.queueCount + (parity ^ 1) * kQueueSetWords;
-
-    // Sample pool housekeeping (PathBuffers::finishedMask): the stripe-0 slot of a pixel retires the mask k_regen has just
-    // consumed — whether or not that slot itself still has a path.
-    if (slot < rp.numPixels && leader) {
-        unsigned long long* done = pb.finishedMask + (size_t)parity * rp.numPixels + slot;
-        const unsigned long long m = *done;
-        if (m) {
-            pb.nextSample[slot] += (uint32_t)__popcll(m);
-            *done = 0ull;
-        }
-    }
-
-    if (slot < rp.numSlots)
-        logicSlot<S, LDS_TABLES, MF, MULTI, TEX>(sc, pb, rp, lds, lightPMF, lightCDF, slot, flags, leader, parity, emitExt, emitShadow, emitRegen);
-
-    // ---- stream compaction of the shadow rays and of the finished slots -----------------------------------------
-    (void)emitExt;     // extension rays need no queue: the traversal kernel reads the state flag
-    blockPush(pushLds, emitShadow && leader, emitRegen && leader, slot, pb.shadowQueue, pb.regenQueue, qw, rp.shardCapacity, pb.errorWord);
-    if (rp.countSlots) {
-        const uint64_t ma = __ballot((emitExt || emitShadow || emitRegen) && leader);
-        if ((threadIdx.x & 63u) == 0 && ma)
-            atomicAdd((unsigned long long*)&pb.totals[totalIndex(T_SLOT_VISITS, blockIdx.x % kShards)], (unsigned long long)__popcll(ma));
-    }
-}
-
-// Finished (or brand-new) slots, dense: sensor->add + the camera-ray half of Job::kernel.
-// Workgroup b serves chunk b / kShards of queue region b % kShards; surplus workgroups exit at once.
 // SpectrumStorage::add.  RGB: the sample is Kahan-added to the pixel (RGBTypes.h:176-179).  Spectral: every component goes
 // to the storage bin of its wavelength scaled by the reciprocal bin width, then the 16-bin addend is Kahan-added
 // (SpectrumTypes.h:818-836).  Bin selection through compare-selects keeps the addend in registers.
@@ -892,10 +773,11 @@ __device__ __forceinline__ Spec16 storageAddend(const Spec16& val, float wlOffse
 }
 
 // Job::kernel's camera half (PathTracingRenderer.cpp:100-120): seeds the sample's stream, draws in source (left-to-right)
-// order and leaves the slot with a camera ray in flight (k_regen; the tail kernel for the passes left when it takes over).
+// order and leaves the slot with a camera ray in flight; writes the slot's sample header (k_shade's compacted start lanes;
+// the tail kernel for the passes left when it takes over).
 template <class S>
 __device__ __forceinline__ void startSample(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t slot, uint32_t pix, uint32_t pass,
-                                            uint4& newHdr) {
+                                            uint32_t samplesDone) {
     // Job::kernel PathTracingRenderer.cpp:100-120, draws in source (left-to-right) order
     const uint32_t xy = pb.pixelXY[pix];
     const uint32_t px = xy & 0xFFFFu, py = xy >> 16;
@@ -936,20 +818,24 @@ __device__ __forceinline__ void startSample(const DevScene& sc, const PathBuffer
     pb.flags[slot] = F_MAKE((uint32_t)ST_FIRST_HIT, 0u, wl, 0u, 0u, 0u);
     pb.rng[(size_t)slot * pb.hdrStride] = make_uint4(rng.s0, rng.s1, rng.s2, rng.s3);
     // alpha = 1, pdfPrev = 0 and sp = 0 are implied by ST_FIRST_HIT (see SpAcc): 48 B (RGB) / 196 B (spectral) not written
-    newHdr.y = __float_as_uint(camWeight);
-    newHdr.z = __float_as_uint(wlOffset);
+    pb.hdr[(size_t)slot * pb.hdrStride] = make_uint4(samplesDone, __float_as_uint(camWeight), __float_as_uint(wlOffset), 0u);
     pb.rayOrg[(size_t)slot * pb.rayStride] = make_float4(lensP.x, lensP.y, lensP.z, 0.0f);
     pb.rayDir[(size_t)slot * pb.rayStride] = make_float4(rayDir.x, rayDir.y, rayDir.z, INFINITY);
 }
 
 // sensor->add(p.x, p.y, wls, weight * C)  PathTracingRenderer.cpp:126-130: the finished path's radiance sum, times the camera
-// weight of its sample, Kahan-added to the slot's pixel accumulator (k_regen; the tail kernel for the last paths of a call).
+// weight of its sample, Kahan-added to the slot's pixel accumulator.  `inRegisters`: C is handed over by the caller (RGB in
+// k_shade); else it is read from the slot's radiance sum in HBM, if the path ever wrote it (flag bit 10).
 template <class S>
-__device__ __forceinline__ void accumulateSample(const PathBuffers& pb, const RenderParams& rp, uint32_t slot, uint32_t flags, const uint4& hdr) {
-    S C, accR, accC;
+__device__ __forceinline__ void accumulateSample(const PathBuffers& pb, const RenderParams& rp, uint32_t slot, uint32_t flags, const uint4& hdr,
+                                                 bool inRegisters, S C) {
+    S accR, accC;
     float unusedW;
     const float camW = __uint_as_float(hdr.y);
-    if (F_SPVALID(flags)) SpecIO<S>::load(pb.spR, nullptr, slot * pb.spStride, rp.numSlots * pb.spStride, C, unusedW);     // else the path gathered nothing: C = 0
+    if (!inRegisters) {
+        C = S();
+        if (F_SPVALID(flags)) SpecIO<S>::load(pb.spR, nullptr, slot * pb.spStride, rp.numSlots * pb.spStride, C, unusedW);     // else the path gathered nothing: C = 0
+    }
     // accR / accC interleave (pb.accC = pb.accR + 1, element stride 2): the pair is one 32-byte sector per slot
     SpecIO<S>::load(pb.accR, nullptr, 2 * slot, 2 * rp.numSlots, accR, unusedW);
     SpecIO<S>::load(pb.accC, nullptr, 2 * slot, 2 * rp.numSlots, accC, unusedW);
@@ -959,87 +845,152 @@ __device__ __forceinline__ void accumulateSample(const PathBuffers& pb, const Re
     SpecIO<S>::store(pb.accC, nullptr, 2 * slot, 2 * rp.numSlots, accC, 0.0f);
 }
 
-template <class S>
-__global__ __launch_bounds__(kShadeBlock) void k_regen(DevScene sc, PathBuffers pb, RenderParams rp, uint32_t parity) {
-    if (pb.activeSlots[0] == 0 || pb.tailMode[0]) return;      // every slot is out of passes / the tail kernel takes over: the remaining launches of this block of iterations are no-ops
-    const uint32_t shard = blockIdx.x % kShards;
-    const uint32_t n = pb.queueCount[queueCounterIndex(parity, Q_REGEN, shard)];
-    const uint32_t i = (blockIdx.x / kShards) * kShadeBlock + threadIdx.x;
-    if ((blockIdx.x / kShards) * kShadeBlock >= n) return;
-    bool becameIdle = false;
-    uint32_t slot = 0;
-    if (i < n) {
-        slot = pb.regenQueue[(size_t)shard * rp.shardCapacity + i];
-        const uint32_t flags = pb.flags[slot];
-        const uint4 hdr = pb.hdr[(size_t)slot * pb.hdrStride];
-        uint32_t sampleIdx = hdr.x;
-        if (F_HASPATH(flags)) {
-            accumulateSample<S>(pb, rp, slot, flags, hdr);
-            ++sampleIdx;
+// What the finishing lanes of a k_shade workgroup hand to its first lanes: the samples to start.
+struct StartLds {
+    unsigned long long poolMask[kShadeBlock];   // per pixel of the workgroup: stripes whose path ended in this launch
+    uint32_t lane[kShadeBlock];                 // compacted: slot = workgroup base + lane
+    uint32_t pass[kShadeBlock];
+    uint32_t samplesDone[kShadeBlock];
+    uint32_t waveBase[kShadeBlock / 64 + 1];
+};
+
+#ifndef SLR_STATIC_PASSES
+#define SLR_STATIC_PASSES 0        // 1 (variant builds): no sample pool, stripe s renders the passes s, s + K, s + 2K, ...
+#endif
+
+template <class S, bool LDS_TABLES, bool MF, bool MULTI = false, bool TEX = false>
+__global__ __launch_bounds__(kShadeBlock)
+__attribute__((amdgpu_waves_per_eu(S::N == 3 ? SLR_WAVES_RGB : (MF ? SLR_WAVES_SPECTRAL_GLOSSY : SLR_WAVES_SPECTRAL)))) void k_shade(DevScene sc, PathBuffers pb, RenderParams rp, uint32_t parity) {
+    __shared__ ShadeLds<S::N != 3> lds;
+    __shared__ PushLds pushLds;
+    __shared__ StartLds start;
+    const uint32_t slot = blockIdx.x * kShadeBlock + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+
+    // ---- the end of a render: nothing left anywhere / nothing left in this block ------------------------------------------
+    if (pb.activeSlots[0] == 0 || pb.tailMode[0]) return;                 // every slot is out of passes / the tail kernel takes over (uniform)
+    if (pb.blockDead[blockIdx.x]) return;
+    uint32_t flags = pb.flags[slot];                                      // numSlots = 256 x workgroups: always in range
+    const uint32_t state0 = F_STATE(flags);
+    {
+        const int anyWork = __syncthreads_or(state0 != ST_IDLE);
+        if (!anyWork) {
+            // every slot here has run out of passes (a slot never leaves ST_IDLE within a render call): the block is finished
+            // for the rest of this call; say so, and the scanning kernels stop reading its state
+            if (threadIdx.x == 0) pb.blockDead[blockIdx.x] = 1u;
+            return;
         }
-        const uint32_t stripe = slot / rp.numPixels;
-        const uint32_t pix = slot - stripe * rp.numPixels;
-        // the first sample of a stripe is its own index; later ones come from the pixel's pool in stripe order
-        uint32_t pass = rp.sppBegin + stripe;
-        if (F_HASPATH(flags)) {
-            const unsigned long long m = pb.finishedMask[(size_t)parity * rp.numPixels + pix];
-            pass = rp.sppBegin + pb.nextSample[pix] + (uint32_t)__popcll(m & ((1ull << stripe) - 1ull));
-        }
-        uint4 newHdr = make_uint4(sampleIdx, 0u, 0u, 0u);
-        if (pass >= rp.sppBegin + rp.sppCount) {
-            pb.flags[slot] = F_MAKE((uint32_t)ST_IDLE, 0u, 0u, 0u, 0u, 0u);
-            becameIdle = true;
+    }
+    const SlotAddr at = slotAddr(rp, slot);
+    const uint32_t nextOfPixel = at.valid ? pb.nextSample[at.pix] : 0u;   // read by every stripe of the pixel before the barrier below, advanced after it
+    start.poolMask[threadIdx.x] = 0ull;
+    if (threadIdx.x == 0) start.waveBase[kShadeBlock / 64] = 0u;
+    if (LDS_TABLES) {
+        if (S::N == 3) {
+            const float4* gm = reinterpret_cast<const float4*>(sc.materials);
+            for (uint32_t i = threadIdx.x; i < sc.numMaterials * 5; i += kShadeBlock) lds.mats[i] = gm[i];
         }
         else {
-            startSample<S>(sc, pb, rp, slot, pix, pass, newHdr);
+            const float4* gm = reinterpret_cast<const float4*>(sc.materialsS);
+            const float4* gs = reinterpret_cast<const float4*>(sc.spectra);
+            for (uint32_t i = threadIdx.x; i < sc.numMaterials * 2; i += kShadeBlock) lds.mats[i] = gm[i];
+            for (uint32_t i = threadIdx.x; i < sc.numSpectra * 2; i += kShadeBlock) lds.mats[2 * kLdsMaterials + i] = gs[i];
+            const float4* gp = reinterpret_cast<const float4*>(sc.spectrumPool);
+            for (uint32_t i = threadIdx.x; i < (sc.numSpectrumData + 3) / 4; i += kShadeBlock) lds.mats[2 * kLdsMaterials + 2 * kLdsSpectra + i] = gp[i];
         }
-        pb.hdr[(size_t)slot * pb.hdrStride] = newHdr;
+        const float4* gl = reinterpret_cast<const float4*>(sc.lightTris);
+        for (uint32_t i = threadIdx.x; i < sc.numLights * 9; i += kShadeBlock) lds.lights[i] = gl[i];
+        if (threadIdx.x < sc.numLights) lds.lightPMF[threadIdx.x] = sc.lightPMF[threadIdx.x];
+        if (threadIdx.x <= sc.numLights) lds.lightCDF[threadIdx.x] = sc.lightCDF[threadIdx.x];
     }
-    // slots run out of samples only at the very end of a render() call, so this atomic is rare
+    __syncthreads();
+    const float* lightPMF = LDS_TABLES ? lds.lightPMF : sc.lightPMF;
+    const float* lightCDF = LDS_TABLES ? lds.lightCDF : sc.lightCDF;
+
+    bool emitExt = false, emitShadow = false, pathEnded = false;
+    S radiance;
+    if (state0 == ST_FIRST_HIT || state0 == ST_NEXT_HIT || state0 == ST_FINISH)
+        logicSlot<S, LDS_TABLES, MF, MULTI, TEX, true>(sc, pb, rp, lds, lightPMF, lightCDF, slot, flags, radiance, emitExt, emitShadow, pathEnded);
+
+    // ---- a path that ended: sensor->add, in the same launch --------------------------------------------------------------------
+    uint32_t samplesDone = 0;
+    if (pathEnded) {
+        const uint4 hdr = pb.hdr[(size_t)slot * pb.hdrStride];
+        accumulateSample<S>(pb, rp, slot, flags, hdr, S::N == 3, radiance);
+        samplesDone = hdr.x + 1u;
+        if (!SLR_STATIC_PASSES) atomicOr(&start.poolMask[at.localPix], 1ull << at.stripe);
+    }
+    // ---- stream compaction of the shadow rays (extension rays need no queue: the traversal kernel reads the state flag) ----------
+    blockPush(pushLds, emitShadow, slot, pb.shadowQueue, pb.queueCount + parity * kQueueSetWords, rp.shardCapacity, pb.errorWord);      // two barriers: the pool masks are complete
+    if (rp.countSlots) {
+        const uint64_t ma = __ballot(emitExt || emitShadow || pathEnded);
+        if (lane == 0 && ma) atomicAdd((unsigned long long*)&pb.totals[totalIndex(T_SLOT_VISITS, blockIdx.x % kShards)], (unsigned long long)__popcll(ma));
+    }
+
+    // ---- the next pass of every slot that needs one: the first sample of a stripe is its own index (ST_REGEN after
+    //      k_reset_slots), later ones come from the pixel's pool in stripe order ----------------------------------------------------
+    const bool wantsPass = pathEnded || (state0 == ST_REGEN && at.valid);
+    uint32_t pass = at.stripe;
+    if (pathEnded) {
+        if (SLR_STATIC_PASSES) pass = at.stripe + rp.stripes * samplesDone;
+        else {
+            const unsigned long long m = start.poolMask[at.localPix];
+            pass = nextOfPixel + (uint32_t)__popcll(m & ((1ull << at.stripe) - 1ull));
+            if ((m & ((1ull << at.stripe) - 1ull)) == 0ull) pb.nextSample[at.pix] = nextOfPixel + (uint32_t)__popcll(m);      // the lowest finishing stripe advances the pool
+        }
+    }
+    const bool starts = wantsPass && pass < rp.sppCount;
+    const bool becameIdle = wantsPass && !starts;
+    if (becameIdle) {
+        pb.flags[slot] = F_MAKE((uint32_t)ST_IDLE, 0u, 0u, 0u, 0u, 0u);
+        pb.hdr[(size_t)slot * pb.hdrStride] = make_uint4(samplesDone, 0u, 0u, 0u);
+    }
+    {
+        // compaction of the samples to start over the workgroup: wave counts in LDS, then lanes 0 .. n-1 run startSample,
+        // so that the 50-draw seeding of the stream (the seeding contract, ~400 integer operations) and the camera
+        // arithmetic run on full waves instead of on the fifth of the lanes whose path has just ended
+        const uint64_t ms = __ballot(starts);
+        if (lane == 0) start.waveBase[wave] = (uint32_t)__popcll(ms);
+        __syncthreads();
+        uint32_t base = 0;
+        for (uint32_t w = 0; w < wave; ++w) base += start.waveBase[w];
+        if (starts) {
+            const uint32_t i = base + (uint32_t)__popcll(ms & ((1ull << lane) - 1ull));
+            start.lane[i] = threadIdx.x;
+            start.pass[i] = pass;
+            start.samplesDone[i] = samplesDone;
+        }
+        __syncthreads();
+        const uint32_t n = start.waveBase[0] + start.waveBase[1] + start.waveBase[2] + start.waveBase[3];
+        if (threadIdx.x < n) {
+            const uint32_t s2 = blockIdx.x * kShadeBlock + start.lane[threadIdx.x];
+            startSample<S>(sc, pb, rp, s2, slotAddr(rp, s2).pix, rp.sppBegin + start.pass[threadIdx.x], start.samplesDone[threadIdx.x]);
+        }
+    }
+    // slots run out of passes only at the very end of a render() call, so this atomic is rare
     const uint64_t mi = __ballot(becameIdle);
-    if ((threadIdx.x & 63u) == 0 && mi) atomicAdd(&pb.activeSlots[0], (uint32_t)(0u - (uint32_t)__popcll(mi)));
+    if (lane == 0 && mi) atomicAdd(&pb.activeSlots[0], (uint32_t)(0u - (uint32_t)__popcll(mi)));
 }
 
-// Start of a render() call: every slot of the shard enters the regen queue with sample counter 0
+// Start of a render() call: every slot of the shard is set to start its first sample with sample counter 0
 // (accumulators are kept unless asked: render() continues the image begun by render_begin()).
 template <class S>
 __global__ void k_reset_slots(PathBuffers pb, RenderParams rp, uint32_t clearAccumulators) {
-    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;     // blockDim == kShadeBlock
-    if (slot < rp.numSlots) {
-        pb.flags[slot] = F_MAKE((uint32_t)ST_REGEN, 0u, 0u, 0u, 0u, 0u);
-        pb.hdr[(size_t)slot * pb.hdrStride] = make_uint4(0u, 0u, 0u, 0u);
-        if (slot < rp.numPixels) {
-            pb.nextSample[slot] = rp.stripes;
-            pb.finishedMask[slot] = 0ull;
-            pb.finishedMask[(size_t)rp.numPixels + slot] = 0ull;
-        }
-        pb.visible[slot] = 0;
-        if (threadIdx.x == 0) pb.blockDead[blockIdx.x] = 0u;
-        // slot block b goes to region b % kShards at chunk b / kShards, exactly as k_logic would append it
-        pb.regenQueue[(size_t)(blockIdx.x % kShards) * rp.shardCapacity + (blockIdx.x / kShards) * kShadeBlock + threadIdx.x] = slot;
-        if (clearAccumulators) {
-            SpecIO<S>::store(pb.accR, nullptr, 2 * slot, 2 * rp.numSlots, S(), 0.0f);
-            SpecIO<S>::store(pb.accC, nullptr, 2 * slot, 2 * rp.numSlots, S(), 0.0f);
-        }
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;     // blockDim == kShadeBlock, numSlots = 256 x gridDim
+    const SlotAddr at = slotAddr(rp, slot);
+    pb.flags[slot] = F_MAKE((uint32_t)(at.valid ? ST_REGEN : ST_IDLE), 0u, 0u, 0u, 0u, 0u);
+    pb.hdr[(size_t)slot * pb.hdrStride] = make_uint4(0u, 0u, 0u, 0u);
+    if (at.valid && at.stripe == 0) pb.nextSample[at.pix] = rp.stripes;
+    pb.visible[slot] = 0;
+    if (threadIdx.x == 0) pb.blockDead[blockIdx.x] = 0u;
+    if (clearAccumulators) {
+        SpecIO<S>::store(pb.accR, nullptr, 2 * slot, 2 * rp.numSlots, S(), 0.0f);
+        SpecIO<S>::store(pb.accC, nullptr, 2 * slot, 2 * rp.numSlots, S(), 0.0f);
     }
     if (blockIdx.x == 0) {
         for (uint32_t k = threadIdx.x; k < 2 * kQueueSetWords; k += blockDim.x) pb.queueCount[k] = 0;
-        __syncthreads();
-        if (threadIdx.x < kShards) {
-            // entries of region r: full blocks r, r + kShards, ... ; the last block of the grid may be partial
-            const uint32_t numBlocks = (rp.numSlots + kShadeBlock - 1) / kShadeBlock;
-            const uint32_t r = threadIdx.x;
-            uint32_t cnt = 0;
-            if (r < numBlocks) {
-                const uint32_t blocksInRegion = (numBlocks - 1 - r) / kShards + 1;
-                cnt = blocksInRegion * kShadeBlock;
-                const uint32_t lastBlock = numBlocks - 1;
-                if (lastBlock % kShards == r) cnt -= numBlocks * kShadeBlock - rp.numSlots;
-            }
-            pb.queueCount[queueCounterIndex(0, Q_REGEN, r)] = cnt;
-        }
         if (threadIdx.x == 0) {
-            pb.activeSlots[0] = rp.numSlots; pb.errorWord[0] = rp.injectError ? ERR_QUEUE_OVERFLOW : 0u;
+            pb.activeSlots[0] = rp.numPixels * rp.stripes; pb.errorWord[0] = rp.injectError ? ERR_QUEUE_OVERFLOW : 0u;
             pb.tailMode[0] = 0u; pb.tailWords[0] = 0u; pb.tailWords[1] = 0u;
         }
     }
@@ -1052,12 +1003,13 @@ __global__ void k_resolve(PathBuffers pb, RenderParams rp, float* dst) {
     if (pix >= rp.numPixels) return;
     const uint32_t xy = pb.pixelXY[pix];
     const uint32_t px = xy & 0xFFFFu, py = xy >> 16;
+    const uint32_t first = slotOf(rp, pix, 0u);
     S sum;
     float unusedW;
-    SpecIO<S>::load(pb.accR, nullptr, 2 * pix, 2 * rp.numSlots, sum, unusedW);
+    SpecIO<S>::load(pb.accR, nullptr, 2 * first, 2 * rp.numSlots, sum, unusedW);
     for (uint32_t st = 1; st < rp.stripes; ++st) {
         S b;
-        SpecIO<S>::load(pb.accR, nullptr, 2 * (st * rp.numPixels + pix), 2 * rp.numSlots, b, unusedW);
+        SpecIO<S>::load(pb.accR, nullptr, 2 * (first + st), 2 * rp.numSlots, b, unusedW);
         sum = sum + b;
     }
     float* o = dst + ((size_t)py * rp.imageWidth + px) * S::N;
@@ -1105,12 +1057,11 @@ __global__ void __launch_bounds__(64) k_bsdf_queries(DevScene sc, uint32_t mater
     SpecIO<S>::store(fsEval, nullptr, i, n, fe, 0.0f);
 }
 
-// k_logic is instantiated in four translation units (pt_shade_rgb / _spec16 / _specq / _multi.hip) so that the build
-// parallelises; launchLogic (pt_shade.hip) picks one.  `lds`: material / light / spectrum tables staged in LDS;
+// k_shade is instantiated in several translation units (pt_shade_{rgb,spec16,multi_*,tex_*}.hip) so that the build
+// parallelises; launchShade (pt_shade.hip) picks one.  `lds`: material / light / spectrum tables staged in LDS;
 // `glossy`: GGX / Ward / Ashikhmin lobes compiled in.
-void launchLogicRGB(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, bool lds, bool glossy, hipStream_t stream);
-void launchLogicSpec16(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, bool lds, bool glossy, hipStream_t stream);
-void launchLogicSpecQ(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, bool lds, bool glossy, hipStream_t stream);
-void launchLogicMulti(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, hipStream_t stream);
+void launchShadeRGB(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, bool lds, bool glossy, hipStream_t stream);
+void launchShadeSpec16(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, bool lds, bool glossy, hipStream_t stream);
+void launchShadeMulti(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, hipStream_t stream);
 
 } // namespace slrhip

@@ -1,11 +1,11 @@
-// pt_shade_multi_spec.hip — one k_logic instantiation (see pt_shade_kernels.h); one per file: each takes a minute or more to compile
+// pt_shade_multi_spec.hip — one k_shade instantiation (see pt_shade_kernels.h); one per file: each takes a minute or more to compile
 #include "pt_shade_kernels.h"
 
 namespace slrhip {
 
-void launchLogicMultiSpec(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, hipStream_t stream) {
-    const dim3 grid((rp.numSlots + kShadeBlock - 1) / kShadeBlock), block(kShadeBlock);
-    hipLaunchKernelGGL((k_logic<Spec16, false, true, true>), grid, block, 0, stream, sc, pb, rp, parity);
+void launchShadeMultiSpec(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, hipStream_t stream) {
+    const dim3 grid(rp.numSlots / kShadeBlock), block(kShadeBlock);
+    hipLaunchKernelGGL((k_shade<Spec16, false, true, true>), grid, block, 0, stream, sc, pb, rp, parity);
 }
 
 } // namespace slrhip

@@ -1,28 +1,18 @@
-// pt_tail.hip — launcher of the tail kernel (pt_tail_kernels.h): picks the instantiation that matches the k_logic variant of the
-// scene (launchLogic, pt_shade.hip); the instantiations are in pt_tail_{rgb,spec16}.hip and pt_tail_{multi,tex}_rgb.hip.
+// pt_tail.hip — launcher of the tail kernel (pt_tail_kernels.h): picks the instantiation that matches the k_shade variant of the
+// scene (launchShade, pt_shade.hip); the instantiations are in pt_tail_{rgb,spec16}.hip and pt_tail_{multi,tex}_rgb.hip.
 #include <algorithm>
 
 #include "pt_tail_kernels.h"
 
 namespace slrhip {
 
-// Live slots -> pb.regenQueue used as one flat list (the queues are dead in tail mode; capacity kShards x shardCapacity >= numSlots).
-// The stripe-0 slots also retire their pixel's sample-pool mask of queue set `parity`: the k_regen of the iteration in which
-// the tail took over has handed those passes out, the k_logic that would have advanced the counter no longer runs.
-__global__ __launch_bounds__(kShadeBlock) void k_tail_collect(PathBuffers pb, RenderParams rp, uint32_t parity) {
+// Live slots -> pb.tailList (numSlots entries).
+__global__ __launch_bounds__(kShadeBlock) void k_tail_collect(PathBuffers pb, RenderParams rp) {
     __shared__ uint32_t waveCount[kShadeBlock / 64];
     __shared__ uint32_t base;
-    if (pb.blockDead[blockIdx.x]) return;             // never set for a block that holds stripe-0 slots
+    if (pb.blockDead[blockIdx.x]) return;
     const uint32_t slot = blockIdx.x * kShadeBlock + threadIdx.x;
-    if (slot < rp.numPixels) {
-        unsigned long long* done = pb.finishedMask + (size_t)parity * rp.numPixels + slot;
-        const unsigned long long m = *done;
-        if (m) {
-            pb.nextSample[slot] += (uint32_t)__popcll(m);
-            *done = 0ull;
-        }
-    }
-    const bool live = slot < rp.numSlots && F_STATE(pb.flags[slot]) != ST_IDLE;
+    const bool live = F_STATE(pb.flags[slot]) != ST_IDLE;
     const uint64_t m = __ballot(live);
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     if (lane == 0) waveCount[wave] = (uint32_t)__popcll(m);
@@ -35,7 +25,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_tail_collect(PathBuffers pb, Re
     if (live) {
         uint32_t off = base;
         for (uint32_t w = 0; w < wave; ++w) off += waveCount[w];
-        pb.regenQueue[off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = slot;
+        pb.tailList[off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = slot;
     }
 }
 
@@ -46,9 +36,9 @@ void launchTailTexRGB(const DevScene& sc, const PathBuffers& pb, const RenderPar
 
 bool tailKernelAvailable(const DevScene& sc, bool spectral) { return !(spectral && (sc.hasMulti || sc.numTextures)); }
 
-void launchTail(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t liveSlots, uint32_t parity, int numCUs, hipStream_t stream) {
+void launchTail(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t liveSlots, int numCUs, hipStream_t stream) {
     if (rp.numSlots == 0 || liveSlots == 0) return;
-    hipLaunchKernelGGL(k_tail_collect, dim3((rp.numSlots + kShadeBlock - 1) / kShadeBlock), dim3(kShadeBlock), 0, stream, pb, rp, parity);
+    hipLaunchKernelGGL(k_tail_collect, dim3(rp.numSlots / kShadeBlock), dim3(kShadeBlock), 0, stream, pb, rp);
     // one lane per listed slot; lanes take further slots from the list when theirs goes idle, so a grid smaller than the list is fine
     const uint32_t blocks = std::min<uint32_t>((liveSlots + kShadeBlock - 1) / kShadeBlock, (uint32_t)numCUs * 4u);
     const bool ldsTables = sc.numMaterials <= (uint32_t)kLdsMaterials && sc.numLights <= (uint32_t)kLdsLights &&

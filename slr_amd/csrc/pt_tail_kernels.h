@@ -7,12 +7,12 @@
 // 11 of 56 ms at the N = 8 shard size.
 //
 // What: once at most RenderParams::tailSlots slots are live the wavefront stops (PathBuffers::tailMode) and
-//   k_tail_collect  retires the sample-pool masks the last k_regen consumed and lists the live slots (one atomic per workgroup);
+//   k_tail_collect  lists the live slots (one atomic per workgroup);
 //   k_tail          gives every lane one listed slot and runs it until the slot has nothing left to do: per bounce the extension
 //                   ray and the pending shadow ray through the one-lane-per-ray traversal of pt_traverse.h, then logicSlot —
-//                   the very function k_logic calls; when the path ends, accumulateSample and, if the pixel has passes left,
-//                   startSample — the two halves of k_regen.  A lane whose slot went idle takes the next listed one (one
-//                   atomic per wave and refill).
+//                   the very function k_shade calls; when the path ends, accumulateSample and, if the pixel has passes left,
+//                   startSample — what k_shade does for a finished path.  A lane whose slot went idle takes the next listed
+//                   one (one atomic per wave and refill).
 // Passes in the tail: a slot goes idle only when its pixel has run out of passes, so a pixel that still has some has all its K
 // stripes alive; stripe s takes the passes next + s, next + s + K, ... of its pixel (next = the pixel's counter when the tail
 // took over).  Which stripe renders which pass therefore still depends on path lengths only: frames stay reproducible, every
@@ -34,7 +34,6 @@ static const uint32_t kTailNone = 0xFFFFFFFFu;
 #endif
 template <class S, bool LDS_TABLES, bool MF, bool MULTI = false, bool TEX = false>
 __global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(SLR_TAIL_WAVES))) void k_tail(DevScene sc, PathBuffers pb, RenderParams rp) {
-    static_assert(S::LANES == 1, "the tail kernel is one lane per path");
     __shared__ ShadeLds<S::N != 3> lds;
     __shared__ TraceLds tlds;
     __shared__ uint32_t red[4];
@@ -61,7 +60,7 @@ __global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(SLR
     const float* lightCDF = LDS_TABLES ? lds.lightCDF : sc.lightCDF;
 
     const uint32_t n = pb.tailWords[0];
-    const uint32_t* list = pb.regenQueue;
+    const uint32_t* list = pb.tailList;
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t below = (1ull << lane) - 1ull;
     uint32_t slot = kTailNone;
@@ -71,7 +70,10 @@ __global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(SLR
     TravCount cnt = {0, 0};
     uint32_t* stack = tlds.stack + threadIdx.x;
 
-    for (uint32_t guard = 0; guard < (1u << 24); ++guard) {     // <= 102 turns per sample, a few hundred samples per lane at most: never reached
+    // <= 102 turns per sample; the passes a lane can still be handed are bounded by the call's pass count (a constant
+    // bound failed one-lane renders of very many passes)
+    const uint64_t guardTurns = 104ull * ((uint64_t)rp.sppCount + 2ull) + 1024ull;
+    for (uint64_t guard = 0; guard < guardTurns; ++guard) {
         // ---- lanes without a path take the next listed ones: one atomic per wave and refill --------------------------------
         const uint64_t idle = __ballot(slot == kTailNone);
         if (idle && !listDrained) {
@@ -92,27 +94,25 @@ __global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(SLR
         const uint32_t state = F_STATE(flags);
         if (state == ST_IDLE) { slot = kTailNone; continue; }    // not expected (the list holds live slots): nothing to do
         if (state == ST_REGEN) {
-            // the path ended (now, or in the last wavefront iteration): the two halves of k_regen for this slot
-            const uint4 hdr = pb.hdr[(size_t)slot * pb.hdrStride];
-            uint32_t sampleIdx = hdr.x;
+            // the path ended at this lane's last turn, or the slot has not started its first sample yet: sensor->add, next pass
+            uint32_t samplesDone = 0;
             if (F_HASPATH(flags)) {
-                accumulateSample<S>(pb, rp, slot, flags, hdr);
-                ++sampleIdx;
+                const uint4 hdr = pb.hdr[(size_t)slot * pb.hdrStride];
+                accumulateSample<S>(pb, rp, slot, flags, hdr, false, S());
+                samplesDone = hdr.x + 1u;
             }
-            const uint32_t stripe = slot / rp.numPixels;
-            const uint32_t pix = slot - stripe * rp.numPixels;
-            const uint32_t pass = pb.nextSample[pix] + stripe + rp.stripes * taken;      // relative to sppBegin, as in k_regen
-            uint4 newHdr = make_uint4(sampleIdx, 0u, 0u, 0u);
+            const SlotAddr at = slotAddr(rp, slot);
+            // a slot that has not started yet (possible only when the tail takes over at the first iteration) owns pass `stripe`
+            const uint32_t pass = F_HASPATH(flags) ? pb.nextSample[at.pix] + at.stripe + rp.stripes * taken : at.stripe;      // relative to sppBegin
             if (pass >= rp.sppCount) {
                 pb.flags[slot] = F_MAKE((uint32_t)ST_IDLE, 0u, 0u, 0u, 0u, 0u);
                 ++wentIdle;
-                pb.hdr[(size_t)slot * pb.hdrStride] = newHdr;
+                pb.hdr[(size_t)slot * pb.hdrStride] = make_uint4(samplesDone, 0u, 0u, 0u);
                 slot = kTailNone;
             }
             else {
-                startSample<S>(sc, pb, rp, slot, pix, rp.sppBegin + pass, newHdr);
-                pb.hdr[(size_t)slot * pb.hdrStride] = newHdr;
-                ++taken;
+                startSample<S>(sc, pb, rp, slot, at.pix, rp.sppBegin + pass, samplesDone);
+                if (F_HASPATH(flags)) ++taken;
             }
             continue;
         }
@@ -136,7 +136,9 @@ __global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(SLR
             ++shadowRays;
         }
         bool emitExt = false, emitShadow = false, emitRegen = false;
-        logicSlot<S, LDS_TABLES, MF, MULTI, TEX>(sc, pb, rp, lds, lightPMF, lightCDF, slot, flags, true, 0u, emitExt, emitShadow, emitRegen);
+        uint32_t fl = flags;
+        S unusedSum;
+        logicSlot<S, LDS_TABLES, MF, MULTI, TEX, false>(sc, pb, rp, lds, lightPMF, lightCDF, slot, fl, unusedSum, emitExt, emitShadow, emitRegen);
         // a finished path is in ST_REGEN now: accumulated at the next turn of this loop
     }
     if (slot != kTailNone) atomicOr(pb.errorWord, ERR_CONSUMER_IDLE);      // the bound was hit: never expected, fails the render loudly

@@ -34,6 +34,7 @@ static const int kSub = 2;                 // 64-slot sub-chunks the producer ke
 #define SLR_WS_AHEAD 4
 #endif
 static const int kAhead = SLR_WS_AHEAD;               // chunks whose state flags the producer reads in one round trip (see k_trace_ws)
+static_assert(64 % kAhead == 0 && kAhead <= 32, "the producer's 64-chunk dead-block mask is consumed kAhead bits at a time");
 static uint32_t g_refill = 20;             // idle lanes that trigger a refill (SLRHIP_WS_REFILL)
 static int g_consumers = 0;                // SLRHIP_WS_NC: consumer waves per workgroup (3, 7 or 15); 0 = by tree size: 15 on quantized (large) trees, else 7
 static const uint32_t kSpinLimit = 1u << 22;
@@ -402,7 +403,7 @@ __device__ __forceinline__ void wsConsume(const DevScene& sc, const PathBuffers&
 }
 
 // The producer wave (see the head of this file and k_trace_ws): phase 1 walks the slots for extension rays, phase 2 the shadow
-// queue; both append to the ray ring of the workgroup.  Shared by the two consumer schedules (wsConsume, wsConsumePool).
+// queue; both append to the ray ring of the workgroup.
 template <class LDS>
 __device__ __forceinline__ void wsProduce(const PathBuffers& pb, LDS& lds, uint32_t numSlots, uint32_t shardCapacity, uint32_t parity,
                                           uint32_t& extRays, uint32_t& shadowRays, WsDebug& dbg) {
@@ -536,377 +537,6 @@ __global__ __launch_bounds__(64 * (NC + 1)) __attribute__((amdgpu_waves_per_eu(8
     }
 }
 
-
-// ---------------------------------------------------------------------------------------------------------------------------------
-// POOL schedule (SLRHIP_TRACE=pool; experiment): the same producer and ring, but a consumer wave keeps kPoolRays rays RESIDENT IN
-// LDS (origin, direction, reciprocal direction, current node, stack column, best hit) and advances them in dense phases:
-//   node phase      up to 64 rays whose next step is a node visit, one per lane (the node-ready list);
-//   triangle phase  up to 64 (ray, leaf triangle) items, one per lane (the triangle queue): a leaf of k triangles is k items,
-//                   tested in parallel; results meet in the ray's 64-bit hit key by an LDS atomic min — key = (t bits, ~index), so
-//                   the smallest t wins and among equal t the larger scene index, the tie rule of the other kernels; the lane that
-//                   retires a ray's last pending item pops the ray's stack and routes it on.
-// A ray waits in LDS while its leaf is in the queue, so the traversal order per ray — and with it the hit — is the one of
-// wsConsume; what changes is that both code blocks run at close to 64 active lanes instead of 0.55 / 0.24 of them
-// (DESIGN.md 8.2 has the arithmetic).  All hand-offs inside a consumer wave are LDS operations of that one wave, which the LDS
-// executes in program order: no fences, no spins.
-static const int kPoolRays = 128;
-static const int kPoolStack = 8;                      // stack rows in LDS; deeper entries live in PathBuffers-independent global spill
-static const int kPoolSpill = 64 - kPoolStack;
-static const unsigned long long kPoolNoHit = ~0ull;
-
-struct PoolLds {
-    float4 org[kPoolRays];                // xyz + tmin
-    float4 dir[kPoolRays];                // xyz + tmax (shrinks to the best hit)
-    float4 inv[kPoolRays];                // 1 / dir (Vector3.h:60), w = ring slot word (bit 31: shadow ray)
-    unsigned long long key[kPoolRays];    // best hit: (t bits << 32) | ~triangle index; kPoolNoHit = none
-    float2 hitB[kPoolRays];               // b1, b2 of the best hit
-    uint32_t cur[kPoolRays];              // node to visit next, or the leaf whose triangles are in the queue
-    uint32_t spPend[kPoolRays];           // [15:0] stack pointer, [31:16] items of this ray still in the triangle queue
-    uint32_t stack[kPoolStack][kPoolRays];
-    uint16_t triQ[4 * kPoolRays];         // ray | k << 8: triangle k of the leaf in cur[ray]
-    uint8_t nodeList[kPoolRays];
-    uint8_t freeList[kPoolRays];
-};
-
-template <int NC>
-struct WsPoolLds {
-    static constexpr uint32_t kRing = 64u * (NC + 1);
-    float4 org[kRing];
-    float4 dir[kRing];
-    uint32_t slot[kRing];
-    PoolLds pool[NC];
-    uint32_t tail, reserved, released, done;
-    uint32_t red[NC + 1];
-};
-
-template <bool COUNT, int NC, bool QUANT>
-__device__ __forceinline__ void wsConsumePool(const DevScene& sc, const PathBuffers& pb, WsPoolLds<NC>& lds, uint32_t* __restrict__ spillBase, WsCounts& cnt, WsDebug& dbg) {
-    const uint64_t tStart = COUNT ? __builtin_readcyclecounter() : 0;
-    constexpr uint32_t kRing = WsPoolLds<NC>::kRing;
-    constexpr uint32_t R = kPoolRays;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint64_t below = (1ull << lane) - 1ull;
-    PoolLds& P = lds.pool[(threadIdx.x >> 6) - 1];
-    // stack entries beyond the LDS rows: [workgroup][consumer wave][entry][ray]
-    uint32_t* spill = spillBase + ((size_t)blockIdx.x * NC + ((threadIdx.x >> 6) - 1)) * (size_t)kPoolSpill * R;
-    const float4* __restrict__ nodes4 = sc.nodes;
-    const float4* __restrict__ tris4 = sc.leafTris;
-
-    for (uint32_t i = lane; i < R; i += 64u) P.freeList[i] = (uint8_t)i;
-    uint32_t nNode = 0, nTri = 0, nFree = R;            // wave-uniform
-    uint32_t idleSpins = 0;
-
-    // ---- helpers ---------------------------------------------------------------------------------------------------------
-    // append a per-lane count (0..4) of triangle items / one node-list entry / one free-list entry: ballot prefixes
-    const auto finishRay = [&](bool fin, uint32_t r) {
-        if (fin) {
-            const uint32_t slotWord = __float_as_uint(P.inv[r].w);
-            const unsigned long long k64 = P.key[r];
-            if (slotWord & kShadowBit) pb.visible[slotWord & ~kShadowBit] = k64 == kPoolNoHit ? 1u : 0u;      // testVisibility
-            else {
-                const float2 b = P.hitB[r];
-                pb.hit[slotWord] = k64 == kPoolNoHit ? make_float4(__uint_as_float(0xFFFFFFFFu), INFINITY, 0.0f, 0.0f)
-                                                      : make_float4(__uint_as_float(~(uint32_t)k64), __uint_as_float((uint32_t)(k64 >> 32)), b.x, b.y);
-            }
-        }
-        const uint64_t m = __ballot(fin);
-        if (fin) P.freeList[nFree + (uint32_t)__popcll(m & below)] = (uint8_t)r;
-        nFree += (uint32_t)__popcll(m);
-    };
-    // `ref` is what ray r does next: an inner node -> node list; a leaf -> its triangles into the queue (the ray waits)
-    const auto route = [&](bool act, uint32_t r, uint32_t ref, uint32_t sp) {
-        const bool leaf = act && (ref & kLeafFlag) != 0;
-        const bool node = act && !leaf;
-        const uint32_t c = leaf ? (ref >> kLeafCountShift) & 0xFu : 0u;       // 1..4
-        const uint64_t b0 = __ballot((c & 1u) != 0), b1 = __ballot((c & 2u) != 0), b2 = __ballot((c & 4u) != 0);
-        const uint32_t off = nTri + (uint32_t)__popcll(b0 & below) + 2u * (uint32_t)__popcll(b1 & below) + 4u * (uint32_t)__popcll(b2 & below);
-        if (leaf) {
-            for (uint32_t k = 0; k < c; ++k) P.triQ[off + k] = (uint16_t)(r | (k << 8));
-            P.cur[r] = ref;
-            P.spPend[r] = sp | (c << 16);
-        }
-        nTri += (uint32_t)__popcll(b0) + 2u * (uint32_t)__popcll(b1) + 4u * (uint32_t)__popcll(b2);
-        const uint64_t mn = __ballot(node);
-        if (node) {
-            P.nodeList[nNode + (uint32_t)__popcll(mn & below)] = (uint8_t)r;
-            P.cur[r] = ref;
-            P.spPend[r] = sp;
-        }
-        nNode += (uint32_t)__popcll(mn);
-    };
-    const auto popStack = [&](uint32_t r, uint32_t& sp) -> uint32_t {
-        --sp;
-        return sp < (uint32_t)kPoolStack ? P.stack[sp][r] : spill[(size_t)(sp - kPoolStack) * R + r];
-    };
-
-    for (;;) {
-        // ---- refill the pool from the ring ---------------------------------------------------------------------------------
-        if (nFree >= 32u) {
-            uint32_t start = 0, take = 0;
-            if (lane == 0) {
-                for (int attempt = 0; attempt < 64; ++attempt) {
-                    uint32_t r = WS_LOAD(&lds.reserved, __ATOMIC_RELAXED);
-                    const uint32_t t = WS_LOAD(&lds.tail, __ATOMIC_ACQUIRE);
-                    take = min(min(t - r, nFree), 64u);
-                    if (take == 0) break;
-                    if (__hip_atomic_compare_exchange_strong(&lds.reserved, &r, r + take, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                             __HIP_MEMORY_SCOPE_WORKGROUP)) { start = r; break; }
-                    take = 0;
-                }
-            }
-            start = __builtin_amdgcn_readfirstlane(start);
-            take = __builtin_amdgcn_readfirstlane(take);
-            if (take) {
-                idleSpins = 0;
-                if (COUNT) ++dbg.refills;
-                if (lane < take) {
-                    const uint32_t pos = (start + lane) & (kRing - 1);
-                    const float4 o = lds.org[pos], d = lds.dir[pos];
-                    const uint32_t slotWord = lds.slot[pos];
-                    const uint32_t r = P.freeList[nFree - 1u - lane];
-                    P.org[r] = o;
-                    P.dir[r] = d;
-                    P.inv[r] = make_float4(1.0f / d.x, 1.0f / d.y, 1.0f / d.z, __uint_as_float(slotWord));      // Vector3.h:60 reciprocal()
-                    P.key[r] = kPoolNoHit;
-                    P.cur[r] = 0u;                    // the root
-                    P.spPend[r] = 0u;
-                    P.nodeList[nNode + lane] = (uint8_t)r;
-                }
-                nFree -= take;
-                nNode += take;
-                // ring space is handed back in reservation order (see wsConsume)
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                if (lane == 0) {
-                    uint32_t spin = 0;
-                    for (; spin < kSpinLimit && WS_LOAD(&lds.released, __ATOMIC_ACQUIRE) != start; ++spin) __builtin_amdgcn_s_sleep(1);
-                    if (spin == kSpinLimit) atomicOr(pb.errorWord, ERR_RING_RELEASE);
-                    WS_STORE(&lds.released, start + take, __ATOMIC_RELEASE);
-                }
-            }
-            else if (nFree == R) {
-                // the pool is empty and there is nothing to take: finished, or the producer is behind
-                if (WS_LOAD(&lds.done, __ATOMIC_ACQUIRE) && WS_LOAD(&lds.tail, __ATOMIC_ACQUIRE) == WS_LOAD(&lds.reserved, __ATOMIC_RELAXED)) break;
-                if (++idleSpins > kSpinLimit) { if (lane == 0) atomicOr(pb.errorWord, ERR_CONSUMER_IDLE); break; }
-                if (COUNT) {
-                    const uint64_t t0 = __builtin_readcyclecounter();
-                    __builtin_amdgcn_s_sleep(4);
-                    dbg.idleCycles += __builtin_readcyclecounter() - t0;
-                    ++dbg.idleSpins;
-                }
-                else __builtin_amdgcn_s_sleep(4);
-                continue;
-            }
-        }
-
-        if (nTri >= 64u || (nTri > 0u && nTri > nNode)) {
-            // ---- triangle phase: 64 (ray, triangle) items ------------------------------------------------------------------
-            const uint32_t m = min(nTri, 64u);
-            if (COUNT) { ++dbg.steps; dbg.activeLanes += m; if (lane == 0) ++dbg.triBlocks; }
-            const bool act = lane < m;
-            uint32_t r = 0, sp = 0;
-            bool last = false;
-            if (act) {
-                const uint32_t item = P.triQ[nTri - m + lane];
-                r = item & 0xFFu;
-                const uint32_t leaf = P.cur[r];
-                const uint32_t first = (leaf & kLeafIndexMask) + (item >> 8);
-                const float4 o = P.org[r], d = P.dir[r];
-                const bool anyHit = (__float_as_uint(P.inv[r].w) & kShadowBit) != 0;
-                const char* tb = reinterpret_cast<const char*>(tris4);
-                const uint32_t tOff = first * 48u;
-                const float4 a = *reinterpret_cast<const float4*>(tb + tOff);
-                const float4 b = *reinterpret_cast<const float4*>(tb + (tOff + 16u));
-                const float4 c = *reinterpret_cast<const float4*>(tb + (tOff + 32u));
-                const V3 v0(a.x, a.y, a.z), e1(b.x, b.y, b.z), e2(c.x, c.y, c.z);
-                const uint32_t triIdx = __float_as_uint(a.w);
-                const V3 org(o.x, o.y, o.z), dir(d.x, d.y, d.z);
-                const float tmin = o.w, tmax = d.w;
-                if (COUNT) { cnt.tris[0] += anyHit ? 0u : 1u; cnt.tris[1] += anyHit ? 1u : 0u; }
-                // Moller-Trumbore exactly as TriangleMesh.cpp:139-160
-                const V3 p = cross(dir, e2);
-                const float det = dot(e1, p);
-                bool accept = det != 0.0f;
-                const float invDet = 1.0f / det;
-                const V3 dd = org - v0;
-                const float b1 = dot(dd, p) * invDet;
-                accept = accept && !(b1 < 0.0f || b1 > 1.0f);
-                const V3 q = cross(dd, e1);
-                const float b2 = dot(dir, q) * invDet;
-                accept = accept && !(b2 < 0.0f || b1 + b2 > 1.0f);
-                const float tt = dot(e2, q) * invDet;
-                accept = accept && !(tt < tmin || tt > tmax);
-                if (accept && __float_as_uint(b.w) != kNoAlpha) accept = alphaPasses(sc.alphaTris, sc.textures, __float_as_uint(b.w), b1, b2);
-                if (accept) {
-                    // t >= tmin >= 0: the bits of a non-negative float order like the float (-0 is brought to +0 first)
-                    const unsigned long long mine = anyHit ? 0ull : ((unsigned long long)__float_as_uint(tt + 0.0f) << 32) | (unsigned long long)(~triIdx);
-                    atomicMin(&P.key[r], mine);
-                    if (P.key[r] == mine) P.hitB[r] = make_float2(b1, b2);          // after every lane's min of this phase: LDS runs in order
-                }
-                const uint32_t old = atomicSub(&P.spPend[r], 1u << 16);
-                last = (old >> 16) == 1u;
-                sp = old & 0xFFFFu;
-            }
-            nTri -= m;
-            // the lane that retired a ray's last item resumes the ray: new tmax, then pop (QBVH.h:322-338)
-            bool fin = false, go = false;
-            uint32_t ref = 0;
-            if (last) {
-                const unsigned long long k64 = P.key[r];
-                const bool anyHit = (__float_as_uint(P.inv[r].w) & kShadowBit) != 0;
-                if (k64 != kPoolNoHit && !anyHit) reinterpret_cast<float*>(&P.dir[r])[3] = __uint_as_float((uint32_t)(k64 >> 32));     // ray.distMax = isect->dist (QBVH.h:335)
-                if ((k64 != kPoolNoHit && anyHit) || sp == 0u) fin = true;
-                else { ref = popStack(r, sp); go = true; }
-            }
-            finishRay(fin, r);
-            route(go, r, ref, sp);
-        }
-        else if (nNode > 0u) {
-            // ---- node phase: 64 rays, four slab tests each -----------------------------------------------------------------
-            const uint32_t m = min(nNode, 64u);
-            if (COUNT) { ++dbg.steps; dbg.activeLanes += m; ++dbg.nodeBlocks; }
-            const bool act = lane < m;
-            uint32_t r = 0, sp = 0, ref = 0;
-            bool fin = false, go = false;
-            if (act) {
-                r = P.nodeList[nNode - m + lane];
-                const float4 o = P.org[r], iv = P.inv[r];
-                const float ox = o.x, oy = o.y, oz = o.z, tmin = o.w, idx = iv.x, idy = iv.y, idz = iv.z;
-                const float tmax = P.dir[r].w;
-                const uint32_t cur = P.cur[r];
-                sp = P.spPend[r];
-                if (COUNT) { const bool sh = (__float_as_uint(iv.w) & kShadowBit) != 0; cnt.nodes[0] += sh ? 0u : 1u; cnt.nodes[1] += sh ? 1u : 0u; }
-                float4 nX, nY, nZ, fX, fY, fZ, ch;
-                if (QUANT) {
-                    const char* nb = reinterpret_cast<const char*>(sc.nodesQ);
-                    const uint32_t nOff = cur * 64u;
-                    const float4 v0 = *reinterpret_cast<const float4*>(nb + nOff);
-                    const float4 v1 = *reinterpret_cast<const float4*>(nb + (nOff + 16u));
-                    const float4 v2 = *reinterpret_cast<const float4*>(nb + (nOff + 32u));
-                    ch = *reinterpret_cast<const float4*>(nb + (nOff + 48u));
-                    const uint32_t qlox = __float_as_uint(v1.z), qloy = __float_as_uint(v1.w), qloz = __float_as_uint(v2.x);
-                    const uint32_t qhix = __float_as_uint(v2.y), qhiy = __float_as_uint(v2.z), qhiz = __float_as_uint(v2.w);
-                    const uint32_t nqx = idx > 0.0f ? qlox : qhix, fqx = idx > 0.0f ? qhix : qlox;      // QBVH.h:66-71
-                    const uint32_t nqy = idy > 0.0f ? qloy : qhiy, fqy = idy > 0.0f ? qhiy : qloy;
-                    const uint32_t nqz = idz > 0.0f ? qloz : qhiz, fqz = idz > 0.0f ? qhiz : qloz;
-#define WS_DEQ(q, sh, scale, org) __builtin_fmaf((float)(((q) >> (sh)) & 0xFFu), scale, org)
-#define WS_DEQ4(q, scale, org) make_float4(WS_DEQ(q, 0, scale, org), WS_DEQ(q, 8, scale, org), WS_DEQ(q, 16, scale, org), WS_DEQ(q, 24, scale, org))
-                    nX = WS_DEQ4(nqx, v0.w, v0.x); fX = WS_DEQ4(fqx, v0.w, v0.x);
-                    nY = WS_DEQ4(nqy, v1.x, v0.y); fY = WS_DEQ4(fqy, v1.x, v0.y);
-                    nZ = WS_DEQ4(nqz, v1.y, v0.z); fZ = WS_DEQ4(fqz, v1.y, v0.z);
-#undef WS_DEQ4
-#undef WS_DEQ
-                }
-                else {
-                    const int nx = idx > 0.0f ? 0 : 3, fx = 3 - nx;
-                    const int ny = idy > 0.0f ? 1 : 4, fy = 5 - ny;
-                    const int nz = idz > 0.0f ? 2 : 5, fz = 7 - nz;
-                    const char* nb = reinterpret_cast<const char*>(nodes4);
-                    const uint32_t nOff = cur * 128u;
-                    nX = *reinterpret_cast<const float4*>(nb + (nOff + (uint32_t)nx * 16u));
-                    nY = *reinterpret_cast<const float4*>(nb + (nOff + (uint32_t)ny * 16u));
-                    nZ = *reinterpret_cast<const float4*>(nb + (nOff + (uint32_t)nz * 16u));
-                    fX = *reinterpret_cast<const float4*>(nb + (nOff + (uint32_t)fx * 16u));
-                    fY = *reinterpret_cast<const float4*>(nb + (nOff + (uint32_t)fy * 16u));
-                    fZ = *reinterpret_cast<const float4*>(nb + (nOff + (uint32_t)fz * 16u));
-                    ch = *reinterpret_cast<const float4*>(nb + (nOff + 96u));
-                }
-                // slab test of QBVH::Node::intersect (QBVH.h:55-76): tNear <= tFar — the arithmetic of wsConsume
-                const float tn0 = fmaxf(fmaxf((nX.x - ox) * idx, (nY.x - oy) * idy), fmaxf((nZ.x - oz) * idz, tmin));
-                const float tn1 = fmaxf(fmaxf((nX.y - ox) * idx, (nY.y - oy) * idy), fmaxf((nZ.y - oz) * idz, tmin));
-                const float tn2 = fmaxf(fmaxf((nX.z - ox) * idx, (nY.z - oy) * idy), fmaxf((nZ.z - oz) * idz, tmin));
-                const float tn3 = fmaxf(fmaxf((nX.w - ox) * idx, (nY.w - oy) * idy), fmaxf((nZ.w - oz) * idz, tmin));
-                const float tf0 = fminf(fminf((fX.x - ox) * idx, (fY.x - oy) * idy), fminf((fZ.x - oz) * idz, tmax));
-                const float tf1 = fminf(fminf((fX.y - ox) * idx, (fY.y - oy) * idy), fminf((fZ.y - oz) * idz, tmax));
-                const float tf2 = fminf(fminf((fX.z - ox) * idx, (fY.z - oy) * idy), fminf((fZ.z - oz) * idz, tmax));
-                const float tf3 = fminf(fminf((fX.w - ox) * idx, (fY.w - oy) * idy), fminf((fZ.w - oz) * idz, tmax));
-                const uint32_t c0 = __float_as_uint(ch.x), c1 = __float_as_uint(ch.y), c2 = __float_as_uint(ch.z), c3 = __float_as_uint(ch.w);
-                const bool h0 = tn0 <= tf0 && c0 != kInvalidChild;
-                const bool h1 = tn1 <= tf1 && c1 != kInvalidChild;
-                const bool h2 = tn2 <= tf2 && c2 != kInvalidChild;
-                const bool h3 = tn3 <= tf3 && c3 != kInvalidChild;
-                float best = INFINITY;
-                uint32_t next = kInvalidChild;
-                if (h0) { best = tn0; next = c0; }
-                if (h1 && tn1 < best) { best = tn1; next = c1; }
-                if (h2 && tn2 < best) { best = tn2; next = c2; }
-                if (h3 && tn3 < best) { best = tn3; next = c3; }
-                // the hit children other than `next` go on the ray's stack in child order
-#define POOL_PUSH(cond, cref)                                                                                   \
-                if ((cond) && (cref) != next) {                                                                  \
-                    if (sp < (uint32_t)kPoolStack) P.stack[sp][r] = (cref);                                      \
-                    else if (sp < 64u) spill[(size_t)(sp - kPoolStack) * R + r] = (cref);                        \
-                    else { atomicOr(pb.errorWord, ERR_STACK_OVERFLOW); --sp; }      /* the host rejects trees that could get here */ \
-                    ++sp;                                                                                        \
-                }
-                POOL_PUSH(h0, c0)
-                POOL_PUSH(h1, c1)
-                POOL_PUSH(h2, c2)
-                POOL_PUSH(h3, c3)
-#undef POOL_PUSH
-                if (next != kInvalidChild) { ref = next; go = true; }
-                else if (sp == 0u) fin = true;
-                else { ref = popStack(r, sp); go = true; }
-            }
-            nNode -= m;
-            finishRay(fin, r);
-            route(go, r, ref, sp);
-        }
-        // else: rays are in flight only if the pool is not empty, which the branches above cover; an empty pool loops to the refill
-    }
-    if (COUNT) dbg.cycles = __builtin_readcyclecounter() - tStart;
-}
-
-template <bool COUNT, int NC, bool QUANT>
-__global__ __launch_bounds__(64 * (NC + 1)) void k_trace_pool(DevScene sc, PathBuffers pb, uint32_t numSlots, uint32_t shardCapacity, uint32_t parity,
-                                                             uint32_t tailSlots, uint32_t* spill) {
-    __shared__ WsPoolLds<NC> lds;
-    if (pb.activeSlots[0] == 0) return;
-    if (tailModeBegins(pb, tailSlots, parity)) return;
-    if (blockIdx.x == 0 && threadIdx.x < Q_KINDS * kShards) pb.queueCount[queueCounterIndex(parity ^ 1, threadIdx.x / kShards, threadIdx.x % kShards)] = 0;
-    if (threadIdx.x == 0) { lds.tail = 0; lds.reserved = 0; lds.released = 0; lds.done = 0; }
-    __syncthreads();
-    uint32_t extRays = 0, shadowRays = 0;
-    WsCounts cnt;
-    WsDebug dbg;
-    if (threadIdx.x < 64) wsProduce(pb, lds, numSlots, shardCapacity, parity, extRays, shadowRays, dbg);
-    else wsConsumePool<COUNT, NC, QUANT>(sc, pb, lds, spill, cnt, dbg);
-    wsBlockAdd(pb.totals, T_EXT_RAYS, extRays, lds.red);
-    wsBlockAdd(pb.totals, T_SHADOW_RAYS, shadowRays, lds.red);
-    if (COUNT) {
-        wsBlockAdd(pb.totals, T_NODES_CLOSEST, cnt.nodes[0], lds.red); wsBlockAdd(pb.totals, T_TRIS_CLOSEST, cnt.tris[0], lds.red);
-        wsBlockAdd(pb.totals, T_NODES_SHADOW, cnt.nodes[1], lds.red); wsBlockAdd(pb.totals, T_TRIS_SHADOW, cnt.tris[1], lds.red);
-        const bool l0 = (threadIdx.x & 63u) == 0;      // wave-level figures as in k_trace_ws: here a "step" is one phase
-        wsBlockAdd(pb.totals, T_WS_STEPS, l0 ? dbg.steps : 0u, lds.red);
-        wsBlockAdd(pb.totals, T_WS_IDLE_SPINS, l0 ? dbg.idleSpins : 0u, lds.red);
-        wsBlockAdd(pb.totals, T_WS_CYCLES, l0 ? (uint32_t)(dbg.cycles >> 6) : 0u, lds.red);
-        wsBlockAdd(pb.totals, T_WS_IDLE_CYCLES, l0 ? (uint32_t)(dbg.idleCycles >> 6) : 0u, lds.red);
-        wsBlockAdd(pb.totals, T_WS_REFILLS, l0 ? dbg.refills : 0u, lds.red);
-        wsBlockAdd(pb.totals, T_WS_PRODUCER_WAITS, l0 ? dbg.producerWaits : 0u, lds.red);
-        wsBlockAdd(pb.totals, T_WS_NODE_BLOCKS, l0 ? dbg.nodeBlocks : 0u, lds.red);
-        wsBlockAdd(pb.totals, T_WS_TRI_BLOCKS, dbg.triBlocks, lds.red);
-        wsBlockAdd(pb.totals, T_WS_ACTIVE_LANES, l0 ? dbg.activeLanes : 0u, lds.red);
-    }
-}
-
-int tracePoolBlocksPerCU() {
-    if (const char* e = getenv("SLRHIP_POOL_BLOCKS_PER_CU")) { const int b = atoi(e); if (b >= 1 && b <= 8) return b; }
-    return 3;       // 52 KiB of LDS per workgroup
-}
-size_t tracePoolSpillWords(uint32_t blocks) { return (size_t)blocks * 3u * (size_t)kPoolSpill * kPoolRays; }
-
-void launchTracePool(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, uint32_t blocks, bool count, uint32_t* spill,
-                     hipStream_t stream) {
-    blocks = (blocks + kShards - 1) / kShards * kShards;
-    const dim3 grid(blocks), block(64 * 4);
-    if (sc.nodesQ) {
-        if (count) hipLaunchKernelGGL((k_trace_pool<true, 3, true>), grid, block, 0, stream, sc, pb, rp.numSlots, rp.shardCapacity, parity, rp.tailSlots, spill);
-        else hipLaunchKernelGGL((k_trace_pool<false, 3, true>), grid, block, 0, stream, sc, pb, rp.numSlots, rp.shardCapacity, parity, rp.tailSlots, spill);
-    }
-    else {
-        if (count) hipLaunchKernelGGL((k_trace_pool<true, 3, false>), grid, block, 0, stream, sc, pb, rp.numSlots, rp.shardCapacity, parity, rp.tailSlots, spill);
-        else hipLaunchKernelGGL((k_trace_pool<false, 3, false>), grid, block, 0, stream, sc, pb, rp.numSlots, rp.shardCapacity, parity, rp.tailSlots, spill);
-    }
-}
 
 template <bool COUNT, int NC>
 static void launchTraceWsT(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, uint32_t blocks, hipStream_t stream) {

@@ -118,7 +118,6 @@ struct slrhip_ctx {
     DevArray<DevTexture> textures;
     DevArray<DevMatTex> matTex;
     DevArray<float4> triUV, alphaTris;
-    DevArray<float4> quadNodes, quadPackets;      // SLRHIP_FLAG_QUAD_LAYOUT: the four-lanes-per-ray layouts (pt_trace_quad.hip)
     DevArray<LeafTri> leafTris;
     DevArray<ShadeTri> shadeTris;
     DevArray<LightTri> lightTris;
@@ -144,17 +143,15 @@ struct slrhip_ctx {
     DevArray<float4> rayOrg, rayDir, hit, alpha, spR, spC, accR, accC, nee, shadowDir;
     DevArray<float> pdfPrev;
     DevArray<uint4> hdr;
-    DevArray<unsigned long long> finishedMask;
     DevArray<uint32_t> nextSample;
-    DevArray<uint32_t> flags, visible, shadowQueue, regenQueue, queueCount, activeSlots, blockDead;
-    DevArray<uint32_t> poolSpill;       // SLRHIP_TRACE=pool: stack entries beyond the LDS rows
+    DevArray<uint32_t> flags, visible, shadowQueue, tailList, queueCount, activeSlots, blockDead;
     DevArray<uint64_t> totals;
     DevArray<float> resolveScratch;
     PathBuffers buffers;
     uint64_t iterations = 0;
     bool firstRenderCall = true;
 
-    // SLRHIP_FLAG_TIME_KERNELS: 4 events per iteration (before closest, after closest, after shadow, after shade)
+    // SLRHIP_FLAG_TIME_KERNELS: 3 events per iteration (before shade, after shade, after trace)
     std::vector<hipEvent_t> events;
     // hipGraph of one block of iterations (slrhip_render): captured on the context's own stream, replayed until no slot is live
     hipStream_t workStream = nullptr;
@@ -585,12 +582,6 @@ int slrhip_upload_scene(slrhip_ctx* ctx, const slrhip_scene_desc* d) {
     HIP_TRY(ctx->matTex.upload(matTex));
     HIP_TRY(ctx->triUV.upload(triUV));
     HIP_TRY(ctx->alphaTris.upload(alphaTris));
-    if (ctx->config.flags & SLRHIP_FLAG_QUAD_LAYOUT) {
-        std::vector<float4> qn, qp;
-        buildQuadLayouts(bvh.nodes, bvh.leafTris, &qn, &qp);
-        HIP_TRY(ctx->quadNodes.upload(qn));
-        HIP_TRY(ctx->quadPackets.upload(qp));
-    }
     HIP_TRY(ctx->shadeTris.upload(shade));
     HIP_TRY(ctx->lightTris.upload(lights));
     HIP_TRY(ctx->materials.upload(mats));
@@ -718,12 +709,18 @@ int slrhip_render_begin(slrhip_ctx* ctx, const slrhip_render_settings* st, slrhi
         // launch-bound): ~7.4 M.  At most 64 stripes: the width of the pool's mask, and the best count measured for the
         // eighth of the image a rank owns at N = 8 (61.5 / 62.5 / 65.4 / 68.0 ms at 64 / 96 / 128 / 192 with a wider mask:
         // below ~16 samples per slot the first, statically assigned sample of every stripe weighs too much).
+        // Powers of two: the stripes of a pixel then fill whole lane groups of the shade workgroup (PathBuffers, slot layout).
         const uint32_t target = ctx->config.mode == SLRHIP_MODE_SPECTRAL ? 7372800u : 22118400u;
-        stripes = numPixels >= target || numPixels == 0 ? 1u : (target + numPixels / 2) / numPixels;
-        if (stripes < 1) stripes = 1;
-        if (stripes > 64) stripes = 64;
+        static const long envStripes = [] { const char* e = getenv("SLRHIP_AUTO_STRIPES"); return e ? atol(e) : 0L; }();      // measurement: force the automatic choice
+        stripes = 1u;
+        while (stripes < 64u && (uint64_t)numPixels * stripes * 3u < (uint64_t)target * 2u) stripes *= 2u;      // the power of two nearest target / numPixels (geometric mean as the boundary: x 1.5)
+        if (numPixels == 0) stripes = 1u;
+        if (envStripes >= 1 && envStripes <= 64) stripes = (uint32_t)envStripes;
     }
-    const size_t numSlots = (size_t)numPixels * stripes;
+    // Slot layout (pt_kernels.h, slotAddr): shade workgroup b holds the `stripes` slots of each of its 256 / stripes pixels
+    const uint32_t pixelsPerBlock = 256u / stripes;
+    const size_t numBlocksLayout = ((size_t)numPixels + pixelsPerBlock - 1) / pixelsPerBlock;
+    const size_t numSlots = std::max<size_t>(numBlocksLayout, 1) * 256u;
     if (numSlots > 0x7FFFFFFFull) return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_render_begin: too many path slots");
 
     const bool spectral = ctx->config.mode == SLRHIP_MODE_SPECTRAL;
@@ -739,12 +736,12 @@ int slrhip_render_begin(slrhip_ctx* ctx, const slrhip_render_settings* st, slrhi
     HIP_TRY(ctx->shadowDir.alloc(numSlots, true));
     HIP_TRY(ctx->pdfPrev.alloc(spectral ? numSlots : 1, true));
     HIP_TRY(ctx->hdr.alloc(numSlots * hdrStride, true)); HIP_TRY(ctx->rng.alloc(hdrStride == 2 ? 1 : numSlots, true));
-    HIP_TRY(ctx->finishedMask.alloc(2 * (size_t)numPixels + 2, true)); HIP_TRY(ctx->nextSample.alloc((size_t)numPixels + 1, true));
+    HIP_TRY(ctx->nextSample.alloc((size_t)numPixels + 1, true));
     HIP_TRY(ctx->flags.alloc(numSlots, true)); HIP_TRY(ctx->visible.alloc(numSlots, true));
     // queue regions: slot block b appends to region b % kShards, so a region holds at most ceil(numBlocks / kShards) blocks
     const uint32_t numBlocks = (uint32_t)((numSlots + 255) / 256);
     const uint32_t shardCapacity = ((numBlocks + kShards - 1) / kShards) * 256;
-    HIP_TRY(ctx->shadowQueue.alloc((size_t)shardCapacity * kShards, true)); HIP_TRY(ctx->regenQueue.alloc((size_t)shardCapacity * kShards, true));
+    HIP_TRY(ctx->shadowQueue.alloc((size_t)shardCapacity * kShards, true)); HIP_TRY(ctx->tailList.alloc(numSlots, true));
     HIP_TRY(ctx->blockDead.alloc(numBlocks));
     HIP_TRY(ctx->queueCount.alloc(2 * kQueueSetWords)); HIP_TRY(ctx->activeSlots.alloc(kStatusWords));      // [0] live slots, [1] device error word, [2] unused, [3] tail mode (1 + parity), [4..5] tail list length / cursor
     HIP_TRY(ctx->totals.alloc((size_t)T_KINDS * kShards * kTotalStride));
@@ -763,20 +760,20 @@ int slrhip_render_begin(slrhip_ctx* ctx, const slrhip_render_settings* st, slrhi
     pb.rayStride = rayStride; pb.spStride = spStride;
     pb.alpha = ctx->alpha.ptr; pb.spR = ctx->spR.ptr; pb.spC = spStride == 2 ? ctx->spR.ptr + 1 : ctx->spC.ptr; pb.accR = ctx->accR.ptr; pb.accC = ctx->accR.ptr + 1;
     pb.nee = ctx->nee.ptr;
-    pb.pdfPrev = spectral ? ctx->pdfPrev.ptr : nullptr; pb.hdr = ctx->hdr.ptr; pb.finishedMask = ctx->finishedMask.ptr; pb.nextSample = ctx->nextSample.ptr; pb.shadowDir = ctx->shadowDir.ptr; pb.flags = ctx->flags.ptr;
-    pb.visible = ctx->visible.ptr; pb.shadowQueue = ctx->shadowQueue.ptr; pb.regenQueue = ctx->regenQueue.ptr;
+    pb.pdfPrev = spectral ? ctx->pdfPrev.ptr : nullptr; pb.hdr = ctx->hdr.ptr; pb.nextSample = ctx->nextSample.ptr; pb.shadowDir = ctx->shadowDir.ptr; pb.flags = ctx->flags.ptr;
+    pb.visible = ctx->visible.ptr; pb.shadowQueue = ctx->shadowQueue.ptr; pb.tailList = ctx->tailList.ptr;
     pb.queueCount = ctx->queueCount.ptr; pb.activeSlots = ctx->activeSlots.ptr; pb.errorWord = ctx->activeSlots.ptr + 1; pb.tailMode = ctx->activeSlots.ptr + 3; pb.tailWords = ctx->activeSlots.ptr + 4; pb.blockDead = ctx->blockDead.ptr; pb.totals = ctx->totals.ptr;
     pb.pixelXY = ctx->pixelXY.ptr;
 
     RenderParams& rp = ctx->params;
-    rp.numSlots = (uint32_t)numSlots; rp.numPixels = numPixels; rp.stripes = stripes;
+    rp.numSlots = numPixels ? (uint32_t)numSlots : 0u; rp.numPixels = numPixels; rp.stripes = stripes;
+    rp.pixelsPerBlock = pixelsPerBlock; rp.stripesRecip = (65536u + stripes - 1u) / stripes;
     rp.sppBegin = 0; rp.sppCount = 0;
     rp.rngSeed = st->rng_seed; rp.timeStart = st->time_start; rp.timeEnd = st->time_end;
     rp.imageWidth = W; rp.imageHeight = H;
     rp.countSlots = (ctx->config.flags & SLRHIP_FLAG_COUNT_TRAVERSAL) ? 1u : 0u;
     rp.shardCapacity = shardCapacity;
     rp.spectral = spectral ? 1u : 0u;
-    rp.spectralQuad = (ctx->config.flags & SLRHIP_FLAG_SPECTRAL_QUAD) ? 1u : 0u;
     rp.injectError = (ctx->config.flags & SLRHIP_FLAG_TEST_DEVICE_ERROR) ? 1u : 0u;
     ctx->settings = *st;
     ctx->shard = shard;
@@ -801,47 +798,38 @@ int slrhip_render(slrhip_ctx* ctx, uint32_t sppBegin, uint32_t sppCount, void* s
     launchResetSlots(ctx->buffers, rp, ctx->firstRenderCall, stream);
     ctx->firstRenderCall = false;
     if (sppCount == 0) return SLRHIP_OK;
-    // persistent traversal workgroups: a fixed number per CU, each staging the top of the tree in LDS once
-    // Traversal schedule: wave-specialised (pt_trace_ws.hip) unless SLRHIP_TRACE=batch asks for the 64-ray-batch kernels
-    // of pt_trace.hip, and so does SLRHIP_FLAG_TRACE_BATCH per context (kept for A/B checks; results are identical)
-    static const bool envBatch = [] { const char* e = getenv("SLRHIP_TRACE"); return e && std::string(e) == "batch"; }();
-    static const bool envPool = [] { const char* e = getenv("SLRHIP_TRACE"); return e && std::string(e) == "pool"; }();
-    const bool useWs = !envBatch && !(ctx->config.flags & SLRHIP_FLAG_TRACE_BATCH);
-    const bool usePool = useWs && (envPool || (ctx->config.flags & SLRHIP_FLAG_TRACE_POOL) != 0);
-    const uint32_t traceBlocks = (uint32_t)ctx->numCUs * (uint32_t)(usePool ? tracePoolBlocksPerCU() : useWs ? traceWsBlocksPerCU(ctx->scene.nodesQ != nullptr) : traceBlocksPerCU());
-    if (usePool) {
-        const size_t words = tracePoolSpillWords((traceBlocks + kShards - 1) / kShards * kShards);
-        if (ctx->poolSpill.count < words) HIP_TRY(ctx->poolSpill.alloc(words));
-    }
+    // persistent traversal workgroups of the wave-specialised kernel (pt_trace_ws.hip): a fixed number per CU
+    const uint32_t traceBlocks = (uint32_t)ctx->numCUs * (uint32_t)traceWsBlocksPerCU(ctx->scene.nodesQ != nullptr);
 
-    uint32_t parity = 0;
-    uint32_t active = rp.numSlots;
-    uint32_t status[4] = {rp.numSlots, 0u, 0u, 0u};       // device words: live slots, error bits, -, tail mode (PathBuffers)
+    uint32_t active = rp.numPixels * rp.stripes;
+    uint32_t status[4] = {active, 0u, 0u, 0u};       // device words: live slots, error bits, -, tail mode (PathBuffers)
     // The end of the call (pt_tail_kernels.h): once at most tailSlots slots are alive the traversal kernel raises the tail-mode
     // word instead of tracing, the rest of the block of iterations is no-ops, and the tail kernel finishes every remaining path
     // and pass in one launch.  ON when the stripe count is automatic (slrhip_config::stripes = 0: the grouping of a pixel's float
     // sum over its stripes then depends on the shard size anyway), on request otherwise (SLRHIP_FLAG_TAIL_KERNEL,
     // SLRHIP_TAIL_SLOTS=n): a caller who fixes the stripe count keeps the property that the shards of a frame sum to the
     // unsharded frame bit for bit.  Never for more than an eighth of the slots (the wavefront kernels are the efficient way to
-    // advance many paths), not in the counting build (its per-ray figures come from the wavefront kernels) and not for the
-    // four-lanes-per-slot spectral variant.  SLRHIP_TAIL_SLOTS=0 turns it off.
+    // advance many paths; with fewer than 8 slots the tail stays off) and not in the counting build (its per-ray figures come
+    // from the wavefront kernels).  SLRHIP_TAIL_SLOTS=0 turns it off.
     static const long envTail = [] { const char* e = getenv("SLRHIP_TAIL_SLOTS"); return e ? atol(e) : -1L; }();
-    static const bool envQuadLanes = [] { const char* e = getenv("SLRHIP_SPECTRAL_LANES"); return e && std::string(e) == "4"; }();
     {
         const bool asked = (ctx->config.flags & SLRHIP_FLAG_TAIL_KERNEL) != 0 || envTail > 0 || ctx->config.stripes == 0;
         const uint32_t bound = envTail > 0 ? (uint32_t)std::min<long>(envTail, 0x7FFFFFFFL) : kDefaultTailSlots;
-        const bool off = !asked || envTail == 0 || !tailKernelAvailable(ctx->scene, rp.spectral != 0) || (ctx->config.flags & SLRHIP_FLAG_COUNT_TRAVERSAL) != 0 || (rp.spectral && (rp.spectralQuad || envQuadLanes));
-        rp.tailSlots = off ? 0u : std::min(bound, std::max(rp.numSlots / 8u, 1u));
+        const bool off = !asked || envTail == 0 || !tailKernelAvailable(ctx->scene, rp.spectral != 0) || (ctx->config.flags & SLRHIP_FLAG_COUNT_TRAVERSAL) != 0;
+        rp.tailSlots = off ? 0u : std::min(bound, active / 8u);
     }
     // tail mode seen in the status words: list the live slots, finish them, read the words again (live slots must be 0 then)
     const auto runTail = [&](hipStream_t s, bool timed) -> int {
         hipEvent_t t0 = nullptr, t1 = nullptr;
         if (timed) { HIP_TRY(hipEventCreate(&t0)); HIP_TRY(hipEventCreate(&t1)); HIP_TRY(hipEventRecord(t0, s)); }
-        launchTail(ctx->scene, ctx->buffers, rp, status[0], status[3] - 1u, ctx->numCUs, s);
+        launchTail(ctx->scene, ctx->buffers, rp, status[0], ctx->numCUs, s);
         if (timed) HIP_TRY(hipEventRecord(t1, s));
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(status, ctx->activeSlots.ptr, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        const uint32_t liveBefore = status[0];
+        uint32_t words[6] = {0, 0, 0, 0, 0, 0};
+        HIP_TRY(hipMemcpyAsync(words, ctx->activeSlots.ptr, 6 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
+        std::memcpy(status, words, 4 * sizeof(uint32_t));
         if (timed) {
             float ms = 0.0f;
             HIP_TRY(hipEventElapsedTime(&ms, t0, t1));
@@ -850,18 +838,18 @@ int slrhip_render(slrhip_ctx* ctx, uint32_t sppBegin, uint32_t sppCount, void* s
             (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
         }
         if (status[1]) return deviceError(status[1]);
-        if (status[0] != 0) return fail(SLRHIP_ERR_HIP, "slrhip_render: the tail kernel left live slots (internal error)");
+        if (status[0] != 0)
+            return fail(SLRHIP_ERR_HIP, "slrhip_render: the tail kernel left " + std::to_string(status[0]) + " live slots of " + std::to_string(liveBefore) +
+                                            " (listed " + std::to_string(words[4]) + ", cursor " + std::to_string(words[5]) + "; internal error)");
         return SLRHIP_OK;
     };
-    // Each check costs one small copy + stream sync; 16 iterations between checks keeps it < 1 %.
+    // One wavefront iteration = k_shade (advance every live path by one vertex; finish and restart the paths that end) then
+    // k_trace_ws (the extension and shadow rays that left).  Each check of the live-slot word costs one small copy + stream
+    // sync; 16 iterations between checks keeps it < 1 %.
     const int kCheckEvery = 16;
-    const int kEv = 5;    // events per iteration: before regen, after regen, after closest, after shadow, after logic
+    const int kEv = 3;    // events per iteration: before shade, after shade, after trace
     const bool timeKernels = (ctx->config.flags & SLRHIP_FLAG_TIME_KERNELS) != 0;
     const bool count = (ctx->config.flags & SLRHIP_FLAG_COUNT_TRAVERSAL) != 0;
-    const auto launchTrace = [&](uint32_t par, hipStream_t s) {
-        if (usePool) launchTracePool(ctx->scene, ctx->buffers, rp, par, traceBlocks, count, ctx->poolSpill.ptr, s);
-        else launchTraceWs(ctx->scene, ctx->buffers, rp, par, traceBlocks, count, s);
-    };
     if (timeKernels && ctx->events.empty()) {
         ctx->events.resize((size_t)kCheckEvery * kEv);
         for (hipEvent_t& e : ctx->events) HIP_TRY(hipEventCreate(&e));
@@ -871,7 +859,7 @@ int slrhip_render(slrhip_ctx* ctx, uint32_t sppBegin, uint32_t sppCount, void* s
 
     // The block of kCheckEvery iterations is the same sequence of launches every time (the parity alternates inside it and is
     // back to 0 at its end), so it is captured ONCE per call into a hipGraph and replayed: one submission per block instead
-    // of 32-48 launches with their dispatch gaps — what is left of the cost of the nearly empty iterations at the end of a
+    // of 32 launches with their dispatch gaps — what is left of the cost of the nearly empty iterations at the end of a
     // render.  Capture needs a real stream, so the work runs on the context's own stream, ordered after the caller's by an
     // event; render() returns only after that stream is idle, which orders the caller's later work after it.
     static const bool noGraph = [] { const char* e = getenv("SLRHIP_GRAPH"); return e && std::string(e) == "0"; }();
@@ -887,13 +875,8 @@ int slrhip_render(slrhip_ctx* ctx, uint32_t sppBegin, uint32_t sppCount, void* s
         hipGraphExec_t exec = nullptr;
         HIP_TRY(hipStreamBeginCapture(ws, hipStreamCaptureModeThreadLocal));
         for (int k = 0; k < kCheckEvery; ++k) {
-            launchRegen(ctx->scene, ctx->buffers, rp, (uint32_t)(k & 1), ws);
-            if (useWs) launchTrace((uint32_t)(k & 1), ws);
-            else {
-                launchTraceClosest(ctx->scene, ctx->buffers, rp, (uint32_t)(k & 1), traceBlocks, count, ws);
-                launchTraceShadow(ctx->scene, ctx->buffers, rp, (uint32_t)(k & 1), traceBlocks, count, ws);
-            }
-            launchLogic(ctx->scene, ctx->buffers, rp, (uint32_t)(k & 1), ws);
+            launchShade(ctx->scene, ctx->buffers, rp, (uint32_t)(k & 1), ws);
+            launchTraceWs(ctx->scene, ctx->buffers, rp, (uint32_t)(k & 1), traceBlocks, count, ws);
         }
         hipError_t ce = hipStreamEndCapture(ws, &graph);
         if (ce == hipSuccess) ce = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
@@ -924,29 +907,19 @@ int slrhip_render(slrhip_ctx* ctx, uint32_t sppBegin, uint32_t sppCount, void* s
     }
 
     // SLRHIP_ITER_LOG=path (with SLRHIP_FLAG_TIME_KERNELS): per-iteration kernel times of this call, one line per iteration
-    // "iteration regen_ms trace_ms logic_ms live_slots_at_block_end" — how the drain of a render's last paths was measured
+    // "iteration shade_ms trace_ms live_slots_at_block_end" — how the drain of a render's last paths was measured
     static const char* iterLog = getenv("SLRHIP_ITER_LOG");
     std::vector<float> iterMs;
     std::vector<uint32_t> iterActive;
+    uint32_t parity = 0;
     while (active > 0) {
         for (int k = 0; k < kCheckEvery; ++k) {
             hipEvent_t* ev = timeKernels ? &ctx->events[(size_t)k * kEv] : nullptr;
             if (ev) HIP_TRY(hipEventRecord(ev[0], stream));
-            launchRegen(ctx->scene, ctx->buffers, rp, parity, stream);
+            launchShade(ctx->scene, ctx->buffers, rp, parity, stream);
             if (ev) HIP_TRY(hipEventRecord(ev[1], stream));
-            if (useWs) {
-                // both ray kinds in one launch: its time is booked under TRACE_CLOSEST, TRACE_SHADOW counts no launches
-                launchTrace(parity, stream);
-                if (ev) { HIP_TRY(hipEventRecord(ev[2], stream)); HIP_TRY(hipEventRecord(ev[3], stream)); }
-            }
-            else {
-                launchTraceClosest(ctx->scene, ctx->buffers, rp, parity, traceBlocks, count, stream);
-                if (ev) HIP_TRY(hipEventRecord(ev[2], stream));
-                launchTraceShadow(ctx->scene, ctx->buffers, rp, parity, traceBlocks, count, stream);
-                if (ev) HIP_TRY(hipEventRecord(ev[3], stream));
-            }
-            launchLogic(ctx->scene, ctx->buffers, rp, parity, stream);
-            if (ev) HIP_TRY(hipEventRecord(ev[4], stream));
+            launchTraceWs(ctx->scene, ctx->buffers, rp, parity, traceBlocks, count, stream);
+            if (ev) HIP_TRY(hipEventRecord(ev[2], stream));
             parity ^= 1;
             ++it;
         }
@@ -956,11 +929,10 @@ int slrhip_render(slrhip_ctx* ctx, uint32_t sppBegin, uint32_t sppCount, void* s
         active = status[0];
         if (status[1]) return deviceError(status[1]);
         if (timeKernels) {
-            static const int cls[4] = {SLRHIP_KERNEL_REGEN, SLRHIP_KERNEL_TRACE_CLOSEST, SLRHIP_KERNEL_TRACE_SHADOW, SLRHIP_KERNEL_SHADE};
+            static const int cls[2] = {SLRHIP_KERNEL_SHADE, SLRHIP_KERNEL_TRACE};
             for (int k = 0; k < kCheckEvery; ++k) {
                 hipEvent_t* ev = &ctx->events[(size_t)k * kEv];
-                for (int j = 0; j < 4; ++j) {
-                    if (useWs && cls[j] == SLRHIP_KERNEL_TRACE_SHADOW) continue;
+                for (int j = 0; j < 2; ++j) {
                     float ms = 0.0f;
                     HIP_TRY(hipEventElapsedTime(&ms, ev[j], ev[j + 1]));
                     ctx->profMs[cls[j]] += ms;
@@ -1019,12 +991,18 @@ int slrhip_reduce_framebuffer(slrhip_ctx* ctx, void* ncclComm, int root, float* 
     const size_t need = (size_t)rp.imageWidth * rp.imageHeight * (rp.spectral ? 16 : 3);
     if (deviceDst && numFloats < need) return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_reduce_framebuffer: destination too small");
     typedef int (*reduce_fn)(const void*, void*, size_t, int, int, int, void*, hipStream_t);
-    static reduce_fn ncclReduceFn = [] {
+    typedef int (*rank_fn)(void*, int*);
+    static void* rccl = [] {
         void* h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-        if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-        return h ? reinterpret_cast<reduce_fn>(dlsym(h, "ncclReduce")) : nullptr;
+        return h ? h : dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     }();
-    if (!ncclReduceFn) return fail(SLRHIP_ERR_UNSUPPORTED, "slrhip_reduce_framebuffer: librccl.so (ncclReduce) not found");
+    static reduce_fn ncclReduceFn = rccl ? reinterpret_cast<reduce_fn>(dlsym(rccl, "ncclReduce")) : nullptr;
+    static rank_fn ncclCommUserRankFn = rccl ? reinterpret_cast<rank_fn>(dlsym(rccl, "ncclCommUserRank")) : nullptr;
+    if (!ncclReduceFn || !ncclCommUserRankFn) return fail(SLRHIP_ERR_UNSUPPORTED, "slrhip_reduce_framebuffer: librccl.so (ncclReduce) not found");
+    // only the root receives: it must hand over a destination (RCCL would fault on a null recvbuff, not return an error)
+    int myRank = -1;
+    if (ncclCommUserRankFn(ncclComm, &myRank) != 0) return fail(SLRHIP_ERR_HIP, "slrhip_reduce_framebuffer: ncclCommUserRank failed");
+    if (myRank == root && !deviceDst) return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_reduce_framebuffer: the root rank needs a destination buffer");
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(ctx->resolveScratch.alloc(need));
     int rc = slrhip_resolve_framebuffer(ctx, ctx->resolveScratch.ptr, need, streamPtr);
@@ -1117,70 +1095,7 @@ int slrhip_trace_rays(slrhip_ctx* ctx, const float* rays, uint32_t n, float* hit
     return SLRHIP_OK;
 }
 
-// Measurement: closest-hit queries on device-resident rays, repeated and timed with HIP events, under one of the two lane
-// mappings (0: one lane per ray, pt_trace.hip's batch kernel; 1: four lanes per ray, pt_trace_quad.hip).
-int slrhip_trace_rays_timed(slrhip_ctx* ctx, const float* rays, uint32_t n, float* hits, int32_t mapping, uint32_t repeats, float* avgMs) {
-    if (!ctx || !rays || !hits || !avgMs) return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_trace_rays_timed: null argument");
-    if (!ctx->haveScene) return fail(SLRHIP_ERR_NO_SCENE, "slrhip_trace_rays_timed: no scene uploaded");
-    if (mapping != 0 && mapping != 1) return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_trace_rays_timed: mapping is 0 (lane per ray) or 1 (four lanes per ray)");
-    if (mapping == 1 && ctx->quadNodes.count <= 1) return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_trace_rays_timed: mapping 1 needs SLRHIP_FLAG_QUAD_LAYOUT at slrhip_create");
-    if (n == 0 || repeats == 0) return SLRHIP_OK;
-    HIP_TRY(hipSetDevice(ctx->device));
-    std::vector<float4> org(n), dir(n);
-    for (uint32_t i = 0; i < n; ++i) {
-        const float* r = rays + (size_t)i * 8;
-        org[i] = make_float4(r[0], r[1], r[2], r[6]);
-        dir[i] = make_float4(r[3], r[4], r[5], r[7]);
-    }
-    DevArray<float4> dOrg, dDir, dOut;
-    HIP_TRY(dOrg.upload(org));
-    HIP_TRY(dDir.upload(dir));
-    HIP_TRY(dOut.alloc(n));
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
-    auto launch = [&] {
-        if (mapping == 0) launchTraceBatch(ctx->scene, dOrg.ptr, dDir.ptr, dOut.ptr, n, nullptr);
-        else launchTraceQuad(ctx->scene, ctx->quadNodes.ptr, ctx->quadPackets.ptr, dOrg.ptr, dDir.ptr, dOut.ptr, n, nullptr);
-    };
-    launch();                                  // warm-up (caches, code object)
-    HIP_TRY(hipEventRecord(e0, nullptr));
-    for (uint32_t r = 0; r < repeats; ++r) launch();
-    HIP_TRY(hipEventRecord(e1, nullptr));
-    HIP_TRY(hipEventSynchronize(e1));
-    HIP_TRY(hipGetLastError());
-    float ms = 0.0f;
-    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-    *avgMs = ms / (float)repeats;
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    HIP_TRY(hipMemcpy(hits, dOut.ptr, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost));
-    hitsToUV(hits, n);
-    return SLRHIP_OK;
-}
-
-// Diagnostic: the extension rays stored in path slots [first, first + n) (after a render: each slot's last ray).
-int slrhip_debug_read_rays(slrhip_ctx* ctx, uint32_t first, uint32_t n, float* rays) {
-    if (!ctx || !rays) return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_debug_read_rays: null argument");
-    if (!ctx->haveRender || (uint64_t)first + n > ctx->params.numSlots) return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_debug_read_rays: slot range out of bounds");
-    HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipDeviceSynchronize());
-    std::vector<float4> org(n), dir(n);
-    if (ctx->buffers.rayStride == 2) {
-        std::vector<float4> both((size_t)n * 2);
-        HIP_TRY(hipMemcpy(both.data(), ctx->rayOrg.ptr + (size_t)first * 2, both.size() * sizeof(float4), hipMemcpyDeviceToHost));
-        for (uint32_t i = 0; i < n; ++i) { org[i] = both[(size_t)i * 2]; dir[i] = both[(size_t)i * 2 + 1]; }
-    }
-    else {
-        HIP_TRY(hipMemcpy(org.data(), ctx->rayOrg.ptr + first, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(dir.data(), ctx->rayDir.ptr + first, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost));
-    }
-    for (uint32_t i = 0; i < n; ++i) {
-        float* r = rays + (size_t)i * 8;
-        r[0] = org[i].x; r[1] = org[i].y; r[2] = org[i].z; r[3] = dir[i].x; r[4] = dir[i].y; r[5] = dir[i].z; r[6] = org[i].w; r[7] = dir[i].w;
-    }
-    return SLRHIP_OK;
-}
-
+// Diagnostic (include/slrhip_debug.h): function-level BSDF queries through the device functions the shade kernel calls.
 int slrhip_bsdf_queries(slrhip_ctx* ctx, uint32_t material, uint32_t n, const float* queries, float wl_offset, float u_lambda, float* out) {
     if (!ctx || !queries || !out) return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_bsdf_queries: null argument");
     if (!ctx->haveScene) return fail(SLRHIP_ERR_NO_SCENE, "slrhip_bsdf_queries: no scene uploaded");

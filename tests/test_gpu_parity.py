@@ -5,13 +5,20 @@ import os
 import numpy as np
 import pytest
 
-from helpers import assert_bit_equal, load_golden, scene_from_golden
+from helpers import assert_bit_equal, libm_tolerance, load_golden, scene_from_golden
 from oracle import binding as ob
 from slr_amd import Context, abi, scenes
 
 pytestmark = pytest.mark.gpu
 
 SCENES = ["rgb_tiny_box", "rgb_cornell_glass", "rgb_cornell_matte"]
+
+# Floors for helpers.libm_tolerance (fraction of floats within 2e-6 relative of the reference's), one notch under what was
+# measured on MI355X for each scene (profiles/r03_parity_stats.jsonl).  Scenes whose paths never call float libm are not
+# here: they are tested bit for bit.
+TOL = {"rgb_ggx_metal": 0.90, "rgb_ggx_glass": 0.90, "rgb_ward": 0.90, "rgb_ashikhmin": 0.90, "rgb_ibl": 0.90, "rgb_ibl_area": 0.90,
+       "rgb_boxes": 0.90, "rgb_multi": 0.90, "spectral_boxes": 0.90, "spectral_ibl": 0.90, "spectral_ggx_metal": 0.90,
+       "spectral_ggx_glass": 0.90, "spectral_ashikhmin": 0.90, "spectral_multi": 0.90}
 
 
 def frame_stats(a, b):
@@ -180,39 +187,38 @@ def test_spectral_continued_render_matches_single_render(sctx):
     assert_bit_equal(sctx.read_framebuffer(), g["framebuffer"], "both halves")
 
 
-def test_trace_schedules_agree_bit_for_bit(oracle_rgb):
-    """The wave-specialised traversal (producer wave, LDS ray ring, refilled consumer lanes) and the 64-ray-batch kernels
-    must give the same frame and the same ray counts, run after run: enough rays (4.7 M slots, ring wrapping thousands of
-    times per workgroup) that a hand-off race in the ring shows up as a differing hash."""
+def test_wave_specialised_traversal_is_reproducible_and_matches_the_oracle(oracle_rgb):
+    """The wave-specialised traversal (producer wave, LDS ray ring, refilled consumer lanes) must give the same frame and the
+    same ray counts run after run, and the oracle's: enough rays (4.7 M slots, ring wrapping thousands of times per
+    workgroup) that a hand-off race in the ring shows up as a differing hash (round 1 found one exactly so)."""
     sc = scenes.cornell_box_spheres(1.0, 48, 24, "glass")
     st = ob.settings(768, 768, seed=5)
+    want, ctr = oracle_rgb.scene(sc).render(st, 32)
     frames, counts = [], []
-    for flags in (abi.FLAG_TRACE_BATCH, 0, 0):
-        c = Context(stripes=8, flags=flags)
+    for _ in range(2):
+        c = Context(stripes=8)
         frames.append(c.render_image(sc, st, 32))
         k = c.counters()
         counts.append((int(k.extension_rays), int(k.shadow_rays), int(k.samples)))
         c.close()
-    assert counts[0] == counts[1] == counts[2], counts
-    assert_bit_equal(frames[1], frames[0], "wave-specialised vs batch")
-    assert_bit_equal(frames[2], frames[1], "wave-specialised, second run")
+    assert counts[0] == counts[1] == (int(ctr.extension_rays), int(ctr.shadow_rays), int(ctr.samples)), counts
+    assert_bit_equal(frames[1], frames[0], "wave-specialised, second run")
+    assert np.allclose(frames[0], want, rtol=2e-6, atol=1e-9)
 
 
-def test_quantized_nodes_give_the_same_hits():
+def test_quantized_nodes_give_the_same_hits(oracle_rgb):
     """Trees of >= 64 Ki nodes are traversed through 64-byte nodes with 8-bit child boxes (rounded outwards on the host):
-    a superset of the float boxes, so frame and ray counts must equal those of the batch kernels on the float nodes."""
+    a superset of the float boxes, so frame and ray counts must equal the oracle's (its own binary tree, float boxes)."""
     sc = scenes.displaced_grid(400, 16.0 / 9.0)
     st = ob.settings(320, 180, seed=9)
-    frames, counts = [], []
-    for flags in (abi.FLAG_TRACE_BATCH, 0):
-        c = Context(stripes=4, flags=flags)
-        frames.append(c.render_image(sc, st, 16))
-        k = c.counters()
-        assert k.bvh_nodes >= 65536
-        counts.append((int(k.extension_rays), int(k.shadow_rays), int(k.samples)))
-        c.close()
-    assert counts[0] == counts[1], counts
-    assert_bit_equal(frames[1], frames[0], "quantized wave-specialised vs float batch")
+    want, ctr = oracle_rgb.scene(sc).render(st, 16)
+    c = Context(stripes=1)
+    fb = c.render_image(sc, st, 16)
+    k = c.counters()
+    c.close()
+    assert k.bvh_nodes >= 65536
+    assert (int(k.extension_rays), int(k.shadow_rays), int(k.samples)) == (int(ctr.extension_rays), int(ctr.shadow_rays), int(ctr.samples))
+    assert_bit_equal(fb, want, "quantized wave-specialised vs the oracle")
 
 
 def test_quantized_grid_against_oracle_and_reference_golden(oracle_rgb):
@@ -265,28 +271,23 @@ def test_quantized_grid_against_oracle_and_reference_golden(oracle_rgb):
 def test_spectral_boxes_against_oracle_and_reference_golden(sctx, oracle_spectral):
     """BASELINE configs[2] exactly: scenes.cornell_box_boxes() (GGX titanium box, alpha_g 0.1, + matte box) in SPECTRAL mode.
     Against the compiled spectral reference's golden (MicrofacetBSDF.cpp:11-110 on its own BSDF objects) and, at 128x128x16 spp,
-    against the oracle: the float-libm tolerance of the GGX tests (device acosf / tanf / atan2f differ from glibc in the last
-    ulp): RMSE <= 1e-3 x mean, >= 90 % of floats within 1e-4 relative; ray counts within 1e-3."""
+    against the oracle: the float-libm tolerance of helpers.libm_tolerance (device acosf / tanf / atan2f differ from glibc in
+    the last ulp); ray counts within 1e-4."""
     g = load_golden("spectral_boxes")
     st = ob.settings(int(g["width"]), int(g["height"]), int(g["seed"]))
     fb = sctx.render_image(scene_from_golden(g), st, int(g["spp"]))
     want = g["framebuffer"]
     assert fb.shape == want.shape and fb.shape[2] == 16
-    s = frame_stats(fb, want)
-    assert s["rmse"] <= 1e-3 * s["mean"], s
-    assert np.isclose(fb, want, rtol=1e-4, atol=1e-9).mean() >= 0.90
-    assert np.isfinite(fb).all()
+    libm_tolerance(fb, want, "spectral_boxes vs reference golden", within=TOL["spectral_boxes"])
     sc = scenes.cornell_box_boxes()
     st = ob.settings(128, 128, seed=3)
     want, ctr = oracle_spectral.scene(sc).render(st, 16)
     fb = sctx.render_image(sc, st, 16)
-    s = frame_stats(fb, want)
-    assert s["rmse"] <= 1e-3 * s["mean"], s
-    assert np.isclose(fb, want, rtol=1e-4, atol=1e-9).mean() >= 0.90
+    libm_tolerance(fb, want, "spectral boxes 128x128x16 vs oracle", within=TOL["spectral_boxes"])
     k = sctx.counters()
     assert int(k.samples) == int(ctr.samples) == 128 * 128 * 16
-    assert abs(int(k.extension_rays) - int(ctr.extension_rays)) <= ctr.extension_rays * 1e-3
-    assert abs(int(k.shadow_rays) - int(ctr.shadow_rays)) <= ctr.shadow_rays * 1e-3
+    assert abs(int(k.extension_rays) - int(ctr.extension_rays)) <= ctr.extension_rays * 1e-4
+    assert abs(int(k.shadow_rays) - int(ctr.shadow_rays)) <= ctr.shadow_rays * 1e-4
 
 
 def test_first_render_call_may_start_at_a_later_pass(ctx, oracle_rgb):
@@ -340,7 +341,7 @@ def test_two_contexts_on_non_blocking_streams_from_two_threads(oracle_rgb):
     SPP = 32
     o = oracle_rgb.scene(sc)
     halves = [o.render(st, SPP // 2, spp_begin=i * SPP // 2)[0].copy() for i in range(2)]
-    for attempt in range(3):
+    for attempt in range(1):      # the fix is a stream-order change, deterministic by construction: one pass is the test
         ctxs = [Context(stripes=4), Context(stripes=4)]
         streams = [non_blocking_stream(), non_blocking_stream()]
         got, errors = [None, None], []
@@ -361,48 +362,6 @@ def test_two_contexts_on_non_blocking_streams_from_two_threads(oracle_rgb):
         assert not errors, errors
         for i in range(2):
             assert np.allclose(got[i], halves[i], rtol=2e-6, atol=1e-9), "context %d, attempt %d" % (i, attempt)
-
-
-def test_four_lanes_per_ray_mapping_returns_the_same_hits(oracle_rgb):
-    """The lane-mapping experiment (pt_trace_quad.hip: four lanes = one ray, one child box / one leaf triangle per lane) is only
-    a fair experiment if it answers the same question: on the reference's golden rays, on 200 000 real secondary rays of a
-    render (every slot's last extension ray) and on the displaced grid, its hits equal the lane-per-ray kernel's bit for bit
-    — t, both barycentrics and the triangle the tie rule picks — and the golden's."""
-    for name, make in (("rgb_cornell_glass", None), ("grid", lambda: scenes.displaced_grid(160, 16.0 / 9.0))):
-        c = Context(stripes=4, flags=abi.FLAG_QUAD_LAYOUT)
-        try:
-            if make is None:
-                g = load_golden(name)
-                sc = scene_from_golden(g)
-                r = g["rays"]
-                rays = np.concatenate([r["org"], r["dir"], r["dist_min"][:, None], r["dist_max"][:, None]], axis=1).astype(np.float32)
-            else:
-                sc, rays = make(), np.zeros((0, 8), np.float32)
-            st = ob.settings(320, 200, seed=3)
-            c.upload_scene(sc)
-            c.render_begin(st)
-            c.render(0, 8)
-            slot_rays = c.read_slot_rays(0, 200_000)
-            slot_rays = slot_rays[np.isfinite(slot_rays[:, :7]).all(axis=1) & (np.abs(slot_rays[:, 3:6]).sum(axis=1) > 0)]
-            rays = np.concatenate([rays, slot_rays])
-            lane, _ = c.trace_rays_timed(rays, 0, repeats=1)
-            quad, _ = c.trace_rays_timed(rays, 1, repeats=1)
-            assert (lane.view(np.uint32) == quad.view(np.uint32)).all(), name
-            assert (lane[:, 0].view(np.uint32) != 0xFFFFFFFF).mean() > 0.02       # (most last rays of the open grid scene leave it)
-            if make is None:
-                want = g["hits"]
-                assert (quad[:len(want), 0].view(np.uint32) == want["triangle"]).all()
-                hit = want["triangle"] != 0xFFFFFFFF
-                assert_bit_equal(quad[:len(want), 1][hit], want["dist"][hit], "quad dist vs golden")
-        finally:
-            c.close()
-    with pytest.raises(Exception, match="QUAD_LAYOUT"):
-        ctx2 = Context()
-        try:
-            ctx2.upload_scene(scenes.tiny_box(1.0))
-            ctx2.trace_rays_timed(np.zeros((4, 8), np.float32) + 1, 1)
-        finally:
-            ctx2.close()
 
 
 def test_spatial_split_tree_gives_the_same_image(oracle_rgb):
@@ -447,8 +406,8 @@ def test_textured_scene_matches_reference_golden(name):
     mode = abi.MODE_SPECTRAL if name.startswith("spectral") else abi.MODE_RGB
     sc = scene_from_golden(g)
     st = ob.settings(int(g["width"]), int(g["height"]), int(g["seed"]))
-    for flags in (0, abi.FLAG_TRACE_BATCH):
-        c = Context(mode=mode, stripes=1, flags=flags | abi.FLAG_QUAD_LAYOUT)
+    for flags in (0,):
+        c = Context(mode=mode, stripes=1, flags=flags)
         try:
             fb = c.render_image(sc, st, int(g["spp"]))
             assert_bit_equal(fb, g["framebuffer"], name + " frame")
@@ -460,9 +419,6 @@ def test_textured_scene_matches_reference_golden(name):
             assert_bit_equal(dist[hit], want["dist"][hit], "dist")
             assert_bit_equal(b0[hit], want["b0"][hit], "b0")
             assert_bit_equal(b1[hit], want["b1"][hit], "b1")
-            rays8 = np.concatenate([r["org"], r["dir"], r["dist_min"][:, None], r["dist_max"][:, None]], axis=1).astype(np.float32)
-            quad, _ = c.trace_rays_timed(rays8, 1, repeats=1)          # the four-lanes-per-ray kernel runs the alpha test too
-            assert (quad[:, 0].view(np.uint32) == want["triangle"]).all()
         finally:
             c.close()
     # a larger frame with the automatic stripe count against the oracle
@@ -513,16 +469,11 @@ def test_oren_nayar_matches_reference_golden(ctx, name):
 def test_ggx_matches_reference_golden_within_tolerance(ctx, name):
     """(Also the Ward and Ashikhmin-Shirley lobes: expf, logf, atanf, powf, double pow.)  GGX calls float libm (acosf, atan2f, tanf, cosf, sinf): the device library can differ from glibc in the last ulp,
     which perturbs a sample by ~1e-7 relative and, rarely, flips a discrete decision.  Tolerance (north_star: per-pixel
-    RMSE < 1e-3): RMSE <= 1e-3 x mean radiance, >= 90 % of floats within 1e-4 relative, samples counted exactly."""
+    RMSE < 1e-3): helpers.libm_tolerance with the per-scene floor of TOL."""
     g = load_golden(name)
     st = ob.settings(int(g["width"]), int(g["height"]), int(g["seed"]))
     fb = ctx.render_image(scene_from_golden(g), st, int(g["spp"]))
-    want = g["framebuffer"]
-    s = frame_stats(fb, want)
-    close = np.isclose(fb, want, rtol=1e-4, atol=1e-9)
-    assert s["rmse"] <= 1e-3 * s["mean"], s
-    assert close.mean() >= 0.90, (close.mean(), s)
-    assert np.isfinite(fb).all()
+    libm_tolerance(fb, g["framebuffer"], name + " vs reference golden", within=TOL[name])
 
 
 @pytest.mark.parametrize("name", ["rgb_ibl", "rgb_ibl_area"])
@@ -533,14 +484,7 @@ def test_environment_light_matches_reference_golden_within_tolerance(ctx, name):
     g = load_golden(name)
     st = ob.settings(int(g["width"]), int(g["height"]), int(g["seed"]))
     fb = ctx.render_image(scene_from_golden(g), st, int(g["spp"]))
-    want = g["framebuffer"]
-    s = frame_stats(fb, want)
-    close = np.isclose(fb, want, rtol=1e-4, atol=1e-9)
-    assert close.mean() >= 0.95, (close.mean(), s)
-    cap = 10 * float(want.mean())
-    sc = frame_stats(np.minimum(fb, cap), np.minimum(want, cap))
-    assert sc["rmse"] <= 1e-3 * sc["mean"], (sc, s)
-    assert np.isfinite(fb).all()
+    libm_tolerance(fb, g["framebuffer"], name + " vs reference golden", within=TOL[name], cap=10)
     assert ctx.counters().samples == int(g["width"]) * int(g["height"]) * int(g["spp"])
 
 
@@ -549,10 +493,10 @@ def test_environment_light_full_size_against_oracle(ctx, oracle_rgb):
     st = ob.settings(160, 90, seed=11)
     want, ctr = oracle_rgb.scene(sc).render(st, 16)
     fb = ctx.render_image(sc, st, 16)
-    assert np.isclose(fb, want, rtol=1e-4, atol=1e-9).mean() >= 0.95
+    libm_tolerance(fb, want, "environment light 160x90x16 vs oracle", within=TOL["rgb_ibl"], cap=10)
     c = ctx.counters()
-    assert abs(int(c.extension_rays) - int(ctr.extension_rays)) <= ctr.extension_rays * 1e-3
-    assert abs(int(c.shadow_rays) - int(ctr.shadow_rays)) <= ctr.shadow_rays * 1e-3
+    assert abs(int(c.extension_rays) - int(ctr.extension_rays)) <= ctr.extension_rays * 1e-4
+    assert abs(int(c.shadow_rays) - int(ctr.shadow_rays)) <= ctr.shadow_rays * 1e-4
 
 
 def test_spectral_environment_light_matches_reference_golden_within_tolerance(sctx):
@@ -563,12 +507,7 @@ def test_spectral_environment_light_matches_reference_golden_within_tolerance(sc
     fb = sctx.render_image(scene_from_golden(g), st, int(g["spp"]))
     want = g["framebuffer"]
     assert fb.shape == want.shape and fb.shape[2] == 16
-    close = np.isclose(fb, want, rtol=1e-4, atol=1e-9)
-    assert close.mean() >= 0.95, close.mean()
-    cap = 10 * float(want.mean())
-    sc = frame_stats(np.minimum(fb, cap), np.minimum(want, cap))
-    assert sc["rmse"] <= 1e-3 * sc["mean"], sc
-    assert np.isfinite(fb).all()
+    libm_tolerance(fb, want, "spectral_ibl vs reference golden", within=TOL["spectral_ibl"], cap=10)
 
 
 def test_spectral_environment_needs_the_upsampling_tables(sctx):
@@ -588,11 +527,9 @@ def test_boxes_scene_against_oracle(ctx, oracle_rgb):
     st = ob.settings(128, 128, seed=3)
     want, ctr = oracle_rgb.scene(sc).render(st, 16)
     fb = ctx.render_image(sc, st, 16)
-    s = frame_stats(fb, want)
-    assert s["rmse"] <= 1e-3 * s["mean"], s
-    assert np.isclose(fb, want, rtol=1e-4, atol=1e-9).mean() >= 0.95
+    libm_tolerance(fb, want, "boxes RGB 128x128x16 vs oracle", within=TOL["rgb_boxes"])
     c = ctx.counters()
-    assert abs(int(c.extension_rays) - int(ctr.extension_rays)) <= ctr.extension_rays * 1e-3
+    assert abs(int(c.extension_rays) - int(ctr.extension_rays)) <= ctr.extension_rays * 1e-4
 
 
 @pytest.fixture(scope="module")
@@ -619,25 +556,7 @@ def test_spectral_ggx_within_tolerance(sctx, name):
     g = load_golden(name)
     st = ob.settings(int(g["width"]), int(g["height"]), int(g["seed"]))
     fb = sctx.render_image(scene_from_golden(g), st, int(g["spp"]))
-    want = g["framebuffer"]
-    s = frame_stats(fb, want)
-    assert s["rmse"] <= 1e-3 * s["mean"], s
-    assert np.isclose(fb, want, rtol=1e-4, atol=1e-9).mean() >= 0.90
-    assert np.isfinite(fb).all()
-
-
-@pytest.mark.parametrize("name", ["spectral_cornell_glass", "spectral_ggx_metal"])
-def test_spectral_quad_kernel_matches_the_one_lane_kernel(name):
-    """SLRHIP_FLAG_SPECTRAL_QUAD: the 16 samples of a path spread over four lanes (DPP broadcasts, in-order cross-lane running
-    sum).  Same arithmetic in the same order, so the frame must equal the one-lane kernel's bit for bit."""
-    g = load_golden(name)
-    st = ob.settings(int(g["width"]), int(g["height"]), int(g["seed"]))
-    frames = []
-    for flags in (0, abi.FLAG_SPECTRAL_QUAD):
-        c = Context(mode=abi.MODE_SPECTRAL, stripes=1, flags=flags)
-        frames.append(c.render_image(scene_from_golden(g), st, int(g["spp"])))
-        c.close()
-    assert_bit_equal(frames[1], frames[0], name + ": quad vs one lane")
+    libm_tolerance(fb, g["framebuffer"], name + " vs reference golden", within=TOL[name])
 
 
 def test_spectral_mode_rejects_rgb_only_spectra(sctx):
@@ -681,7 +600,7 @@ def _assert_lobe_close(got, want, what, exact_rows_floor, far_fraction, far_rel,
 
 @pytest.mark.parametrize("mode", ["rgb", "spectral"])
 def test_bsdf_queries_match_golden_and_oracle(mode):
-    """slrhip_bsdf_queries runs the same device functions k_logic calls.  Against the compiled reference's answers
+    """slrhip_bsdf_queries runs the same device functions k_shade calls.  Against the compiled reference's answers
     (tests/golden/bsdf_kat_*.npz) and, on 4096 fresh queries per lobe, against the oracle.  Lobes without float libm
     calls: every float bit-exact.  The others: the tolerance stated in _assert_lobe_close."""
     g = load_golden("bsdf_kat_" + mode)
@@ -744,10 +663,7 @@ def test_multibsdf_frame_matches_reference_golden(name):
 def test_multibsdf_with_ggx_component_within_tolerance(name):
     """The same scene with a GGX component in the mix: the float-libm tolerance of the GGX tests."""
     fb, want = _render_golden(name)
-    s = frame_stats(fb, want)
-    assert s["rmse"] <= 1e-3 * s["mean"], s
-    assert np.isclose(fb, want, rtol=1e-4, atol=1e-9).mean() >= 0.90
-    assert np.isfinite(fb).all()
+    libm_tolerance(fb, want, name + " vs reference golden", within=TOL[name])
 
 
 def test_multibsdf_rejects_what_it_does_not_support(ctx):
@@ -897,10 +813,10 @@ def test_sample_pool_is_reproducible_and_complete(oracle_rgb):
 @pytest.mark.parametrize("mode", [abi.MODE_RGB, abi.MODE_SPECTRAL])
 def test_tail_kernel_gives_the_frame_of_the_wavefront_iterations(mode):
     """Once few slots are live the rest of a render call is ONE launch (k_tail: each remaining slot taken to its end by one lane,
-    through the same logicSlot / accumulateSample / startSample code as k_logic / k_regen and the one-lane-per-ray traversal).
+    through the same logicSlot / accumulateSample / startSample code as k_shade and the one-lane-per-ray traversal).
     On request (SLRHIP_FLAG_TAIL_KERNEL).  Against the pure wavefront schedule: the same samples (sample and ray counts equal), with one stripe
     the same frame bit for bit; with more stripes only the grouping of a pixel's float sum over its stripes may differ.  Also
-    for a render continued in a second call, more stripes than passes, and the batch traversal kernels; and reproducible."""
+    for a render continued in a second call and more stripes than passes; and reproducible."""
     if os.environ.get("SLRHIP_TAIL_SLOTS") == "0":
         pytest.skip("the tail kernel is switched off in this environment")
     sc = scenes.cornell_box_spheres(1.0, 16, 8, "glass")
@@ -915,9 +831,9 @@ def test_tail_kernel_gives_the_frame_of_the_wavefront_iterations(mode):
         fb = c.read_framebuffer()
         ctr, prof = c.counters(), c.profile()
         c.close()
-        return fb, (int(ctr.samples), int(ctr.extension_rays), int(ctr.shadow_rays)), int(prof.launches[4])
+        return fb, (int(ctr.samples), int(ctr.extension_rays), int(ctr.shadow_rays)), int(prof.launches[2])
 
-    for stripes, calls, extra in ((1, ((0, 24),), 0), (8, ((0, 40),), 0), (8, ((0, 24), (24, 16)), 0), (64, ((0, 16),), 0), (8, ((0, 40),), abi.FLAG_TRACE_BATCH)):
+    for stripes, calls, extra in ((1, ((0, 24),), 0), (8, ((0, 40),), 0), (8, ((0, 24), (24, 16)), 0), (64, ((0, 16),), 0)):
         want, counts_w, tails_w = run(extra, stripes, calls)
         got, counts_g, tails_g = run(abi.FLAG_TAIL_KERNEL | extra, stripes, calls)
         again, counts_a, _ = run(abi.FLAG_TAIL_KERNEL | extra, stripes, calls)
@@ -929,30 +845,6 @@ def test_tail_kernel_gives_the_frame_of_the_wavefront_iterations(mode):
             assert_bit_equal(got, want, "tail kernel vs wavefront iterations, one stripe")
         else:
             assert np.allclose(got, want, rtol=5e-6, atol=1e-9), (stripes, calls)
-
-
-@pytest.mark.gpu
-def test_ldsresident_pool_traversal_gives_the_same_frames():
-    """SLRHIP_FLAG_TRACE_POOL: the experimental traversal schedule that keeps a consumer wave's rays in LDS and runs dense node and
-    triangle phases (hits merged by a 64-bit LDS atomic min on (t, ~index): the same closest hit and the same tie rule).  Same
-    hits => the same frame bit for bit, the same ray counts, the same node / triangle counts per ray — on a float-node tree with
-    an alpha-tested, textured scene and on a quantized-node tree (>= 64 Ki nodes)."""
-    cases = [(scenes.cornell_textured(1.0, 10, 5), ob.settings(96, 72, seed=5), 8, abi.MODE_RGB),
-             (scenes.cornell_box_spheres(1.0, 16, 8, "glass"), ob.settings(64, 48, seed=6), 8, abi.MODE_SPECTRAL),
-             (scenes.displaced_grid(400, 4.0 / 3.0), ob.settings(96, 72, seed=7), 4, abi.MODE_RGB)]
-    for sc, st, spp, mode in cases:
-        out = []
-        for flags in (0, abi.FLAG_TRACE_POOL):
-            c = Context(mode=mode, flags=flags | abi.FLAG_COUNT_TRAVERSAL)
-            fb = c.render_image(sc, st, spp)
-            ctr, prof = c.counters(), c.profile()
-            out.append((fb, (int(ctr.extension_rays), int(ctr.shadow_rays)), (int(prof.nodes[0]), int(prof.nodes[1])), (int(prof.triangles[0]), int(prof.triangles[1]))))
-            c.close()
-        assert out[0][1] == out[1][1] and out[0][2] == out[1][2], (out[0][1:], out[1][1:])
-        # a shadow ray stops at its first accepted triangle in the default schedule; the pool tests a whole leaf at once
-        assert out[0][3][0] == out[1][3][0] and out[1][3][1] >= out[0][3][1]
-        assert_bit_equal(out[1][0], out[0][0], "LDS-resident pool traversal vs the default schedule")
-        assert out[0][0].sum() > 0
 
 
 @pytest.mark.gpu
@@ -974,7 +866,7 @@ def test_tail_kernel_variants_match_the_wavefront_iterations_bit_for_bit():
             c = Context(mode=mode, stripes=1, flags=flags | abi.FLAG_TIME_KERNELS)
             fb = c.render_image(sc, st, 6)
             ctr, prof = c.counters(), c.profile()
-            out.append((fb, (int(ctr.samples), int(ctr.extension_rays), int(ctr.shadow_rays)), int(prof.launches[4])))
+            out.append((fb, (int(ctr.samples), int(ctr.extension_rays), int(ctr.shadow_rays)), int(prof.launches[2])))
             c.close()
         # spectral scenes with MultiBSDF materials or textures have no tail kernel (not built: compile time) and stay on the wavefront
         expect = 0 if name in ("multi spectral", "textured spectral") else 1
