@@ -52,11 +52,11 @@ def assert_bit_equal(a, b, what=""):
     assert not bad.any(), "%s: %d of %d floats differ, max abs diff %g" % (what, bad.sum(), bad.size, np.abs(a - b).max())
 
 
-def libm_tolerance(got, want, what, within=0.999, rtol=2e-6, rmse_rel=1e-3, cap=None):
+def libm_tolerance(got, want, what, within=0.999, rtol=2e-6, rmse_rel=2e-5, cap=None):
     """Frames whose paths call float libm (GGX / Ward / Ashikhmin lobes, the environment sphere): the device math library is not
     glibc, so a sample moves by an ulp and — rarely — a discrete decision flips.  Stated tolerance: at least `within` of the
-    floats inside `rtol` relative (thresholds one notch under the figures measured on MI355X: profiles/r03_parity_stats.jsonl,
-    written by this function on the GPU box), RMSE <= `rmse_rel` x the mean (on frames clipped at `cap` x the mean where single
+    floats inside `rtol` relative (thresholds one notch under the figures measured on MI355X: profiles/r03_a_parity_stats.jsonl,
+    written by this function on the GPU box), RMSE <= `rmse_rel` x the mean (measured <= 1.3e-6; north_star's bound is 1e-3; on frames clipped at `cap` x the mean where single
     texels are hundreds of times the mean), everything finite."""
     import json
     got, want = np.asarray(got), np.asarray(want)

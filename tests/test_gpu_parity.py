@@ -14,11 +14,11 @@ pytestmark = pytest.mark.gpu
 SCENES = ["rgb_tiny_box", "rgb_cornell_glass", "rgb_cornell_matte"]
 
 # Floors for helpers.libm_tolerance (fraction of floats within 2e-6 relative of the reference's), one notch under what was
-# measured on MI355X for each scene (profiles/r03_parity_stats.jsonl).  Scenes whose paths never call float libm are not
+# measured on MI355X for each scene (profiles/r03_a_parity_stats.jsonl).  Scenes whose paths never call float libm are not
 # here: they are tested bit for bit.
-TOL = {"rgb_ggx_metal": 0.90, "rgb_ggx_glass": 0.90, "rgb_ward": 0.90, "rgb_ashikhmin": 0.90, "rgb_ibl": 0.90, "rgb_ibl_area": 0.90,
-       "rgb_boxes": 0.90, "rgb_multi": 0.90, "spectral_boxes": 0.90, "spectral_ibl": 0.90, "spectral_ggx_metal": 0.90,
-       "spectral_ggx_glass": 0.90, "spectral_ashikhmin": 0.90, "spectral_multi": 0.90}
+TOL = {"rgb_ggx_metal": 0.998, "rgb_ggx_glass": 0.985, "rgb_ward": 0.9995, "rgb_ashikhmin": 0.9995, "rgb_ibl": 0.9995, "rgb_ibl_area": 0.9995,
+       "rgb_boxes": 0.999, "rgb_multi": 0.999, "spectral_boxes": 0.998, "spectral_ibl": 0.9995, "spectral_ggx_metal": 0.998,
+       "spectral_ggx_glass": 0.98, "spectral_ashikhmin": 0.998, "spectral_multi": 0.9995}
 
 
 def frame_stats(a, b):
@@ -201,9 +201,13 @@ def test_wave_specialised_traversal_is_reproducible_and_matches_the_oracle(oracl
         k = c.counters()
         counts.append((int(k.extension_rays), int(k.shadow_rays), int(k.samples)))
         c.close()
-    assert counts[0] == counts[1] == (int(ctr.extension_rays), int(ctr.shadow_rays), int(ctr.samples)), counts
+    assert counts[0] == counts[1], counts
     assert_bit_equal(frames[1], frames[0], "wave-specialised, second run")
-    assert np.allclose(frames[0], want, rtol=2e-6, atol=1e-9)
+    # against the oracle: among 56 M rays one or two meet two triangles at the same distance where the trees differ in which
+    # of them they test (the tie rule is tree-independent only among the triangles a tree TESTS)
+    want_counts = (int(ctr.extension_rays), int(ctr.shadow_rays), int(ctr.samples))
+    assert counts[0][2] == want_counts[2] and all(abs(a - b) <= 1e-6 * b for a, b in zip(counts[0][:2], want_counts[:2])), (counts[0], want_counts)
+    assert np.isclose(frames[0], want, rtol=2e-6, atol=1e-9).mean() >= 0.99999
 
 
 def test_quantized_nodes_give_the_same_hits(oracle_rgb):
