@@ -291,27 +291,40 @@ template <class S> struct SpAcc;
 // (state FIRST_HIT) supplies the values instead of what it loaded.  RGB keeps the pair in registers and always stores it,
 // so it is valid from then on; the spectral variants update HBM only when a contribution arrives and track that in `valid`
 // (flag bit 10), which k_regen consults before reading the sum.
+#ifndef SLR_SP_LAZY
+#define SLR_SP_LAZY 1      // 0 (variant builds): read and write the RGB radiance sum, its compensation and the pending light sample at every visit
+#endif
 template <> struct SpAcc<RGB> {
+    // The Kahan pair is read only once the path has written it (flag bit 10) and written back only by a visit that added to it;
+    // the pending light sample only by a visit that has one (flag bit 14).  Most visits do neither: a first hit adds only on an
+    // emitter, a later one when its shadow ray came back visible or the ray found a light.
     RGB r, c, nee;
-    __device__ __forceinline__ void begin(const PathBuffers& pb, uint32_t slot, uint32_t n) {
+    bool valid, changed;
+    __device__ __forceinline__ void begin(const PathBuffers& pb, uint32_t slot, uint32_t n, uint32_t flags) {
         float unused;
-        SpecIO<RGB>::load(pb.spR, nullptr, slot * pb.spStride, n * pb.spStride, r, unused);
-        SpecIO<RGB>::load(pb.spC, nullptr, slot * pb.spStride, n * pb.spStride, c, unused);
-        SpecIO<RGB>::load(pb.nee, nullptr, slot, n, nee, unused);
+        valid = !SLR_SP_LAZY || (F_STATE(flags) != ST_FIRST_HIT && F_SPVALID(flags));
+        changed = !SLR_SP_LAZY;
+        r = RGB(); c = RGB(); nee = RGB();
+        if (valid) {
+            SpecIO<RGB>::load(pb.spR, nullptr, slot * pb.spStride, n * pb.spStride, r, unused);
+            SpecIO<RGB>::load(pb.spC, nullptr, slot * pb.spStride, n * pb.spStride, c, unused);
+        }
+        if (!SLR_SP_LAZY || F_SHADOW(flags)) SpecIO<RGB>::load(pb.nee, nullptr, slot, n, nee, unused);
     }
     __device__ __forceinline__ void startPath(bool first, uint32_t) { if (first) { r = RGB(); c = RGB(); } }
-    __device__ __forceinline__ uint32_t validBits() const { return 1u << 10; }
+    __device__ __forceinline__ uint32_t validBits() const { return (valid || changed) ? 1u << 10 : 0u; }
     __device__ __forceinline__ RGB total() const { return r; }
-    __device__ __forceinline__ void addPendingNee(const PathBuffers&, uint32_t, uint32_t) { kahanAdd(r, c, nee); }
-    __device__ __forceinline__ void add(const PathBuffers&, uint32_t, uint32_t, const RGB& v) { kahanAdd(r, c, v); }
+    __device__ __forceinline__ void addPendingNee(const PathBuffers&, uint32_t, uint32_t) { kahanAdd(r, c, nee); changed = true; }
+    __device__ __forceinline__ void add(const PathBuffers&, uint32_t, uint32_t, const RGB& v) { kahanAdd(r, c, v); changed = true; }
     __device__ __forceinline__ void end(const PathBuffers& pb, uint32_t slot, uint32_t n, bool pathContinues) {
+        if (!changed) return;
         SpecIO<RGB>::store(pb.spR, nullptr, slot * pb.spStride, n * pb.spStride, r, 0.0f);
         if (pathContinues) SpecIO<RGB>::store(pb.spC, nullptr, slot * pb.spStride, n * pb.spStride, c, 0.0f);       // a finished path only hands over the sum
     }
 };
 template <> struct SpAcc<Spec16> {
     bool valid;
-    __device__ __forceinline__ void begin(const PathBuffers&, uint32_t, uint32_t) {}
+    __device__ __forceinline__ void begin(const PathBuffers&, uint32_t, uint32_t, uint32_t) {}
     __device__ __forceinline__ void startPath(bool first, uint32_t flags) { valid = !first && F_SPVALID(flags); }
     __device__ __forceinline__ uint32_t validBits() const { return valid ? 1u << 10 : 0u; }
     __device__ __forceinline__ Spec16 total() const { return Spec16(); }      // the sum is in HBM (flag bit 10 says whether it was ever written)
@@ -416,7 +429,7 @@ __device__ __forceinline__ void logicSlot(const DevScene& sc, const PathBuffers&
     SpAcc<S> sp;
     float bsdfPDFprev;
     SpecIO<S>::load(pb.alpha, pb.pdfPrev, slot, rp.numSlots, alpha, bsdfPDFprev);
-    sp.begin(pb, slot, rp.numSlots);
+    sp.begin(pb, slot, rp.numSlots, flags);
     const float4 h = pb.hit[slot];
     const float4 o4 = pb.rayOrg[(size_t)slot * pb.rayStride], d4 = pb.rayDir[(size_t)slot * pb.rayStride];
     const uint32_t vis = pb.visible[slot];
