@@ -20,6 +20,8 @@
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "pt_device.h"
 #include "pt_kernels.h"
 #include "pt_tex.h"
@@ -48,22 +50,16 @@ static const bool kNoSpill = true;
 static const bool kNoSpill = false;
 #endif
 static const uint32_t kIdle = 0xFFFFFFFFu;
+// SLR_WS_TOP (variant builds; 0 = off, the default): the first SLR_WS_TOP nodes of the breadth-first tree — levels 0-3 of a
+// four-wide tree are 85 nodes — are staged in LDS by every workgroup and read from there (north_star's "nodes staged through
+// LDS"; DESIGN.md has the measurement that decided the default).  128-byte nodes in rows of 144 B, 64-byte quantized nodes in
+// rows of 80 B, so that lanes at different nodes spread over the banks.
+#ifndef SLR_WS_TOP
+#define SLR_WS_TOP 0
+#endif
+static const uint32_t kTop = SLR_WS_TOP;
 
 static int wsConsumers(bool quantized) { return g_consumers ? g_consumers : (quantized ? 15 : 7); }
-
-int traceWsBlocksPerCU(bool quantized) {
-    static const bool init = [] {
-        if (const char* e = getenv("SLRHIP_WS_REFILL")) g_refill = (uint32_t)atoi(e);
-        if (const char* e = getenv("SLRHIP_WS_NC")) { const int n = atoi(e); g_consumers = n == 3 ? 3 : n == 15 ? 15 : n == 7 ? 7 : 0; }
-        if (g_refill < 1) g_refill = 1;
-        if (g_refill > 64) g_refill = 64;
-        return true;
-    }();
-    (void)init;
-    if (const char* e = getenv("SLRHIP_WS_BLOCKS_PER_CU")) { const int b = atoi(e); if (b >= 1 && b <= 8) return b; }   // experiments
-    const int nc = wsConsumers(quantized);
-    return nc == 15 ? 2 : nc == 7 ? 4 : 8;       // 18.5 / 39.5 / 64.5 KiB of LDS per workgroup, 32 waves per CU either way (<= 64 VGPR)
-}
 
 template <int NC>
 struct WsLds {
@@ -77,7 +73,24 @@ struct WsLds {
     uint32_t released;                     // entries consumers have finished reading (ring space)
     uint32_t done;                         // producer has published its last entry
     uint32_t red[NC + 1];
+    float4 top[kTop ? kTop * 9 : 1];       // SLR_WS_TOP: staged nodes, row stride 9 (float nodes) or 5 (quantized) float4
 };
+
+int traceWsBlocksPerCU(bool quantized) {
+    static const bool init = [] {
+        if (const char* e = getenv("SLRHIP_WS_REFILL")) g_refill = (uint32_t)atoi(e);
+        if (const char* e = getenv("SLRHIP_WS_NC")) { const int n = atoi(e); g_consumers = n == 3 ? 3 : n == 15 ? 15 : n == 7 ? 7 : 0; }
+        if (g_refill < 1) g_refill = 1;
+        if (g_refill > 64) g_refill = 64;
+        return true;
+    }();
+    (void)init;
+    if (const char* e = getenv("SLRHIP_WS_BLOCKS_PER_CU")) { const int b = atoi(e); if (b >= 1 && b <= 8) return b; }   // experiments
+    const int nc = wsConsumers(quantized);
+    // 18.5 / 39.5 / 64.5 KiB of LDS per workgroup, 32 waves per CU either way (<= 64 VGPR); fewer where staged nodes (SLR_WS_TOP) need the room
+    const size_t lds = nc == 15 ? sizeof(WsLds<15>) : nc == 7 ? sizeof(WsLds<7>) : sizeof(WsLds<3>);
+    return std::min(nc == 15 ? 2 : nc == 7 ? 4 : 8, (int)(163840 / lds));
+}
 
 // streamed once per launch: keep them out of the vector L1 so that it stays with the BVH nodes
 typedef float wsFloat4 __attribute__((ext_vector_type(4)));
@@ -144,7 +157,7 @@ struct WsCounts {
 };
 
 template <bool COUNT, int NC, bool QUANT>
-__device__ __forceinline__ void wsConsume(const DevScene& sc, const PathBuffers& pb, WsLds<NC>& lds, uint32_t refill, WsCounts& cnt, WsDebug& dbg) {
+__device__ __forceinline__ void wsConsume(const DevScene& sc, const PathBuffers& pb, WsLds<NC>& lds, uint32_t refill, uint32_t numTop, WsCounts& cnt, WsDebug& dbg) {
     const uint64_t tStart = COUNT ? __builtin_readcyclecounter() : 0;
     constexpr uint32_t kRing = WsLds<NC>::kRing;
     const uint32_t lane = threadIdx.x & 63u;
@@ -243,12 +256,19 @@ __device__ __forceinline__ void wsConsume(const DevScene& sc, const PathBuffers&
                 if (QUANT) {
                     // 64-byte node, 8-bit child boxes (device_types.h QNodeQ): plane = fma(byte, scale, origin), rounded outwards by
                     // the host, so the boxes are supersets of the float boxes and the set of hits is unchanged
-                    const char* nb = reinterpret_cast<const char*>(sc.nodesQ);
-                    const uint32_t nOff = cur * 64u;
-                    const float4 v0 = *reinterpret_cast<const float4*>(nb + nOff);
-                    const float4 v1 = *reinterpret_cast<const float4*>(nb + (nOff + 16u));
-                    const float4 v2 = *reinterpret_cast<const float4*>(nb + (nOff + 32u));
-                    ch = *reinterpret_cast<const float4*>(nb + (nOff + 48u));
+                    float4 v0, v1, v2;
+                    if (kTop && cur < numTop) {
+                        const float4* n = lds.top + cur * 5u;
+                        v0 = n[0]; v1 = n[1]; v2 = n[2]; ch = n[3];
+                    }
+                    else {
+                        const char* nb = reinterpret_cast<const char*>(sc.nodesQ);
+                        const uint32_t nOff = cur * 64u;
+                        v0 = *reinterpret_cast<const float4*>(nb + nOff);
+                        v1 = *reinterpret_cast<const float4*>(nb + (nOff + 16u));
+                        v2 = *reinterpret_cast<const float4*>(nb + (nOff + 32u));
+                        ch = *reinterpret_cast<const float4*>(nb + (nOff + 48u));
+                    }
                     const uint32_t qlox = __float_as_uint(v1.z), qloy = __float_as_uint(v1.w), qloz = __float_as_uint(v2.x);
                     const uint32_t qhix = __float_as_uint(v2.y), qhiy = __float_as_uint(v2.z), qhiz = __float_as_uint(v2.w);
                     const uint32_t nqx = idx > 0.0f ? qlox : qhix, fqx = idx > 0.0f ? qhix : qlox;      // QBVH.h:66-71
@@ -268,6 +288,11 @@ __device__ __forceinline__ void wsConsume(const DevScene& sc, const PathBuffers&
                     const int nx = idx > 0.0f ? 0 : 3, fx = 3 - nx;
                     const int ny = idy > 0.0f ? 1 : 4, fy = 5 - ny;
                     const int nz = idz > 0.0f ? 2 : 5, fz = 7 - nz;
+                    if (kTop && cur < numTop) {
+                        const float4* n = lds.top + cur * 9u;
+                        nX = n[nx]; nY = n[ny]; nZ = n[nz]; fX = n[fx]; fY = n[fy]; fZ = n[fz]; ch = n[6];
+                    }
+                    else {
                     const char* nb = reinterpret_cast<const char*>(nodes4);
                     const uint32_t nOff = cur * 128u;
                     nX = *reinterpret_cast<const float4*>(nb + (nOff + (uint32_t)nx * 16u));
@@ -277,6 +302,7 @@ __device__ __forceinline__ void wsConsume(const DevScene& sc, const PathBuffers&
                     fY = *reinterpret_cast<const float4*>(nb + (nOff + (uint32_t)fy * 16u));
                     fZ = *reinterpret_cast<const float4*>(nb + (nOff + (uint32_t)fz * 16u));
                     ch = *reinterpret_cast<const float4*>(nb + (nOff + 96u));
+                    }
                 }
                 // slab test of QBVH::Node::intersect (QBVH.h:55-76): tNear <= tFar.  (Tried: fma(plane, id, -(o * id)) on
                 // padded boxes, half the arithmetic — but for rays that start ON a surface the cancellation noise near t = 0
@@ -511,13 +537,18 @@ __global__ __launch_bounds__(64 * (NC + 1)) __attribute__((amdgpu_waves_per_eu(8
         pb.queueCount[queueCounterIndex(parity ^ 1, threadIdx.x / kShards, threadIdx.x % kShards)] = 0;
     }
     if (threadIdx.x == 0) { lds.tail = 0; lds.reserved = 0; lds.released = 0; lds.done = 0; }
+    const uint32_t numTop = kTop ? min(kTop, sc.numNodes) : 0u;
+    if (kTop) {
+        if (QUANT) for (uint32_t i = threadIdx.x; i < numTop * 4u; i += blockDim.x) lds.top[(i >> 2) * 5u + (i & 3u)] = sc.nodesQ[i];
+        else for (uint32_t i = threadIdx.x; i < numTop * 8u; i += blockDim.x) lds.top[(i >> 3) * 9u + (i & 7u)] = sc.nodes[i];
+    }
     __syncthreads();
     uint32_t extRays = 0, shadowRays = 0;
     WsCounts cnt;
     WsDebug dbg;
     if (threadIdx.x < 64) wsProduce(pb, lds, numSlots, shardCapacity, parity, extRays, shadowRays, dbg);
     else {
-        wsConsume<COUNT, NC, QUANT>(sc, pb, lds, refill, cnt, dbg);
+        wsConsume<COUNT, NC, QUANT>(sc, pb, lds, refill, numTop, cnt, dbg);
     }
     wsBlockAdd(pb.totals, T_EXT_RAYS, extRays, lds.red);
     wsBlockAdd(pb.totals, T_SHADOW_RAYS, shadowRays, lds.red);
