@@ -700,20 +700,18 @@ int slrhip_render_begin(slrhip_ctx* ctx, const slrhip_render_settings* st, slrhi
     const uint32_t numPixels = pixels[0] == 0xFFFFFFFFu ? 0u : (uint32_t)pixels.size();
     uint32_t stripes = ctx->config.stripes;
     if (stripes == 0) {
-        // Paths in flight: throughput keeps rising with the slot count (longer launches amortise the
-        // per-wave tail of the traversal kernels: 807 / 1146 / 1267 Msamples/s at 0.9 / 3.7 / 7.4 M slots on
-        // the 1280x720 Cornell scene), at ≈ 200 B of HBM per slot.  With the per-pixel sample pool (finishedMask) the
-        // stripes of a pixel finish together, and fewer, fuller iterations keep paying: 1 988 / 2 079 / 2 098 / 2 073
-        // Msamples/s at 8 / 16 / 24 / 32 stripes (environment light: 3 850 / 4 172 / 4 323 / 4 415).  RGB: ~22 M slots
-        // (24 stripes at 1280x720, 4.4 GB).  Spectral (492 B per slot; its shade kernel is latency-bound, not
-        // launch-bound): ~7.4 M.  At most 64 stripes: the width of the pool's mask, and the best count measured for the
-        // eighth of the image a rank owns at N = 8 (61.5 / 62.5 / 65.4 / 68.0 ms at 64 / 96 / 128 / 192 with a wider mask:
-        // below ~16 samples per slot the first, statically assigned sample of every stripe weighs too much).
-        // Powers of two: the stripes of a pixel then fill whole lane groups of the shade workgroup (PathBuffers, slot layout).
+        // Paths in flight: throughput keeps rising with the slot count (longer launches amortise the per-wave tail of the
+        // traversal kernel: 807 / 1146 / 1267 Msamples/s at 0.9 / 3.7 / 7.4 M slots on the 1280x720 Cornell scene in round 1),
+        // at ~200 B of HBM per slot; the per-pixel sample pool keeps the stripes of a pixel finishing together, so fewer, fuller
+        // iterations keep paying.  The count is a power of two (the stripes of a pixel then fill whole lane groups of the shade
+        // workgroup, PathBuffers): the smallest that reaches ~22 M slots in RGB mode, ~7.4 M in spectral mode (492 B per slot; its
+        // shade kernel is latency-bound, not launch-bound), at most 64 (the width of the pool's mask; also the best count measured
+        // for the eighth of the image a rank owns at N = 8).  Measured with the fused shade kernel, 16 vs 32 stripes at 1280x720
+        // (profiles/r03_e_*): Cornell 2 709 vs 2 719, environment light 5 630 vs 6 061, 10 M-triangle grid 1 954 vs 1 981 Msamples/s.
         const uint32_t target = ctx->config.mode == SLRHIP_MODE_SPECTRAL ? 7372800u : 22118400u;
         static const long envStripes = [] { const char* e = getenv("SLRHIP_AUTO_STRIPES"); return e ? atol(e) : 0L; }();      // measurement: force the automatic choice
         stripes = 1u;
-        while (stripes < 64u && (uint64_t)numPixels * stripes * 3u < (uint64_t)target * 2u) stripes *= 2u;      // the power of two nearest target / numPixels (geometric mean as the boundary: x 1.5)
+        while (stripes < 64u && (uint64_t)numPixels * stripes < target) stripes *= 2u;
         if (numPixels == 0) stripes = 1u;
         if (envStripes >= 1 && envStripes <= 64) stripes = (uint32_t)envStripes;
     }
