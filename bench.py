@@ -76,6 +76,8 @@ def parse():
     ap.add_argument("--stripes", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--tree", default="auto", choices=["auto", "host", "device"],
+                    help="accelerator build: host binned SAH, device LBVH (SLRHIP_FLAG_BVH_DEVICE_BUILD), auto = device from 2^20 triangles on")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"),
                     help="per-kernel HBM traffic from separate rocprofv3 --pmc passes of this same command (tools/pmc_traffic.py)")
@@ -148,7 +150,10 @@ def main():
         scene = scenes.displaced_grid(args.grid_n, W / H)
         what = "BASELINE configs[4]: one displaced grid (hash-noise heightfield, seed 20240611), matte, one area light, thin lens r=0.025"
     settings = abi.RenderSettings(W, H, 0.0, 0.0, 1.0, abi.DEFAULT_SEED)
-    flags = 0 if args.no_kernel_timing else abi.FLAG_TIME_KERNELS
+    build_flag = abi.FLAG_BVH_DEVICE_BUILD if args.tree == "device" else 0
+    if args.tree == "host":
+        os.environ["SLRHIP_BVH"] = "host"
+    flags = (0 if args.no_kernel_timing else abi.FLAG_TIME_KERNELS) | build_flag
     ctx = Context(device=local_rank, mode=mode, stripes=args.stripes, flags=flags)
     ctx.upload_scene(scene)
     comps = 16 if mode == abi.MODE_SPECTRAL else 3
@@ -207,7 +212,7 @@ def main():
         "config": {"workload": "%s, %d triangles, %s mode, %dx%d, %d spp, seed %d" % (
                        what, len(scene.triangles), "spectral" if mode == abi.MODE_SPECTRAL else "RGB", W, H, spp, abi.DEFAULT_SEED),
                    "sharding": "8x8 tiles round-robin over %d rank(s), one RCCL reduce of the framebuffer per step" % world,
-                   "stripes": int(args.stripes)},
+                   "stripes": int(args.stripes), "tree": "device LBVH" if (args.tree == "device" or (args.tree == "auto" and len(scene.triangles) >= 1 << 20)) else "host binned SAH"},
         # evidence that the collective saw N ranks: the process group's backend and size as torch.distributed reports
         # them, and each rank's own render time for its shard (ms per step, host clock around slrhip_render)
         "backend": (dist.get_backend() if world > 1 else None), "rccl_ranks": (dist.get_world_size() if world > 1 else 1),
@@ -228,7 +233,7 @@ def main():
             if kernels.get("tail", {}).get("launches") == 0:
                 kernels.pop("tail")       # listed only when it ran (SLRHIP_TAIL_SLOTS=0 turns it off)
             # traversal statistics from an instrumented, untimed pass on this rank's shard
-            cctx = Context(device=local_rank, mode=mode, stripes=args.stripes, flags=abi.FLAG_COUNT_TRAVERSAL)
+            cctx = Context(device=local_rank, mode=mode, stripes=args.stripes, flags=abi.FLAG_COUNT_TRAVERSAL | build_flag)
             cctx.upload_scene(scene)
             cctx.render_begin(settings, shard=(rank, world))
             cctx.render(0, min(spp, 16))
@@ -346,7 +351,7 @@ def main():
                 out["cpu_baseline_port"] = port
             if not args.no_parity:
                 # the TIMED configuration (automatic stripe count + sample pool): stripes only reorder a pixel's float sum
-                pctx = Context(device=local_rank, mode=mode, stripes=args.stripes)
+                pctx = Context(device=local_rank, mode=mode, stripes=args.stripes, flags=build_flag)
                 got = pctx.render_image(scene, settings, n)
                 pc = pctx.counters()
                 pctx.close()
@@ -363,7 +368,7 @@ def main():
                                  "ray_counts_equal": bool(int(pc.extension_rays) == int(octr.extension_rays) and int(pc.shadow_rays) == int(octr.shadow_rays)),
                                  "mean_radiance": float(want.mean() / n * sens)}
                 # and with ONE stripe, which keeps the sensor's accumulation order: expected bit for bit where no float libm is on the path
-                pctx = Context(device=local_rank, mode=mode, stripes=1)
+                pctx = Context(device=local_rank, mode=mode, stripes=1, flags=build_flag)
                 got1 = pctx.render_image(scene, settings, n)
                 pctx.close()
                 exact = (got1.view(np.uint32) == want.view(np.uint32)) | ((got1 == 0) & (want == 0))

@@ -331,6 +331,11 @@ typedef struct slrhip_profile {
                                          * a triangle straddling a split plane is referenced from both sides with clipped boxes.
                                          * Same hits; fewer triangle tests, more node visits: measured slower with these kernels on
                                          * every BASELINE scene, so the object-split SAH tree stays the default          */
+#define SLRHIP_FLAG_BVH_DEVICE_BUILD 4u /* build the accelerator AND the per-triangle records on the GPU (bvh_device.hip: LBVH over 63-bit Morton codes,
+                                         * the host build's 4-wide collapse, quantized nodes): 10 M triangles in a fraction of a second instead of
+                                         * seconds on the host cores, at the price of a tree of lower quality (more nodes per ray; DESIGN.md has both
+                                         * figures).  Same hits.  Automatic from 2^20 triangles on (SLRHIP_BVH=host in the environment keeps the host build);
+                                         * scenes with alpha-textured triangles, or fewer than 1024 triangles, always use the host build */
 #define SLRHIP_FLAG_TEST_DEVICE_ERROR 16u /* test hook: the next slrhip_render raises the device-side error word, so that the
                                          * error path (SLRHIP_ERR_HIP + message) can be exercised; renders nothing useful */
 #define SLRHIP_FLAG_TIME_KERNELS   1u   /* bracket every launch with HIP events (a few us per launch)        */

@@ -91,7 +91,7 @@ class Profile(C.Structure):
                 ("nodes", C.c_uint64 * 2), ("triangles", C.c_uint64 * 2), ("slot_visits", C.c_uint64)]
 
 
-FLAG_TIME_KERNELS, FLAG_COUNT_TRAVERSAL, FLAG_TEST_DEVICE_ERROR, FLAG_BVH_SPATIAL_SPLITS, FLAG_TAIL_KERNEL = 1, 2, 16, 64, 128
+FLAG_TIME_KERNELS, FLAG_COUNT_TRAVERSAL, FLAG_BVH_DEVICE_BUILD, FLAG_TEST_DEVICE_ERROR, FLAG_BVH_SPATIAL_SPLITS, FLAG_TAIL_KERNEL = 1, 2, 4, 16, 64, 128
 MAX_STRIPES = 64
 KERNEL_NAMES = ("trace", "shade", "tail")
 

@@ -1,6 +1,7 @@
 // bvh.h — host-side 4-wide BVH build (see bvh.cpp).
 #pragma once
 #include <cmath>
+#include <string>
 #include <vector>
 
 #include "../../include/slrhip.h"
@@ -48,6 +49,20 @@ void buildBinarySBVH(const slrhip_vertex* verts, const slrhip_triangle* tris, ui
 
 // Fills out->quantized from out->nodes (conservative: every dequantized box contains the float box).
 void quantizeNodes(QBVH* out);
+
+// The same records built on the GPU (bvh_device.hip): LBVH over 63-bit Morton codes, the same 4-wide collapse, quantized nodes,
+// leaf packets and per-triangle shading records.  All pointers are DEVICE memory from hipMalloc, owned by the caller afterwards.
+// lightTris = scene indices of the emitting triangles in light-list order (their ShadeTri::light is patched in).
+struct DeviceGeometry {
+    QNode* nodes = nullptr;
+    QNodeQ* nodesQ = nullptr;        // nullptr unless asked for
+    LeafTri* leafTris = nullptr;
+    ShadeTri* shadeTris = nullptr;
+    uint32_t numNodes = 0, numLeafTris = 0, depth = 0;
+    double secondsUpload = 0, secondsSort = 0, secondsHierarchy = 0, secondsCollapse = 0, secondsRecords = 0;
+};
+int buildGeometryDevice(const slrhip_vertex* verts, uint32_t numVerts, const slrhip_triangle* tris, uint32_t numTris, const uint32_t* lightTris,
+                        uint32_t numLights, bool wantQuantized, DeviceGeometry* out, std::string* err);
 
 // Returns 0 on success.
 int buildQBVH(const slrhip_vertex* verts, const slrhip_triangle* tris, uint32_t numTris, QBVH* out, bool spatialSplits = false);

@@ -368,6 +368,44 @@ def test_two_contexts_on_non_blocking_streams_from_two_threads(oracle_rgb):
             assert np.allclose(got[i], halves[i], rtol=2e-6, atol=1e-9), "context %d, attempt %d" % (i, attempt)
 
 
+def test_device_built_tree_gives_the_same_image(oracle_rgb):
+    """SURVEY 8 row f2, second half: tree, quantized nodes, leaf packets and per-triangle shading records built on the GPU
+    (bvh_device.hip: LBVH over Morton codes + the host build's 4-wide collapse; reference build path Accelerator/SBVH.h:379-407,
+    QBVH.h:254-284).  Another tree over the same triangles: the reference golden's closest hits must come out bit-equal, the frame
+    and the ray counts must equal the oracle's (up to the one-in-a-million equal-distance ray whose winner depends on which
+    triangles a tree tests), on a float-node tree (Cornell, 4 428 triangles) and on a quantized one (320 002)."""
+    from test_oracle_golden import procedural_scene
+    g = load_golden("rgb_grid400")
+    for name, sc, st, spp in (("cornell", scenes.cornell_box_spheres(4.0 / 3.0, 48, 24, "glass"), ob.settings(160, 120, seed=12), 8),
+                              ("grid", procedural_scene(g), ob.settings(320, 180, seed=9), 16),
+                              ("grid640", scenes.displaced_grid(640, 16.0 / 9.0), ob.settings(160, 90, seed=4), 4)):      # 819 200 triangles: quantized nodes on either tree
+        want, ctr = oracle_rgb.scene(sc).render(st, spp)
+        out = {}
+        for label, flags in (("host", abi.FLAG_COUNT_TRAVERSAL), ("device", abi.FLAG_COUNT_TRAVERSAL | abi.FLAG_BVH_DEVICE_BUILD)):
+            c = Context(stripes=1, flags=flags)
+            try:
+                fb = c.render_image(sc, st, spp)
+                k, p = c.counters(), c.profile()
+                out[label] = (fb, int(k.extension_rays), int(k.shadow_rays), int(k.samples), int(k.bvh_nodes), p.nodes[0] / p.rays[0], p.triangles[0] / p.rays[0], k.build_seconds)
+                if name == "grid640":
+                    assert k.bvh_nodes >= 65536
+                if name == "grid":
+                    tri, dist, b0, b1 = c.trace_rays(g["rays"]["org"], g["rays"]["dir"], g["rays"]["dist_min"], g["rays"]["dist_max"])
+                    hit = g["hits"]["triangle"] != 0xFFFFFFFF
+                    assert (tri == g["hits"]["triangle"]).all(), label
+                    assert_bit_equal(dist[hit], g["hits"]["dist"][hit], label + " dist")
+                    assert_bit_equal(b0[hit], g["hits"]["b0"][hit], label + " b0")
+            finally:
+                c.close()
+        print(name, {k: v[4:] for k, v in out.items()})
+        assert_bit_equal(out["host"][0], want, name + ": host-built tree vs oracle")
+        s = frame_stats(out["device"][0], want)
+        assert s["exact_fraction"] >= 0.9999, (name, s)
+        assert out["device"][3] == out["host"][3] == int(ctr.samples)
+        assert all(abs(a - b) <= 1e-5 * b for a, b in zip(out["device"][1:3], (int(ctr.extension_rays), int(ctr.shadow_rays)))), (name, out["device"][1:3])
+        assert out["device"][5] < 2.0 * out["host"][5]              # nodes per extension ray: an LBVH is worse than the SAH tree, not absurdly so
+
+
 def test_spatial_split_tree_gives_the_same_image(oracle_rgb):
     """the tree built with spatial splits (sbvh.cpp: the reference's SBVH, Accelerator/SBVH.h:57-348 — references
     duplicated across split planes with clipped boxes, Surface/TriangleMesh.cpp:19-125) is another tree over the same triangles:
