@@ -300,7 +300,7 @@ template <> struct SpAcc<RGB> {
     // emitter, a later one when its shadow ray came back visible or the ray found a light.
     RGB r, c, nee;
     bool valid, changed;
-    __device__ __forceinline__ void begin(const PathBuffers& pb, uint32_t slot, uint32_t n, uint32_t flags) {
+    __device__ __forceinline__ void begin(const PathBuffers& pb, uint32_t slot, uint32_t n, uint32_t flags, bool /*resolves*/) {
         float unused;
         valid = !SLR_SP_LAZY || (F_STATE(flags) != ST_FIRST_HIT && F_SPVALID(flags));
         changed = !SLR_SP_LAZY;
@@ -322,9 +322,31 @@ template <> struct SpAcc<RGB> {
         if (pathContinues) SpecIO<RGB>::store(pb.spC, nullptr, slot * pb.spStride, n * pb.spStride, c, 0.0f);       // a finished path only hands over the sum
     }
 };
+#ifndef SLR_SPEC_PREFETCH
+#define SLR_SPEC_PREFETCH 1      // 0 (variant builds): the pending light sample and the radiance sum are fetched when the resolve runs
+#endif
 template <> struct SpAcc<Spec16> {
+    // The Kahan pair (2 x 64 B) and the pending light sample (64 B) stay in HBM and are updated in place when a contribution
+    // arrives.  The one contribution that is known before the visit starts — the pending light sample of a slot whose shadow ray
+    // came back visible (flag bit 14 + the visibility word, both read before the state loads are issued) — has its twelve 16-byte
+    // operands requested WITH the state loads, so that the resolve costs no memory round trip of its own.
     bool valid;
-    __device__ __forceinline__ void begin(const PathBuffers&, uint32_t, uint32_t, uint32_t) {}
+    float4 pn[4], pr[4], pc[4];
+    bool fetched;
+    __device__ __forceinline__ void begin(const PathBuffers& pb, uint32_t slot, uint32_t n, uint32_t flags, bool resolves) {
+        fetched = false;
+        if (SLR_SPEC_PREFETCH && resolves) {
+            const bool had = F_STATE(flags) != ST_FIRST_HIT && F_SPVALID(flags);
+            const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                pn[p] = pb.nee[(size_t)p * n + slot];
+                pr[p] = had ? pb.spR[((size_t)p * n + slot) * pb.spStride] : zero;
+                pc[p] = had ? pb.spC[((size_t)p * n + slot) * pb.spStride] : zero;
+            }
+            fetched = true;
+        }
+    }
     __device__ __forceinline__ void startPath(bool first, uint32_t flags) { valid = !first && F_SPVALID(flags); }
     __device__ __forceinline__ uint32_t validBits() const { return valid ? 1u << 10 : 0u; }
     __device__ __forceinline__ Spec16 total() const { return Spec16(); }      // the sum is in HBM (flag bit 10 says whether it was ever written)
@@ -346,9 +368,12 @@ template <> struct SpAcc<Spec16> {
         const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-            const float4 v = pb.nee[(size_t)p * n + slot];
-            float4 r = zero, c = zero;
-            if (valid) { r = pb.spR[((size_t)p * n + slot) * pb.spStride]; c = pb.spC[((size_t)p * n + slot) * pb.spStride]; }
+            float4 v, r = zero, c = zero;
+            if (fetched) { v = pn[p]; r = pr[p]; c = pc[p]; }
+            else {
+                v = pb.nee[(size_t)p * n + slot];
+                if (valid) { r = pb.spR[((size_t)p * n + slot) * pb.spStride]; c = pb.spC[((size_t)p * n + slot) * pb.spStride]; }
+            }
             kahanAdd(r.x, c.x, v.x); kahanAdd(r.y, c.y, v.y); kahanAdd(r.z, c.z, v.z); kahanAdd(r.w, c.w, v.w);
             pb.spR[((size_t)p * n + slot) * pb.spStride] = r;
             pb.spC[((size_t)p * n + slot) * pb.spStride] = c;
@@ -417,7 +442,7 @@ __device__ __forceinline__ int32_t texturizeMat(const DevScene& sc, Mat<S>& mm, 
 // (k_tail): the slot is left in ST_REGEN with bit 15 set and its sum in HBM, for the lane's next turn.
 template <class S, bool LDS_TABLES, bool MF, bool MULTI, bool TEX, bool FUSED>
 __device__ __forceinline__ void logicSlot(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, const ShadeLds<S::N != 3>& lds,
-                                          const float* lightPMF, const float* lightCDF, uint32_t slot, uint32_t& flags, S& radiance,
+                                          const float* lightPMF, const float* lightCDF, uint32_t slot, uint32_t& flags, uint32_t vis, S& radiance,
                                           bool& emitExt, bool& emitShadow, bool& emitRegen) {
     constexpr bool leader = true;
     // ---- all state loads up front: one memory round trip instead of a dependent chain (flags: read above) -----------
@@ -429,10 +454,9 @@ __device__ __forceinline__ void logicSlot(const DevScene& sc, const PathBuffers&
     SpAcc<S> sp;
     float bsdfPDFprev;
     SpecIO<S>::load(pb.alpha, pb.pdfPrev, slot, rp.numSlots, alpha, bsdfPDFprev);
-    sp.begin(pb, slot, rp.numSlots, flags);
+    sp.begin(pb, slot, rp.numSlots, flags, F_SHADOW(flags) && vis);
     const float4 h = pb.hit[slot];
     const float4 o4 = pb.rayOrg[(size_t)slot * pb.rayStride], d4 = pb.rayDir[(size_t)slot * pb.rayStride];
-    const uint32_t vis = pb.visible[slot];
     const float wlOffset = S::N == 3 ? 0.0f : __uint_as_float(pb.hdr[(size_t)slot * pb.hdrStride].z);
 
     const uint32_t state = F_STATE(flags);
@@ -461,7 +485,7 @@ __device__ __forceinline__ void logicSlot(const DevScene& sc, const PathBuffers&
         }
 
         // ---- 1. resolve the pending next-event estimate (:180,202) ---------------------------------
-        if (F_SHADOW(flags) && vis) sp.addPendingNee(pb, slot, rp.numSlots);
+        if (F_SHADOW(flags) && vis) sp.addPendingNee(pb, slot, rp.numSlots);      // (its operands were requested with the state loads: SpAcc::begin)
 
         // ---- 2. the hit that just came back ------------------------------------------------------------
         Mat<S> m;
@@ -884,6 +908,7 @@ __attribute__((amdgpu_waves_per_eu(S::N == 3 ? SLR_WAVES_RGB : (MF ? SLR_WAVES_S
     if (pb.activeSlots[0] == 0 || pb.tailMode[0]) return;                 // every slot is out of passes / the tail kernel takes over (uniform)
     if (pb.blockDead[blockIdx.x]) return;
     uint32_t flags = pb.flags[slot];                                      // numSlots = 256 x workgroups: always in range
+    const uint32_t vis = pb.visible[slot];                                // with the flags: both are known before the state loads are issued
     const uint32_t state0 = F_STATE(flags);
     {
         const int anyWork = __syncthreads_or(state0 != ST_IDLE);
@@ -923,7 +948,7 @@ __attribute__((amdgpu_waves_per_eu(S::N == 3 ? SLR_WAVES_RGB : (MF ? SLR_WAVES_S
     bool emitExt = false, emitShadow = false, pathEnded = false;
     S radiance;
     if (state0 == ST_FIRST_HIT || state0 == ST_NEXT_HIT || state0 == ST_FINISH)
-        logicSlot<S, LDS_TABLES, MF, MULTI, TEX, true>(sc, pb, rp, lds, lightPMF, lightCDF, slot, flags, radiance, emitExt, emitShadow, pathEnded);
+        logicSlot<S, LDS_TABLES, MF, MULTI, TEX, true>(sc, pb, rp, lds, lightPMF, lightCDF, slot, flags, vis, radiance, emitExt, emitShadow, pathEnded);
 
     // ---- a path that ended: sensor->add, in the same launch --------------------------------------------------------------------
     uint32_t samplesDone = 0;

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(SLR
         bool emitExt = false, emitShadow = false, emitRegen = false;
         uint32_t fl = flags;
         S unusedSum;
-        logicSlot<S, LDS_TABLES, MF, MULTI, TEX, false>(sc, pb, rp, lds, lightPMF, lightCDF, slot, fl, unusedSum, emitExt, emitShadow, emitRegen);
+        logicSlot<S, LDS_TABLES, MF, MULTI, TEX, false>(sc, pb, rp, lds, lightPMF, lightCDF, slot, fl, pb.visible[slot], unusedSum, emitExt, emitShadow, emitRegen);
         // a finished path is in ST_REGEN now: accumulated at the next turn of this loop
     }
     if (slot != kTailNone) atomicOr(pb.errorWord, ERR_CONSUMER_IDLE);      // the bound was hit: never expected, fails the render loudly
