@@ -139,11 +139,13 @@ enum {
      * of which may be wrapped in InverseBSDF (InverseSurfaceMaterial basic_SurfaceMaterials.cpp:47-50,
      * basic_BSDFs.cpp:172-203).
      *   spectrum[0], spectrum[1] = indices of the two component MATERIALS: earlier entries of the material
-     *                              table, single-lobe types; their emittance is ignored
+     *                              table; single-lobe types, or MULTI records whose own components are
+     *                              single lobes (one level of nesting = up to four lobes, MultiBSDF.h:17:
+     *                              sum(mix(a, b), c), mix(sum(a, b), sum(c, d)), ...); their emittance is ignored
      *   spectrum[2]              = SLRHIP_MULTI_INVERSE_0 | SLRHIP_MULTI_INVERSE_1 bits
      *   param, param2            = the `scale` each component's getBSDF receives: 1, 1 for "sum";
      *                              1 - f, f for "mix" with a constant factor f
-     * InverseBSDF is limited to the reflection-only lobes (MATTE, METAL, MICROFACET_METAL, WARD, ASHIKHMIN):
+     * InverseBSDF is limited to single lobes of the reflection-only types (MATTE, METAL, MICROFACET_METAL, WARD, ASHIKHMIN):
      * the two-sided lobes read query.flags inside sampleInternal, which this path fixes at All.             */
     SLRHIP_MATERIAL_MULTI = 7
 };

@@ -1453,14 +1453,23 @@ float bsdfWeight(const BSDF<N>& f, const BSDFQuery<N>& q) {
 }
 
 // ------------------------------------------------------------------------------------------
-// MultiBSDF over (optionally inverted) lobes: BSDFs/MultiBSDF.cpp, InverseBSDF basic_BSDFs.cpp:172-203
+// MultiBSDF over (optionally inverted) lobes and over other MultiBSDFs: BSDFs/MultiBSDF.cpp, InverseBSDF basic_BSDFs.cpp:172-203.
+// SummedSurfaceMaterial / MixedSurfaceMaterial always add exactly two components (SummedSurfaceMaterial.cpp:13-20,
+// MixedSurfaceMaterial.cpp:14-22), so a material expression is a BINARY TREE of BSDFs whose inner nodes are MultiBSDFs.
 // ------------------------------------------------------------------------------------------
 template <int N>
 struct AnyBSDF {
-    uint32_t type;        // m_type: a single lobe's, or the union of the components' (MultiBSDF.cpp:16)
-    int n;                // 0: lobe[0] is the whole BSDF;  2: MultiBSDF of two components
-    BSDF<N> lobe[2];
-    bool inverse[2];      // component i is InverseBSDF(lobe[i])
+    static const int kMaxNodes = 15;
+    struct Node {
+        bool multi;           // MultiBSDF of children child[0], child[1]; else a lobe
+        bool inverse;         // lobe only: InverseBSDF(lobe)
+        int child[2];
+        uint32_t type;        // m_type: the lobe's (flipped under InverseBSDF, basic_BSDFs.h:71), or the union of the components' (MultiBSDF.cpp:16)
+        BSDF<N> lobe;
+    };
+    Node nodes[kMaxNodes];    // nodes[0] is the BSDF createBSDF returns
+    int numNodes;
+    uint32_t type;            // = nodes[0].type
 };
 inline uint32_t dtFlip(uint32_t t) { return t ^ DT_WholeSphere; }        // DDF.h:79
 
@@ -1518,83 +1527,118 @@ inline uint32_t sampleDiscrete(const float* importances, float* sumImportances, 
     return 0;
 }
 
+// The virtual calls MultiBSDF makes on a component — BSDF::weight (DDF.h:280-289) and the three *Internal functions — for
+// either kind of node.
+template <int N> float nodeWeight(const AnyBSDF<N>& f, int i, const BSDFQuery<N>& q);
+template <int N> Spec<N> nodeSampleInternal(const AnyBSDF<N>& f, int i, const BSDFQuery<N>& q, float uComponent, const float uDir[2], BSDFResult* result);
+template <int N> Spec<N> nodeEvaluateInternal(const AnyBSDF<N>& f, int i, const BSDFQuery<N>& q, uint32_t flags, V3 dir);
+template <int N> float nodeEvaluatePDFInternal(const AnyBSDF<N>& f, int i, const BSDFQuery<N>& q, V3 dir);
+template <int N> inline bool nodeMatches(const AnyBSDF<N>& f, int i, uint32_t flags) { return dtMatches(f.nodes[i].type, flags); }
+
 // MultiBSDF::sampleInternalNoRev  MultiBSDF.cpp:20-59
 template <int N>
-Spec<N> multiSampleInternal(const AnyBSDF<N>& f, const BSDFQuery<N>& q, float uComponent, const float uDir[2], BSDFResult* result) {
-    const Component<N> c[2] = {{f.lobe[0], f.inverse[0]}, {f.lobe[1], f.inverse[1]}};
+Spec<N> multiSampleInternal(const AnyBSDF<N>& f, int node, const BSDFQuery<N>& q, float uComponent, const float uDir[2], BSDFResult* result) {
+    const int* c = f.nodes[node].child;
     float weights[2];
-    for (int i = 0; i < f.n; ++i) weights[i] = c[i].weight(q);
+    for (int i = 0; i < 2; ++i) weights[i] = nodeWeight(f, c[i], q);
     float sumWeights, base;
-    uint32_t idx = sampleDiscrete(weights, &sumWeights, &base, (uint32_t)f.n, uComponent);
+    uint32_t idx = sampleDiscrete(weights, &sumWeights, &base, 2u, uComponent);
     if (sumWeights == 0.0f) { result->dirPDF = 0.0f; return Spec<N>(); }
     uComponent = (uComponent * sumWeights - base) / weights[idx];
     result->dirPDF = 0.0f;
-    Spec<N> value = c[idx].sampleInternal(q, uComponent, uDir, result);
+    Spec<N> value = nodeSampleInternal(f, c[idx], q, uComponent, uDir, result);
     result->dirPDF *= weights[idx];
     if (result->dirPDF == 0.0f) return Spec<N>();
     if (!dtIsDelta(result->dirType)) {
-        for (int i = 0; i < f.n; ++i)
-            if (i != (int)idx && c[i].matches(q.flags))
-                result->dirPDF += c[i].evaluatePDFInternal(q, result->dir_sn) * weights[i];
+        for (int i = 0; i < 2; ++i)
+            if (i != (int)idx && nodeMatches(f, c[i], q.flags))
+                result->dirPDF += nodeEvaluatePDFInternal(f, c[i], q, result->dir_sn) * weights[i];
         uint32_t mflags = q.flags & sideTest(q.gNormal_sn, q.dir_sn, result->dir_sn);
         value = Spec<N>();
-        for (int i = 0; i < f.n; ++i) {
-            if (!c[i].matches(mflags)) continue;
-            value = value + c[i].evaluateInternal(q, mflags, result->dir_sn);
+        for (int i = 0; i < 2; ++i) {
+            if (!nodeMatches(f, c[i], mflags)) continue;
+            value = value + nodeEvaluateInternal(f, c[i], q, mflags, result->dir_sn);
         }
     }
     result->dirPDF /= sumWeights;
     return value;
 }
-// MultiBSDF::evaluateInternal :125-149, evaluatePDFInternalNoRev :151-169
+// MultiBSDF::evaluateInternal :125-149, evaluatePDFInternalNoRev :151-169, weightInternal :207-212
 template <int N>
-Spec<N> multiEvaluateInternal(const AnyBSDF<N>& f, const BSDFQuery<N>& q, uint32_t flags, V3 dir) {
-    const Component<N> c[2] = {{f.lobe[0], f.inverse[0]}, {f.lobe[1], f.inverse[1]}};
+Spec<N> multiEvaluateInternal(const AnyBSDF<N>& f, int node, const BSDFQuery<N>& q, uint32_t flags, V3 dir) {
+    const int* c = f.nodes[node].child;
     Spec<N> ret;
-    for (int i = 0; i < f.n; ++i) {
-        if (!c[i].matches(flags)) continue;
-        ret = ret + c[i].evaluateInternal(q, flags, dir);
+    for (int i = 0; i < 2; ++i) {
+        if (!nodeMatches(f, c[i], flags)) continue;
+        ret = ret + nodeEvaluateInternal(f, c[i], q, flags, dir);
     }
     return ret;
 }
 template <int N>
-float multiEvaluatePDFInternal(const AnyBSDF<N>& f, const BSDFQuery<N>& q, V3 dir) {
-    const Component<N> c[2] = {{f.lobe[0], f.inverse[0]}, {f.lobe[1], f.inverse[1]}};
+float multiEvaluatePDFInternal(const AnyBSDF<N>& f, int node, const BSDFQuery<N>& q, V3 dir) {
+    const int* c = f.nodes[node].child;
     Kahan<float> sumWeights;
     float weights[2];
-    for (int i = 0; i < f.n; ++i) { weights[i] = c[i].weight(q); sumWeights.add(weights[i]); }
+    for (int i = 0; i < 2; ++i) { weights[i] = nodeWeight(f, c[i], q); sumWeights.add(weights[i]); }
     if (sumWeights.result == 0.0f) return 0.0f;
     float retPDF = 0.0f;
-    for (int i = 0; i < f.n; ++i)
-        if (weights[i] > 0) retPDF += c[i].evaluatePDFInternal(q, dir) * weights[i];
+    for (int i = 0; i < 2; ++i)
+        if (weights[i] > 0) retPDF += nodeEvaluatePDFInternal(f, c[i], q, dir) * weights[i];
     retPDF /= sumWeights.result;
     return retPDF;
+}
+template <int N>
+float nodeWeight(const AnyBSDF<N>& f, int i, const BSDFQuery<N>& q) {
+    const typename AnyBSDF<N>::Node& n = f.nodes[i];
+    if (!n.multi) return Component<N>{n.lobe, n.inverse}.weight(q);
+    if (!dtMatches(n.type, q.flags)) return 0;              // BSDF::weight
+    Kahan<float> sumWeights;                                // MultiBSDF::weightInternal
+    for (int k = 0; k < 2; ++k) sumWeights.add(nodeWeight(f, n.child[k], q));
+    return sumWeights.result * 1.0f;                        // non-adjoint: snCorrection 1
+}
+template <int N>
+Spec<N> nodeSampleInternal(const AnyBSDF<N>& f, int i, const BSDFQuery<N>& q, float uComponent, const float uDir[2], BSDFResult* result) {
+    const typename AnyBSDF<N>::Node& n = f.nodes[i];
+    if (!n.multi) return Component<N>{n.lobe, n.inverse}.sampleInternal(q, uComponent, uDir, result);
+    return multiSampleInternal(f, i, q, uComponent, uDir, result);
+}
+template <int N>
+Spec<N> nodeEvaluateInternal(const AnyBSDF<N>& f, int i, const BSDFQuery<N>& q, uint32_t flags, V3 dir) {
+    const typename AnyBSDF<N>::Node& n = f.nodes[i];
+    if (!n.multi) return Component<N>{n.lobe, n.inverse}.evaluateInternal(q, flags, dir);
+    return multiEvaluateInternal(f, i, q, flags, dir);
+}
+template <int N>
+float nodeEvaluatePDFInternal(const AnyBSDF<N>& f, int i, const BSDFQuery<N>& q, V3 dir) {
+    const typename AnyBSDF<N>::Node& n = f.nodes[i];
+    if (!n.multi) return Component<N>{n.lobe, n.inverse}.evaluatePDFInternal(q, dir);
+    return multiEvaluatePDFInternal(f, i, q, dir);
 }
 
 // The public BSDF interface (DDF.h:231-279) on either kind
 template <int N>
 Spec<N> bsdfSample(const AnyBSDF<N>& f, const BSDFQuery<N>& q, float uComponent, const float uDir[2], BSDFResult* result) {
-    if (f.n == 0) return bsdfSample(f.lobe[0], q, uComponent, uDir, result);
+    if (!f.nodes[0].multi) return bsdfSample(f.nodes[0].lobe, q, uComponent, uDir, result);
     if (!dtMatches(f.type, q.flags)) { result->dirPDF = 0.0f; result->dirType = 0; return Spec<N>(); }
-    Spec<N> fs_sn = multiSampleInternal(f, q, uComponent, uDir, result);
+    Spec<N> fs_sn = multiSampleInternal(f, 0, q, uComponent, uDir, result);
     if (result->dirPDF == 0.0f) return Spec<N>();
     float snCorrection = std::fabs(result->dir_sn.z / dot(result->dir_sn, q.gNormal_sn));
     return fs_sn * snCorrection;
 }
 template <int N>
 Spec<N> bsdfEvaluate(const AnyBSDF<N>& f, const BSDFQuery<N>& q, V3 dir) {
-    if (f.n == 0) return bsdfEvaluate(f.lobe[0], q, dir);
+    if (!f.nodes[0].multi) return bsdfEvaluate(f.nodes[0].lobe, q, dir);
     uint32_t flags = q.flags & sideTest(q.gNormal_sn, q.dir_sn, dir);
     if (!dtMatches(f.type, flags)) return Spec<N>();
-    Spec<N> fs_sn = multiEvaluateInternal(f, q, flags, dir);
+    Spec<N> fs_sn = multiEvaluateInternal(f, 0, q, flags, dir);
     float snCorrection = std::fabs(dir.z / dot(dir, q.gNormal_sn));
     return fs_sn * snCorrection;
 }
 template <int N>
 float bsdfEvaluatePDF(const AnyBSDF<N>& f, const BSDFQuery<N>& q, V3 dir) {
-    if (f.n == 0) return bsdfEvaluatePDF(f.lobe[0], q, dir);
+    if (!f.nodes[0].multi) return bsdfEvaluatePDF(f.nodes[0].lobe, q, dir);
     if (!dtMatches(f.type, q.flags)) return 0;
-    return multiEvaluatePDFInternal(f, q, dir);
+    return multiEvaluatePDFInternal(f, 0, q, dir);
 }
 
 // SurfacePoint::createBSDF (geometry.cpp:56-58) -> SurfaceMaterial::getBSDF
@@ -1666,26 +1710,41 @@ BSDF<N> createLobe(const Scene& s, const slrhip_material& m, const Wls<N>& wls, 
     return f;
 }
 
-// SummedSurfaceMaterial.cpp:13-20 / MixedSurfaceMaterial.cpp:14-22 / InverseSurfaceMaterial basic_SurfaceMaterials.cpp:47-50
+// SummedSurfaceMaterial.cpp:13-20 / MixedSurfaceMaterial.cpp:14-22 / InverseSurfaceMaterial basic_SurfaceMaterials.cpp:47-50:
+// getBSDF(surfPt, wls, mem, scale) recursively; a "mix" hands scale * (1 - factor) and scale * factor down, a "sum" scale itself.
+template <int N>
+int buildBSDFNode(AnyBSDF<N>& f, const Scene& s, const slrhip_material& m, const Wls<N>& wls, float scale, float texU, float texV) {
+    const int idx = f.numNodes++;
+    typename AnyBSDF<N>::Node& n = f.nodes[idx];
+    n.inverse = false;
+    n.child[0] = n.child[1] = -1;
+    if (m.type != SLRHIP_MATERIAL_MULTI) {
+        n.multi = false;
+        n.lobe = createLobe<N>(s, m, wls, scale, texU, texV);
+        n.type = n.lobe.type;
+        return idx;
+    }
+    n.multi = true;
+    const float scales[2] = {scale * m.param, scale * m.param2};
+    uint32_t type = 0;
+    for (int i = 0; i < 2; ++i) {
+        const int c = buildBSDFNode<N>(f, s, s.materials[m.spectrum[i]], wls, scales[i], texU, texV);
+        f.nodes[idx].child[i] = c;
+        if ((m.spectrum[2] >> i) & 1) {                    // InverseSurfaceMaterial over a single lobe (validated at scene creation)
+            f.nodes[c].inverse = true;
+            f.nodes[c].type = dtFlip(f.nodes[c].type);     // InverseBSDF ctor, basic_BSDFs.h:71
+        }
+        type |= f.nodes[c].type;                           // MultiBSDF::add :16
+    }
+    f.nodes[idx].type = type;
+    return idx;
+}
 template <int N>
 AnyBSDF<N> createBSDFOf(const Scene& s, const slrhip_material& m, const Wls<N>& wls, float texU = 0.0f, float texV = 0.0f) {
     AnyBSDF<N> f;
-    f.inverse[0] = f.inverse[1] = false;
-    if (m.type != SLRHIP_MATERIAL_MULTI) {
-        f.n = 0;
-        f.lobe[0] = createLobe<N>(s, m, wls, 1.0f, texU, texV);
-        f.lobe[1] = f.lobe[0];
-        f.type = f.lobe[0].type;
-        return f;
-    }
-    f.n = 2;
-    f.type = 0;
-    const float scales[2] = {1.0f * m.param, 1.0f * m.param2};      // `scale * (1.0f - factor)`, `scale * factor` with scale = 1
-    for (int i = 0; i < 2; ++i) {
-        f.lobe[i] = createLobe<N>(s, s.materials[m.spectrum[i]], wls, scales[i], texU, texV);
-        f.inverse[i] = (m.spectrum[2] >> i) & 1;
-        f.type |= f.inverse[i] ? dtFlip(f.lobe[i].type) : f.lobe[i].type;      // MultiBSDF::add :16, InverseBSDF ctor
-    }
+    f.numNodes = 0;
+    buildBSDFNode<N>(f, s, m, wls, 1.0f, texU, texV);
+    f.type = f.nodes[0].type;
     return f;
 }
 template <int N>
@@ -2127,11 +2186,15 @@ slr_oracle_scene* slr_oracle_create(const slrhip_scene_desc* d, int mode) {
         if (m.type != SLRHIP_MATERIAL_MULTI) continue;
         bool ok = (uint32_t)m.spectrum[2] <= 3u;
         for (int k = 0; k < 2 && ok; ++k) {
-            ok = m.spectrum[k] >= 0 && (uint32_t)m.spectrum[k] < i && s->materials[m.spectrum[k]].type < SLRHIP_MATERIAL_MULTI;
-            if (ok && ((m.spectrum[2] >> k) & 1)) {
-                uint32_t ct = s->materials[m.spectrum[k]].type;
-                ok = ct != SLRHIP_MATERIAL_GLASS && ct != SLRHIP_MATERIAL_MICROFACET_GLASS;
+            ok = m.spectrum[k] >= 0 && (uint32_t)m.spectrum[k] < i;
+            if (!ok) break;
+            const slrhip_material& c = s->materials[m.spectrum[k]];
+            if (c.type == SLRHIP_MATERIAL_MULTI) {
+                // one level of nesting: the components of a component are single lobes (<= 4 lobes in all), and it is not inverted
+                ok = !((m.spectrum[2] >> k) & 1) && s->materials[c.spectrum[0]].type < SLRHIP_MATERIAL_MULTI &&
+                     s->materials[c.spectrum[1]].type < SLRHIP_MATERIAL_MULTI;
             }
+            else if ((m.spectrum[2] >> k) & 1) ok = c.type != SLRHIP_MATERIAL_GLASS && c.type != SLRHIP_MATERIAL_MICROFACET_GLASS;
         }
         if (!ok) { delete s; return nullptr; }
     }

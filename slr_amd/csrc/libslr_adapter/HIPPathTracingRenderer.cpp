@@ -202,7 +202,8 @@ struct Flattener {
     }
 
     // SurfaceMaterial -> index into out->materials (material -> BSDF factories of SURVEY row a16)
-    bool materialOf(const SurfaceMaterial* mat, uint32_t* index, bool allowMulti = true) {
+    // multiLevels: how many levels of summed / mixed materials may still open below this one (the C ABI takes one level of nesting)
+    bool materialOf(const SurfaceMaterial* mat, uint32_t* index, int multiLevels = 2) {
         auto it = materialIndex.find(mat);
         if (it != materialIndex.end()) { *index = it->second; return true; }
         slrhip_material m;
@@ -248,7 +249,8 @@ struct Flattener {
             if (!spectrumOf(a->m_Rs, &m.spectrum[0]) || !spectrumOf(a->m_Rd, &m.spectrum[1]) || !floatOf(a->m_nu, &m.param) || !floatOf(a->m_nv, &m.param2)) return false;
         }
         else {
-            // SummedSurfaceMaterial / MixedSurfaceMaterial over two single-lobe materials, either possibly an InverseSurfaceMaterial
+            // SummedSurfaceMaterial / MixedSurfaceMaterial over two materials: single lobes (either possibly an InverseSurfaceMaterial) or,
+            // one level down, summed / mixed materials of single lobes
             const SurfaceMaterial* c[2] = {nullptr, nullptr};
             float scale0 = 1.0f, scale1 = 1.0f;
             if (const SummedSurfaceMaterial* s = dynamic_cast<const SummedSurfaceMaterial*>(base)) { c[0] = s->m_mat0; c[1] = s->m_mat1; }
@@ -259,14 +261,15 @@ struct Flattener {
                 scale0 = 1.0f - f; scale1 = f;                       // MixedSurfaceMaterial.cpp:16-17 with scale = 1
             }
             else return fail("a surface material outside the hot path");
-            if (!allowMulti) return fail("nested sum / mix materials are not supported");
+            if (multiLevels <= 0) return fail("sum / mix materials nested more than one level deep are not supported");
             m.type = SLRHIP_MATERIAL_MULTI;
             int32_t bits = 0;
             for (int k = 0; k < 2; ++k) {
                 const SurfaceMaterial* child = c[k];
-                if (const InverseSurfaceMaterial* inv = dynamic_cast<const InverseSurfaceMaterial*>(child)) { child = inv->m_baseMat; bits |= 1 << k; }
+                bool inverted = false;
+                if (const InverseSurfaceMaterial* inv = dynamic_cast<const InverseSurfaceMaterial*>(child)) { child = inv->m_baseMat; bits |= 1 << k; inverted = true; }
                 uint32_t ci;
-                if (!materialOf(child, &ci, false)) return false;
+                if (!materialOf(child, &ci, inverted ? 0 : multiLevels - 1)) return false;      // InverseBSDF only over a single lobe
                 m.spectrum[k] = (int32_t)ci;
             }
             m.spectrum[2] = bits;

@@ -1,4 +1,4 @@
-// pt_bsdf_multi.h — MultiBSDF over two component lobes, either of which may be an InverseBSDF.
+// pt_bsdf_multi.h — MultiBSDF over two components: lobes (either of which may be an InverseBSDF) or MultiBSDFs of two lobes.
 //
 // Reference: SummedSurfaceMaterial::getBSDF / MixedSurfaceMaterial::getBSDF build a MultiBSDF of the two components'
 // BSDFs (SurfaceMaterials/SummedSurfaceMaterial.cpp:13-20, MixedSurfaceMaterial.cpp:14-22, with `scale` handed down to
@@ -20,7 +20,9 @@ SLR_DEV float luminance(const RGB& s) { return (float)(0.222485 * (double)s.r + 
 SLR_DEV float luminance(const Spec16& s) { return s.sum() / 16; }
 
 // The MULTI record: param = scale of component 0, onA = scale of component 1, onB = packMultiBits(...) (device_types.h) as raw bits
-// (written by slrhip_upload_scene; only moved, never used in arithmetic).
+// (written by slrhip_upload_scene; only moved, never used in arithmetic).  A component may itself be a MULTI record whose
+// components are single lobes: the reference's material expressions are binary trees (SummedSurfaceMaterial / MixedSurfaceMaterial
+// always add two BSDFs), here up to two levels = four lobes (MultiBSDF::maxNumElems, MultiBSDF.h:17).
 struct MultiRec {
     uint32_t child[2];
     uint32_t childType[2];     // SLRHIP_MATERIAL_* of the components, so the union lobe type needs no table look-up
@@ -37,11 +39,62 @@ SLR_DEV MultiRec decodeMulti(const Mat<S>& m) {
     r.scale[0] = m.param; r.scale[1] = m.onA;
     return r;
 }
-// m_type of the MultiBSDF: the union of its components' (MultiBSDF::add, MultiBSDF.cpp:16; InverseBSDF ctor basic_BSDFs.h:71)
-SLR_DEV uint32_t multiType(const MultiRec& r, uint32_t wlFlags) {
-    const uint32_t t0 = bsdfType(r.childType[0], wlFlags), t1 = bsdfType(r.childType[1], wlFlags);
-    return (r.inverse[0] ? dtFlip(t0) : t0) | (r.inverse[1] ? dtFlip(t1) : t1);
+
+// The expression tree flattened: leaves 0 .. numLeaves-1 in order; the root's component 0 covers the first size0 of them
+// (1 = a lobe, 2 = a nested MultiBSDF), component 1 the rest.
+struct MultiTree {
+    uint32_t leafMat[4];       // material table index
+    uint32_t leafMatType[4];   // SLRHIP_MATERIAL_*
+    float leafScale[4];        // the `scale` the lobe's getBSDF receives: the product down the tree, in the reference's order
+    uint32_t inverseMask;      // bit i: leaf i is wrapped in InverseBSDF
+    uint32_t numLeaves, size0;
+};
+// run-time index into a four-entry table without an indexed register file access
+template <class T> SLR_DEV T sel4(const T (&a)[4], uint32_t i) {
+    T r = a[0];
+    r = i == 1u ? a[1] : r;
+    r = i == 2u ? a[2] : r;
+    r = i == 3u ? a[3] : r;
+    return r;
 }
+template <class S, class Load>
+SLR_DEV MultiTree buildMultiTree(const MultiRec& root, const Load& load) {
+    MultiTree t;
+    t.inverseMask = 0u;
+    uint32_t n = 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if (root.childType[i] == SLRHIP_MATERIAL_MULTI) {
+            const MultiRec sub = decodeMulti(load(root.child[i]));
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                t.leafMat[n] = sub.child[j]; t.leafMatType[n] = sub.childType[j];
+                t.leafScale[n] = root.scale[i] * sub.scale[j];          // `scale * (1.0f - factor)` / `scale * factor` one level down
+                if (sub.inverse[j]) t.inverseMask |= 1u << n;
+                ++n;
+            }
+        }
+        else {
+            t.leafMat[n] = root.child[i]; t.leafMatType[n] = root.childType[i]; t.leafScale[n] = root.scale[i];
+            if (root.inverse[i]) t.inverseMask |= 1u << n;
+            ++n;
+        }
+        if (i == 0) t.size0 = n;
+    }
+    t.numLeaves = n;
+    for (uint32_t k = n; k < 4u; ++k) { t.leafMat[k] = t.leafMat[0]; t.leafMatType[k] = t.leafMatType[0]; t.leafScale[k] = 0.0f; }
+    return t;
+}
+// m_type of a group of leaves: the union of its lobes' (MultiBSDF::add, MultiBSDF.cpp:16; InverseBSDF ctor basic_BSDFs.h:71)
+SLR_DEV uint32_t multiGroupType(const MultiTree& t, uint32_t first, uint32_t count, uint32_t wlFlags) {
+    uint32_t type = 0u;
+    for (uint32_t i = first; i < first + count; ++i) {
+        const uint32_t lt = bsdfType(sel4(t.leafMatType, i), wlFlags);
+        type |= ((t.inverseMask >> i) & 1u) ? dtFlip(lt) : lt;
+    }
+    return type;
+}
+SLR_DEV uint32_t multiType(const MultiTree& t, uint32_t wlFlags) { return multiGroupType(t, 0u, t.numLeaves, wlFlags); }
 // `scale * spectrum` in the components' getBSDF (basic_SurfaceMaterials.cpp:19,22,33,42, ModifiedWardDurReflection.cpp:18,
 // AshikhminShirleyReflection.cpp:19); the microfacet materials ignore their scale (MicrofacetSurfaceMaterial.cpp:14-28).
 // The loaders applied scale = 1 already, an exact multiply.
@@ -136,52 +189,113 @@ SLR_DEV uint32_t sampleDiscrete2(float w0, float w1, float* sumImportances, floa
     return 0;          // falls out of the loop: index 0 with the base of the last step
 }
 
-// `load(i)` returns component i's Mat<S> (scale applied) — a callable so the kernel decides where the tables live.
+// `load(i)` returns material record i as a Mat<S> — a callable so the kernel decides where the tables live.
+// The lobes are visited in loops with a run-time leaf index (one copy of the lobe code per operation), and the sums are taken
+// in the reference's nesting order: a nested MultiBSDF's weight() = BSDF::weight over MultiBSDF::weightInternal (the sum of
+// its two lobes' weights), its sampleInternal / evaluateInternal / evaluatePDFInternal = the same functions one level down.
 template <class S, class Load>
 struct MultiBSDF {
-    MultiRec rec;
+    MultiTree tr;
     uint32_t wlFlags;      // WavelengthSamples flags (dispersive = !lambdaSelected for the specular dielectric)
     Load load;
 
-    SLR_DEV Component<S> component(int i) const {
+    SLR_DEV Component<S> leaf(uint32_t i) const {
         Component<S> c;
-        c.base = load(rec.child[i]);
-        applyScale(c.base, rec.scale[i]);
+        c.base = load(sel4(tr.leafMat, i));
+        applyScale(c.base, sel4(tr.leafScale, i));
         c.baseType = bsdfType(c.base.type, wlFlags);
-        c.inverse = rec.inverse[i];
+        c.inverse = (tr.inverseMask >> i) & 1u;
         return c;
     }
+    SLR_DEV uint32_t groupFirst(uint32_t g) const { return g ? tr.size0 : 0u; }
+    SLR_DEV uint32_t groupSize(uint32_t g) const { return g ? tr.numLeaves - tr.size0 : tr.size0; }
+    SLR_DEV bool groupMatches(uint32_t g, uint32_t flags) const { return dtMatches(multiGroupType(tr, groupFirst(g), groupSize(g), wlFlags), flags); }
+    // BSDF::weight of root component g: a lobe's own, or matches ? w_a + w_b : 0 for a nested MultiBSDF (weightInternal, MultiBSDF.cpp:207-212)
+    SLR_DEV float groupWeight(uint32_t g, uint32_t flags, const float (&w)[4]) const {
+        const uint32_t f = groupFirst(g);
+        if (groupSize(g) == 1u) return sel4(w, f);
+        return groupMatches(g, flags) ? sel4(w, f) + sel4(w, f + 1u) : 0.0f;
+    }
+
     // BSDF::sample (DDF.h:231-246) over MultiBSDF::sampleInternalNoRev (MultiBSDF.cpp:20-59); query.flags = All
     SLR_DEV S sample(uint32_t type, V3 dirOut, V3 gNorm, uint32_t wl, float uComp, float u0, float u1, BsdfSample* res) const {
         const uint32_t flags = DT_All;
         res->dirPDF = 0.0f;
         res->dirType = 0;
         if (!dtMatches(type, flags)) return S();
-        float weights[2];
-        weights[0] = component(0).weight(flags, dirOut, wl);
-        weights[1] = component(1).weight(flags, dirOut, wl);
-        float sumWeights, base;
-        const uint32_t idx = sampleDiscrete2(weights[0], weights[1], &sumWeights, &base, uComp);
-        if (sumWeights == 0.0f) return S();
-        const float wIdx = idx == 0 ? weights[0] : weights[1];
-        const float wOther = idx == 0 ? weights[1] : weights[0];
-        uComp = (uComp * sumWeights - base) / wIdx;
-        S value;
-        {
-            const Component<S> sel = component((int)idx);
-            value = sel.sampleInternal(flags, dirOut, gNorm, wl, uComp, u0, u1, res);
+        float w[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 1
+        for (uint32_t i = 0; i < tr.numLeaves; ++i) {
+            const float wi = leaf(i).weight(flags, dirOut, wl);
+            w[0] = i == 0u ? wi : w[0]; w[1] = i == 1u ? wi : w[1]; w[2] = i == 2u ? wi : w[2]; w[3] = i == 3u ? wi : w[3];
         }
-        res->dirPDF *= wIdx;
+        const float W0 = groupWeight(0u, flags, w), W1 = groupWeight(1u, flags, w);
+        float sumWeights, base;
+        const uint32_t g = sampleDiscrete2(W0, W1, &sumWeights, &base, uComp);
+        if (sumWeights == 0.0f) return S();
+        const float Wsel = g == 0u ? W0 : W1, Wother = g == 0u ? W1 : W0;
+        uComp = (uComp * sumWeights - base) / Wsel;
+        // the selected component: a lobe, or a nested MultiBSDF that selects one of its two lobes the same way
+        const uint32_t first = groupFirst(g), nested = groupSize(g) == 2u;
+        uint32_t selLeaf = first;
+        float innerSum = 0.0f, wa = 0.0f, wb = 0.0f;
+        if (nested) {
+            wa = sel4(w, first); wb = sel4(w, first + 1u);
+            float ibase;
+            const uint32_t ii = sampleDiscrete2(wa, wb, &innerSum, &ibase, uComp);
+            if (innerSum == 0.0f) return S();                    // inner: dirPDF = 0, Zero; outer: dirPDF *= weight stays 0, Zero
+            selLeaf = first + ii;
+            uComp = (uComp * innerSum - ibase) / (ii == 0u ? wa : wb);
+        }
+        S value = leaf(selLeaf).sampleInternal(flags, dirOut, gNorm, wl, uComp, u0, u1, res);
+        const bool delta = dtIsDelta(res->dirType);
+        if (nested) {
+            res->dirPDF *= selLeaf == first ? wa : wb;
+            if (res->dirPDF == 0.0f) return S();
+            if (!delta) {
+                const uint32_t other = selLeaf == first ? first + 1u : first;
+                const Component<S> c = leaf(other);
+                if (c.matches(flags)) res->dirPDF += c.evaluatePDFInternal(flags, dirOut, res->dir_sn, wl) * (other == first ? wa : wb);
+            }
+            res->dirPDF /= innerSum;
+        }
+        res->dirPDF *= Wsel;
         if (res->dirPDF == 0.0f) return S();
-        if (!dtIsDelta(res->dirType)) {
+        if (!delta) {
+            // the other root component's PDF term (:41-45)
+            const uint32_t og = 1u - g, of = groupFirst(og);
+            if (groupMatches(og, flags)) {
+                float pdfOther;
+                if (groupSize(og) == 1u) pdfOther = leaf(of).evaluatePDFInternal(flags, dirOut, res->dir_sn, wl);
+                else {
+                    // MultiBSDF::evaluatePDFInternalNoRev (:151-169) of the nested component
+                    const float oa = sel4(w, of), ob = sel4(w, of + 1u);
+                    const float osum = oa + ob;
+                    pdfOther = 0.0f;
+                    if (osum != 0.0f) {
+#pragma unroll 1
+                        for (uint32_t k = 0; k < 2u; ++k) {
+                            const float wk = k == 0u ? oa : ob;
+                            if (wk > 0) pdfOther += leaf(of + k).evaluatePDFInternal(flags, dirOut, res->dir_sn, wl) * wk;
+                        }
+                        pdfOther /= osum;
+                    }
+                }
+                res->dirPDF += pdfOther * Wother;
+            }
+            // the value: the sum over the matching components, each a lobe or the sum over ITS matching lobes (:47-55, :125-149)
             const uint32_t mflags = flags & sideTest(gNorm, dirOut, res->dir_sn);
             value = S();
-            // the loops of :41-55 unrolled in component order; the PDF term belongs to the component that was not selected
-            for (int i = 0; i < 2; ++i) {
-                const Component<S> c = component(i);
-                if (i != (int)idx && c.matches(flags)) res->dirPDF += c.evaluatePDFInternal(flags, dirOut, res->dir_sn, wl) * wOther;
-                if (c.matches(mflags)) value = value + c.evaluateInternal(mflags, dirOut, gNorm, res->dir_sn, wl);
+            S groupValue;
+            bool groupOn = groupMatches(0u, mflags);
+#pragma unroll 1
+            for (uint32_t i = 0; i < tr.numLeaves; ++i) {
+                if (i == tr.size0) { if (groupOn) value = value + groupValue; groupValue = S(); groupOn = groupMatches(1u, mflags); }
+                if (!groupOn) continue;
+                const Component<S> c = leaf(i);
+                if (c.matches(mflags)) groupValue = groupValue + c.evaluateInternal(mflags, dirOut, gNorm, res->dir_sn, wl);
             }
+            if (groupOn) value = value + groupValue;
         }
         res->dirPDF /= sumWeights;
         const float snCorrection = fabsf(res->dir_sn.z / dot(res->dir_sn, gNorm));
@@ -194,19 +308,43 @@ struct MultiBSDF {
         const uint32_t queryFlags = DT_All;
         const uint32_t flags = queryFlags & sideTest(gNorm, dirOut, dir);
         const bool evalMatches = dtMatches(type, flags);
-        S fs_sn;
-        float weights[2], pdfs[2] = {0.0f, 0.0f};
-        for (int i = 0; i < 2; ++i) {
-            const Component<S> c = component(i);
-            weights[i] = c.weight(queryFlags, dirOut, wl);
-            if (weights[i] > 0) pdfs[i] = c.evaluatePDFInternal(queryFlags, dirOut, dir, wl);
-            if (evalMatches && c.matches(flags)) fs_sn = fs_sn + c.evaluateInternal(flags, dirOut, gNorm, dir, wl);
+        S fs_sn, groupValue;
+        float w[4] = {0.0f, 0.0f, 0.0f, 0.0f}, p[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        bool groupOn = evalMatches && groupMatches(0u, flags);
+#pragma unroll 1
+        for (uint32_t i = 0; i < tr.numLeaves; ++i) {
+            if (i == tr.size0) { if (groupOn) fs_sn = fs_sn + groupValue; groupValue = S(); groupOn = evalMatches && groupMatches(1u, flags); }
+            const Component<S> c = leaf(i);
+            const float wi = c.weight(queryFlags, dirOut, wl);
+            const float pi = wi > 0 ? c.evaluatePDFInternal(queryFlags, dirOut, dir, wl) : 0.0f;
+            w[0] = i == 0u ? wi : w[0]; w[1] = i == 1u ? wi : w[1]; w[2] = i == 2u ? wi : w[2]; w[3] = i == 3u ? wi : w[3];
+            p[0] = i == 0u ? pi : p[0]; p[1] = i == 1u ? pi : p[1]; p[2] = i == 2u ? pi : p[2]; p[3] = i == 3u ? pi : p[3];
+            if (groupOn && c.matches(flags)) groupValue = groupValue + c.evaluateInternal(flags, dirOut, gNorm, dir, wl);
         }
-        const float sumWeights = weights[0] + weights[1];
+        if (groupOn) fs_sn = fs_sn + groupValue;
+        // PDFs in nesting order
+        float W[2], P[2];
+#pragma unroll
+        for (uint32_t g = 0; g < 2u; ++g) {
+            const uint32_t f = groupFirst(g);
+            W[g] = groupWeight(g, queryFlags, w);
+            if (groupSize(g) == 1u) P[g] = sel4(p, f);
+            else {
+                const float a = sel4(w, f), b = sel4(w, f + 1u), sum = a + b;
+                float r = 0.0f;
+                if (sum != 0.0f) {
+                    if (a > 0) r += sel4(p, f) * a;
+                    if (b > 0) r += sel4(p, f + 1u) * b;
+                    r /= sum;
+                }
+                P[g] = r;
+            }
+        }
+        const float sumWeights = W[0] + W[1];
         float retPDF = 0.0f;
         if (dtMatches(type, queryFlags) && sumWeights != 0.0f) {
-            if (weights[0] > 0) retPDF += pdfs[0] * weights[0];
-            if (weights[1] > 0) retPDF += pdfs[1] * weights[1];
+            if (W[0] > 0) retPDF += P[0] * W[0];
+            if (W[1] > 0) retPDF += P[1] * W[1];
             retPDF /= sumWeights;
         }
         *pdf = retPDF;

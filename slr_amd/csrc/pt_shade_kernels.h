@@ -601,11 +601,11 @@ __device__ __forceinline__ void logicSlot(const DevScene& sc, const PathBuffers&
                     return cm;
                 };
                 const bool isMulti = MULTI && m.type == SLRHIP_MATERIAL_MULTI;
-                MultiRec multiRec = {};
+                MultiTree multiTree = {};
                 if constexpr (MULTI) {
                     if (isMulti) {
-                        multiRec = decodeMulti(m);
-                        type = multiType(multiRec, wlSel);
+                        multiTree = buildMultiTree<S>(decodeMulti(m), loadComponent);
+                        type = multiType(multiTree, wlSel);
                     }
                 }
                 if (dtMatches(type, DT_WholeSphere | DT_NonDelta)) {
@@ -692,7 +692,7 @@ __device__ __forceinline__ void logicSlot(const DevScene& sc, const PathBuffers&
                     bool evaluated = false;
                     if constexpr (MULTI) {
                         if (isMulti) {
-                            const MultiBSDF<S, decltype(loadComponent)> multi = {multiRec, wlSel, loadComponent};
+                            const MultiBSDF<S, decltype(loadComponent)> multi = {multiTree, wlSel, loadComponent};
                             fs = multi.evaluate(type, dirOut_sn, gNorm_sn, shadowDir_sn, wl, &pdfDir);
                             evaluated = true;
                         }
@@ -715,7 +715,7 @@ __device__ __forceinline__ void logicSlot(const DevScene& sc, const PathBuffers&
                 bool sampled = false;
                 if constexpr (MULTI) {
                     if (isMulti) {
-                        const MultiBSDF<S, decltype(loadComponent)> multi = {multiRec, wlSel, loadComponent};
+                        const MultiBSDF<S, decltype(loadComponent)> multi = {multiTree, wlSel, loadComponent};
                         fs = multi.sample(type, dirOut_sn, gNorm_sn, wl, uComp, u0, u1, &bs);
                         sampled = true;
                     }
@@ -1078,8 +1078,8 @@ __global__ void __launch_bounds__(64) k_bsdf_queries(DevScene sc, uint32_t mater
             if (cm.type & kMatTexturedBit) (void)texturizeMat<S>(sc, cm, idx, 0.0f, 0.0f, wlOffset);
             return cm;
         };
-        const MultiBSDF<S, decltype(loadComponent)> multi = {decodeMulti(m), 0u, loadComponent};
-        const uint32_t type = multiType(multi.rec, 0u);
+        const MultiBSDF<S, decltype(loadComponent)> multi = {buildMultiTree<S>(decodeMulti(m), loadComponent), 0u, loadComponent};
+        const uint32_t type = multiType(multi.tr, 0u);
         fs = multi.sample(type, dirOut, gNorm, wl, q[9], q[10], q[11], &bs);
         fe = multi.evaluate(type, dirOut, gNorm, dirIn, wl, &pdf);
     }

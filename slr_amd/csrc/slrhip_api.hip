@@ -337,7 +337,7 @@ int slrhip_upload_scene(slrhip_ctx* ctx, const slrhip_scene_desc* d) {
         if (m.type > SLRHIP_MATERIAL_MULTI)
             return fail(SLRHIP_ERR_UNSUPPORTED, "slrhip_upload_scene: unknown material type");
         if (m.type == SLRHIP_MATERIAL_MULTI) {
-            // MultiBSDF of two earlier single-lobe materials (include/slrhip.h); the record carries indices, scales, flags
+            // MultiBSDF of two earlier materials — single lobes, or MULTI records of single lobes (include/slrhip.h); the record carries indices, scales, flags
             if ((uint32_t)m.spectrum[2] > 3u)
                 return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: MULTI material with unknown inverse bits");
             uint32_t childType[2];
@@ -346,9 +346,16 @@ int slrhip_upload_scene(slrhip_ctx* ctx, const slrhip_scene_desc* d) {
                     return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: MULTI component must be an earlier entry of the material table");
                 if ((uint32_t)m.spectrum[k] > kMultiMaxChildIndex)
                     return fail(SLRHIP_ERR_UNSUPPORTED, "slrhip_upload_scene: MULTI component index beyond 1023");
-                childType[k] = d->materials[m.spectrum[k]].type;
-                if (childType[k] >= SLRHIP_MATERIAL_MULTI)
-                    return fail(SLRHIP_ERR_UNSUPPORTED, "slrhip_upload_scene: MULTI components must be single-lobe materials (no nesting)");
+                const slrhip_material& cmat = d->materials[m.spectrum[k]];
+                childType[k] = cmat.type;
+                if (childType[k] == SLRHIP_MATERIAL_MULTI) {
+                    // one level of nesting: the components of a component are single lobes (four lobes in all, the reference's
+                    // MultiBSDF::maxNumElems); an InverseBSDF over a MultiBSDF is not supported
+                    if (d->materials[cmat.spectrum[0]].type >= SLRHIP_MATERIAL_MULTI || d->materials[cmat.spectrum[1]].type >= SLRHIP_MATERIAL_MULTI)
+                        return fail(SLRHIP_ERR_UNSUPPORTED, "slrhip_upload_scene: MULTI materials nest one level deep (at most four lobes)");
+                    if ((m.spectrum[2] >> k) & 1)
+                        return fail(SLRHIP_ERR_UNSUPPORTED, "slrhip_upload_scene: inverse of a MULTI component is not supported");
+                }
                 if (((m.spectrum[2] >> k) & 1) && (childType[k] == SLRHIP_MATERIAL_GLASS || childType[k] == SLRHIP_MATERIAL_MICROFACET_GLASS))
                     return fail(SLRHIP_ERR_UNSUPPORTED, "slrhip_upload_scene: inverse of a two-sided lobe (glass, microfacet glass) is not supported");
             }

@@ -12,7 +12,7 @@ values, matte / metal / glass / microfacet / Ward / Ashikhmin materials, diffuse
 setRenderSettings — i.e. the walls, lights, cameras and materials of TestScenes/Cornell_Box_*.txt.  What the image
 lacks (no assimp / OpenEXR, no asset files in the reference tree): load3DModel accepts only the two primitive models
 the test scenes use ("…/sphere.assbin", "…/box.assbin") and substitutes this package's tessellated unit sphere / cube;
-Image2D textures, setEnvironment images, nested "sum" / "mix" / "inverse" materials and the scan* helpers raise UnsupportedFeature
+Image2D textures, setEnvironment images, "sum" / "mix" materials nested more than one level deep and the scan* helpers raise UnsupportedFeature
 ("sum" / "mix" of two single-lobe materials, either possibly "inverse", load as SLRHIP_MATERIAL_MULTI).
 """
 import math
@@ -670,7 +670,7 @@ class Interpreter:
                 spectrum_cache[key] = _bind_spectrum(b, sv)
             return spectrum_cache[key]
 
-        def material(m, see_emitter=True):
+        def material(m, see_emitter=True, multi_levels=2):
             key = (id(m), see_emitter)        # m stays alive in the node graph, so its id is stable
             if key in material_cache:
                 return material_cache[key]
@@ -684,11 +684,11 @@ class Interpreter:
                 for c in (p["mat0"], p["mat1"]):
                     flipped = c.kind == "inverse"
                     leaf = c.params["base"] if flipped else c
-                    if leaf.kind in ("sum", "mix", "inverse"):
-                        raise UnsupportedFeature('nested "sum" / "mix" / "inverse" materials')
+                    if leaf.kind == "inverse" or (leaf.kind in ("sum", "mix") and (flipped or multi_levels <= 1)):
+                        raise UnsupportedFeature('"sum" / "mix" materials nested more than one level deep, or an "inverse" of one')
                     if flipped and leaf.kind in ("glass", "microfacet glass"):
                         raise UnsupportedFeature('"inverse" of a two-sided material (%s)' % leaf.kind)
-                    comps.append(material(leaf, see_emitter=False))      # a component's own emitter is not seen through the sum
+                    comps.append(material(leaf, see_emitter=False, multi_levels=multi_levels - 1))      # a component's own emitter is not seen through the sum
                     inv.append(flipped)                                  # (SurfaceMaterial::isEmitting is false for it)
                 if m.kind == "sum":
                     idx = b.summed(comps[0], comps[1], inv, emit)

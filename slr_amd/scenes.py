@@ -377,6 +377,62 @@ def material_zoo():
     return b.build(cornell_camera(1.0), name="material_zoo"), mats
 
 
+def material_zoo_nested():
+    """MultiBSDFs whose components are MultiBSDFs (SummedSurfaceMaterial / MixedSurfaceMaterial of summed / mixed materials:
+    one level of nesting, up to four lobes — MultiBSDF.cpp:20-59 calling itself through the BSDF interface), for the
+    function-level known-answer tests.  Returns (scene, {name: material index}); the libm-free entries are bit-exact on the GPU."""
+    b = SceneBuilder()
+    cornell_walls(b)
+    one = b.spectrum_grey(1.0)
+    lambert = b.matte(b.spectrum_srgb_nonlinear(0.75, 0.5, 0.25))
+    thin = b.matte(b.spectrum_srgb_nonlinear(0.2, 0.6, 0.3))
+    oren = b.matte(b.spectrum_srgb_nonlinear(0.7, 0.6, 0.3), sigma=0.6)
+    mirror = b.metal(one, b.spectrum_ior("Aluminium", 0, ALUMINIUM_ETA_RGB), b.spectrum_ior("Aluminium", 1, ALUMINIUM_K_RGB))
+    glass = b.glass(b.spectrum_grey(0.999), b.spectrum_ior("Air", 0, AIR_ETA_RGB), b.spectrum_ior("Glass_BK7", 0, BK7_ETA_RGB))
+    ward = b.ward(b.spectrum_srgb_nonlinear(0.8, 0.7, 0.4), 0.15, 0.4)
+    ggx = b.microfacet_metal(b.spectrum_ior("Titanium", 0, TITANIUM_ETA_RGB), b.spectrum_ior("Titanium", 1, TITANIUM_K_RGB), 0.5)
+    mix_lo = b.mixed(lambert, oren, 0.4)
+    sum_lm = b.summed(lambert, mirror)
+    sum_oi = b.summed(oren, thin, inverse=(False, True))
+    mix_gw = b.mixed(ggx, ward, 0.7)
+    mats = {
+        "sum_of_mix_and_mirror": b.summed(mix_lo, mirror),                    # nested on the left
+        "mix_of_lambert_and_sum_with_inverse": b.mixed(lambert, sum_oi, 0.35),  # nested on the right, an InverseBSDF inside
+        "sum_of_two_sums": b.summed(sum_lm, sum_oi),                          # four lobes, delta + diffuse + transmitted
+        "mix_of_mix_and_glass": b.mixed(mix_lo, glass, 0.25),                 # a two-sided delta lobe next to a nested pair
+        "sum_of_mix_ggx_ward_and_lambert": b.summed(mix_gw, lambert),         # float-libm lobes nested
+        "mix_of_two_mixes": b.mixed(mix_lo, mix_gw, 0.6),
+    }
+    for i, m in enumerate(mats.values()):
+        x, z = -1.2 + 0.22 * (i % 11), -0.3 * (i // 11)
+        b.add_quad([(x, 0.01, z), (x + 0.2, 0.01, z), (x + 0.2, 0.01, z - 0.2), (x, 0.01, z - 0.2)], (0, 1, 0), (1, 0, 0), m)
+    return b.build(cornell_camera(1.0), name="material_zoo_nested"), mats
+
+
+NESTED_LIBM_FREE = ("sum_of_mix_and_mirror", "mix_of_lambert_and_sum_with_inverse", "sum_of_two_sums", "mix_of_mix_and_glass")
+
+
+def cornell_multi_nested(aspect=1.0, segments=12, rings=6):
+    """Nested MultiBSDF materials in a Cornell box, no float-libm lobe on the path (bit-exact on the GPU): a sphere of
+    sum(mix(Lambert, Oren-Nayar; 0.4), specular aluminium), a sphere of mix(mix(Lambert, Oren-Nayar), glass; 0.25) and a
+    free-standing sheet of sum(sum(Lambert, mirror), sum(Oren-Nayar, inverse(Lambert))) — four lobes."""
+    b = SceneBuilder()
+    cornell_walls(b)
+    orange = b.matte(b.spectrum_srgb_nonlinear(0.8, 0.45, 0.15))
+    green = b.matte(b.spectrum_srgb_nonlinear(0.2, 0.6, 0.3))
+    rough = b.matte(b.spectrum_srgb_nonlinear(0.7, 0.7, 0.75), sigma=0.5)
+    al = b.metal(b.spectrum_grey(0.6), b.spectrum_ior("Aluminium", 0, ALUMINIUM_ETA_RGB), b.spectrum_ior("Aluminium", 1, ALUMINIUM_K_RGB))
+    glass = b.glass(b.spectrum_grey(0.999), b.spectrum_ior("Air", 0, AIR_ETA_RGB), b.spectrum_ior("Glass_BK7", 0, BK7_ETA_RGB))
+    blend = b.mixed(orange, rough, 0.4)
+    lacquer = b.summed(blend, al)
+    frosted = b.mixed(blend, glass, 0.25)
+    leaf = b.summed(b.summed(orange, al), b.summed(rough, green, inverse=(False, True)))
+    b.add_uv_sphere(segments, rings, lacquer, _translate(-0.7, 0, -0.8) @ _scale(0.5) @ _translate(0, 1, 0))
+    b.add_uv_sphere(segments, rings, frosted, _translate(0.75, 0, -0.2) @ _scale(0.45) @ _translate(0, 1, 0))
+    b.add_quad([(-0.4, 0.0, 0.9), (0.5, 0.0, 0.6), (0.5, 1.3, 0.6), (-0.4, 1.3, 0.9)], (0.316, 0, 0.949), (0.949, 0, -0.316), leaf)
+    return b.build(cornell_camera(aspect), name="cornell_multi_nested")
+
+
 def bsdf_queries(n=256, seed=2024):
     """[n][12] query rows for slrhip_bsdf_queries / the oracle's bsdf_kat: outgoing direction, geometric normal (tilted up
     to ~30 degrees off the shading normal) and incoming direction in the shading frame, plus the three sample numbers.

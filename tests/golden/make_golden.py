@@ -104,12 +104,12 @@ def make_procedural(name, generator, args, lib, width, height, spp):
 KAT_WAVELENGTHS = ((0.37, 0.61), (0.0, 0.0), (0.93, 0.9999))    # (offset, uLambda) of createWithEqualOffsets
 
 
-def make_bsdf_kat(name, lib):
+def make_bsdf_kat(name, lib, zoo=None):
     """Function-level known answers (SURVEY 8c): BSDF::sample / evaluate / evaluatePDF of the reference's own BSDF objects,
     one material per lobe, 192 queries (scenes.bsdf_queries) under three wavelength selections."""
     if lib is None:
         raise SystemExit("reference library for %s not built" % name)
-    sc, mats = scenes.material_zoo()
+    sc, mats = (zoo or scenes.material_zoo)()
     ref = lib.scene(sc)
     q = scenes.bsdf_queries(192, 2024)
     out = dict(scene_arrays(sc))
@@ -277,7 +277,25 @@ def main_round2(only):
         make_procedural("rgb_grid400", "displaced_grid", (400, 16.0 / 9.0), lib, 160, 90, 8)
 
 
+def main_round3(only):
+    """Fixtures added in round 3: nested MultiBSDFs (a summed / mixed material whose components are summed / mixed materials,
+    SummedSurfaceMaterial.cpp:13-20 over MultiBSDF.cpp:20-59), function level and whole frames, both builds of the reference."""
+    spec = ob.load("ref_spectral")
+    lib = ob.load("ref_rgb")
+    if not only or "bsdf_kat_nested_rgb" in only:
+        make_bsdf_kat("bsdf_kat_nested_rgb", lib, scenes.material_zoo_nested)
+    if not only or "bsdf_kat_nested_spectral" in only:
+        make_bsdf_kat("bsdf_kat_nested_spectral", spec, scenes.material_zoo_nested)
+    if not only or "rgb_multi_nested" in only:
+        make("rgb_multi_nested", scenes.cornell_multi_nested(1.0, 12, 6), lib, 40, 40, 8, 2)
+    if not only or "spectral_multi_nested" in only:
+        make("spectral_multi_nested", scenes.cornell_multi_nested(1.0, 10, 5), spec, 32, 32, 8, 2)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "round3":
+        main_round3(sys.argv[2:])
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "round2":
         main_round2(sys.argv[2:])
         sys.exit(0)

@@ -708,14 +708,43 @@ def test_multibsdf_with_ggx_component_within_tolerance(name):
     libm_tolerance(fb, want, name + " vs reference golden", within=TOL[name])
 
 
+@pytest.mark.parametrize("mode", ["rgb", "spectral"])
+def test_nested_multibsdf_matches_reference_golden(mode):
+    """a summed / mixed material whose components are summed / mixed materials (MultiBSDF.cpp:20-59,125-212
+    calling itself through the BSDF interface; up to four lobes).  Function level against the compiled reference's answers on
+    six nested materials (tests/golden/bsdf_kat_nested_*.npz): every float bit-equal where no float-libm lobe is a component,
+    the libm tolerance otherwise; and a whole frame with four-lobe materials, bit for bit."""
+    amode = abi.MODE_RGB if mode == "rgb" else abi.MODE_SPECTRAL
+    g = load_golden("bsdf_kat_nested_" + mode)
+    c = Context(device=0, mode=amode, stripes=1)
+    try:
+        c.upload_scene(scene_from_golden(g))
+        for name, m in zip(g["material_names"], g["material_indices"]):
+            name, m = str(name), int(m)
+            got = np.stack([c.bsdf_queries(m, g["queries"], float(off), float(ul)) for off, ul in g["wavelengths"]])
+            if name in scenes.NESTED_LIBM_FREE:
+                assert_bit_equal(got, g["out_" + name], "%s %s vs golden" % (mode, name))
+            else:
+                _assert_lobe_close(got, g["out_" + name], "%s %s vs golden" % (mode, name), 0.5, 0.01, 1e-4, 1e-2)
+        f = load_golden(mode + "_multi_nested")
+        st = ob.settings(int(f["width"]), int(f["height"]), int(f["seed"]))
+        fb = c.render_image(scene_from_golden(f), st, int(f["spp"]))
+        assert_bit_equal(fb, f["framebuffer"], mode + " nested MultiBSDF frame")
+        assert c.counters().samples == int(f["width"]) * int(f["height"]) * int(f["spp"])
+    finally:
+        c.close()
+
+
 def test_multibsdf_rejects_what_it_does_not_support(ctx):
     b = scenes.SceneBuilder()
     scenes.cornell_walls(b)
     glass = b.glass(b.spectrum_grey(0.999), b.spectrum_ior("Air", 0, scenes.AIR_ETA_RGB), b.spectrum_ior("Glass_BK7", 0, scenes.BK7_ETA_RGB))
     matte = b.matte(b.spectrum_grey(0.5))
     inner = b.summed(matte, matte)
+    deeper = b.summed(inner, matte)                                          # one level of nesting: accepted
     for bad in (lambda: b.summed(matte, glass, inverse=(False, True)),       # inverse of a two-sided lobe
-                lambda: b.summed(inner, matte),                              # nesting
+                lambda: b.summed(deeper, matte),                             # two levels of nesting
+                lambda: b.summed(inner, matte, inverse=(True, False)),       # inverse of a MULTI component
                 lambda: b.material(abi.MAT_MULTI, (matte, 10_000, 0), 1.0, -1, 1.0)):   # component index out of range
         n = len(b.materials)
         bad()

@@ -192,11 +192,39 @@ def test_bsdf_known_answers(oracle_rgb, oracle_spectral, mode):
 
 
 @pytest.mark.parametrize("mode", ["rgb", "spectral"])
+def test_nested_multibsdf_known_answers_and_frame(oracle_rgb, oracle_spectral, mode):
+    """A summed / mixed material whose components are summed / mixed materials: the reference builds a MultiBSDF of MultiBSDFs
+    (SummedSurfaceMaterial.cpp:13-20, MixedSurfaceMaterial.cpp:14-22) and MultiBSDF.cpp:20-59,125-212 then calls itself through
+    the BSDF interface.  Every float of sample / evaluate / evaluatePDF on six nested materials (two to four lobes, an
+    InverseBSDF and a two-sided delta lobe among them), and a whole frame, against the compiled reference's answers."""
+    lib = oracle_rgb if mode == "rgb" else oracle_spectral
+    g = load_golden("bsdf_kat_nested_" + mode)
+    sc = lib.scene(scene_from_golden(g))
+    C = sc.components
+    for name, m in zip(g["material_names"], g["material_indices"]):
+        for w, (off, ul) in enumerate(g["wavelengths"]):
+            got = sc.bsdf_kat(int(m), g["queries"], float(off), float(ul))
+            want = g["out_" + str(name)][w]
+            assert got.shape == want.shape == (len(g["queries"]), 6 + 2 * C)
+            assert_bit_equal(got, want, "%s %s wl %d" % (mode, name, w))
+        assert (g["out_" + str(name)][0][:, 3] != 0).mean() > 0.75, name
+    f = load_golden(mode + "_multi_nested")
+    fb, ctr = lib.scene(scene_from_golden(f)).render(ob.settings(int(f["width"]), int(f["height"]), int(f["seed"])), int(f["spp"]), threads=0)
+    assert_bit_equal(fb, f["framebuffer"], mode + " nested frame")
+    assert f["framebuffer"].sum() > 0
+
+
+@pytest.mark.parametrize("mode", ["rgb", "spectral"])
 def test_bsdf_queries_match_compiled_reference(request, oracle_rgb, oracle_spectral, mode):
     """Same comparison against the compiled reference itself on fresh random queries (container only)."""
     from slr_amd import scenes
     ref_lib = request.getfixturevalue("ref_" + mode)
     scene, mats = scenes.material_zoo()
+    nested_scene, nested = scenes.material_zoo_nested()
+    on, rn = (oracle_rgb if mode == "rgb" else oracle_spectral).scene(nested_scene), ref_lib.scene(nested_scene)
+    qn = scenes.bsdf_queries(1024, 99)
+    for name, m in nested.items():
+        assert_bit_equal(on.bsdf_kat(m, qn, 0.25, 0.8), rn.bsdf_kat(m, qn, 0.25, 0.8), "%s nested %s" % (mode, name))
     o = (oracle_rgb if mode == "rgb" else oracle_spectral).scene(scene)
     r = ref_lib.scene(scene)
     q = scenes.bsdf_queries(1024, 7)

@@ -177,7 +177,19 @@ def test_summed_mixed_and_inverse_materials_become_multi_records():
     assert set(sc.triangles["material"]) == {2, 5}
 
 
-@pytest.mark.parametrize("extra, used", [('bad = createSurfaceMaterial("sum", (green, ti));', "bad"),                    # nesting
+def test_one_level_of_nested_sum_mix_materials_loads():
+    """sum(matte, sum(matte, inverse(matte))): a summed material whose component is a summed material (MULTI record over a MULTI
+    record), as SummedSurfaceMaterial.cpp:13-20 builds it."""
+    from slr_amd import abi
+    it = sl.Interpreter()
+    it.run(MULTI_SCRIPT % ('nested = createSurfaceMaterial("sum", (green, ti));', "nested"))
+    m = it.build().materials
+    top = [i for i, t in enumerate(m["type"]) if t == abi.MAT_MULTI][-1]
+    kinds = [m["type"][m["spectrum"][top][k]] for k in range(2)]
+    assert sorted(kinds) == sorted([abi.MAT_MATTE, abi.MAT_MULTI])
+
+
+@pytest.mark.parametrize("extra, used", [('mid = createSurfaceMaterial("sum", (green, ti)); bad = createSurfaceMaterial("sum", (mid, green));', "bad"),      # two levels of nesting
                                          ('bad = createSurfaceMaterial("inverse", (ti,));', "bad"),                       # inverse on its own
                                          ('g = createSurfaceMaterial("glass", (SpectrumTexture(Spectrum(0.9, 0.9, 0.9)), SpectrumTexture(Spectrum("ID": "Air", 0)), '
                                           'SpectrumTexture(Spectrum("ID": "Glass_BK7", 0)))); bad = createSurfaceMaterial("sum", (ti, createSurfaceMaterial("inverse", (g,))));', "bad")])
