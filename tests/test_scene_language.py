@@ -178,7 +178,7 @@ def test_summed_mixed_and_inverse_materials_become_multi_records():
 
 
 def test_one_level_of_nested_sum_mix_materials_loads():
-    """sum(matte, sum(matte, inverse(matte))): a summed material whose component is a summed material (MULTI record over a MULTI
+    """sum(sum(matte, inverse(matte)), microfacet metal): a summed material whose component is a summed material (MULTI record over a MULTI
     record), as SummedSurfaceMaterial.cpp:13-20 builds it."""
     from slr_amd import abi
     it = sl.Interpreter()
@@ -186,7 +186,7 @@ def test_one_level_of_nested_sum_mix_materials_loads():
     m = it.build().materials
     top = [i for i, t in enumerate(m["type"]) if t == abi.MAT_MULTI][-1]
     kinds = [m["type"][m["spectrum"][top][k]] for k in range(2)]
-    assert sorted(kinds) == sorted([abi.MAT_MATTE, abi.MAT_MULTI])
+    assert sorted(kinds) == sorted([abi.MAT_MF_METAL, abi.MAT_MULTI])
 
 
 @pytest.mark.parametrize("extra, used", [('mid = createSurfaceMaterial("sum", (green, ti)); bad = createSurfaceMaterial("sum", (mid, green));', "bad"),      # two levels of nesting
