@@ -174,14 +174,22 @@ typedef struct slrhip_material {
  * Core/SurfaceObject.cpp:123-134) and its alpha texture (Triangle::m_alphaTex, TriangleMesh.cpp:163-167: a hit where the alpha
  * value is 0 does not occur) ride in slrhip_material::reserved, as the material group of libSLRSceneGraph/TriangleMeshNode
  * pairs them.                                                                                                              */
-enum { SLRHIP_TEXTURE_CHECKER_SPECTRUM = 0, SLRHIP_TEXTURE_CHECKER_FLOAT = 1, SLRHIP_TEXTURE_CHECKER_NORMAL = 2 };
+/*   IMAGE_SPECTRUM    ImageSpectrumTexture: the texel nearest to the mapped coordinate, wrapped by fmod                Textures/image_textures.cpp:13-79
+ *                     reserved[0], reserved[1] = width, height; reserved[2] = index of the image's first texel in
+ *                     slrhip_scene_desc::texture_texels (3 floats per texel, row-major).  RGB mode: what the look-up of the
+ *                     reference's RGB build returns (8-bit formats: byte / 255, RGBA16F: the halves).  Spectral mode: (u, v, s) as
+ *                     the spectral build stores the image (Core/Image.h:39-40,265-310), evaluated per hit like
+ *                     UpsampledContinuousSpectrum(u, v, s / EqualEnergyReflectance) (image_textures.cpp:23-32) — needs
+ *                     slrhip_scene_desc::upsampling.  The image decoding and colour conversion stay with the caller (libSLRSceneGraph's
+ *                     image loaders are outside this boundary).                                                                  */
+enum { SLRHIP_TEXTURE_CHECKER_SPECTRUM = 0, SLRHIP_TEXTURE_CHECKER_FLOAT = 1, SLRHIP_TEXTURE_CHECKER_NORMAL = 2, SLRHIP_TEXTURE_IMAGE_SPECTRUM = 3 };
 typedef struct slrhip_texture {
     uint32_t kind;
     float offset[2];
     float scale[2];
     int32_t spectrum[2];       /* CHECKER_SPECTRUM: indices into slrhip_scene_desc::spectra                    */
     float value[2];            /* CHECKER_FLOAT: the two values; CHECKER_NORMAL: stepWidth in (0, 1], reverse   */
-    uint32_t reserved[3];
+    uint32_t reserved[3];      /* IMAGE_SPECTRUM: width, height, first texel; else 0                                 */
 } slrhip_texture;
 #define SLRHIP_TEXTURE_REF(t) (-2 - (int32_t)(t))              /* value of slrhip_material::spectrum[k] naming texture t */
 #define SLRHIP_MATERIAL_NORMAL_MAP(t) ((uint32_t)(t) + 1u)      /* OR into slrhip_material::reserved: bits 0..15  */
@@ -255,6 +263,8 @@ typedef struct slrhip_scene_desc {
     const slrhip_upsampling_tables* upsampling;   /* needed only with an environment map in spectral mode, else may be NULL */
     const slrhip_texture* textures;               /* NULL / 0 = no textured material (version 5)                             */
     uint32_t num_textures;
+    const float* texture_texels;                  /* texels of the IMAGE_SPECTRUM textures, 3 floats each (appended in version 7) */
+    uint32_t num_texture_texels;                  /* number of TEXELS                                                        */
 } slrhip_scene_desc;
 
 /* ---- render settings -------------------------------------------------------------- */

@@ -107,6 +107,37 @@ public:
     }
 };
 
+// A material's image texture: ImageSpectrumTexture needs Image2D (OpenEXR half, absent here), so — like ArrayEnvTexture — the
+// look-up of image_textures.cpp:13-20 is restated over a float array and the reference's own Texture2DMapping; in the spectral
+// build the reference's own UpsampledContinuousSpectrum does the evaluation (:23-32).  Parity for the texel addressing is
+// therefore unpinned (both sides are restatements); everything after the texel is the reference's.
+class ArrayImageTexture : public SpectrumTexture {
+    const Texture2DMapping* m_mapping;
+    uint32_t m_width, m_height;
+    std::vector<float> m_texels;
+public:
+    ArrayImageTexture(const Texture2DMapping* mapping, uint32_t w, uint32_t h, const float* texels) : m_mapping(mapping), m_width(w), m_height(h),
+        m_texels(texels, texels + (size_t)w * h * 3) {}
+    SampledSpectrum evaluate(const SurfacePoint &surfPt, const WavelengthSamples &wls) const override {
+        Point3D tc = m_mapping->map(surfPt);
+        float u = std::fmod(tc.x, 1.0f);
+        float v = std::fmod(tc.y, 1.0f);
+        u += u < 0 ? 1.0f : 0.0f;
+        v += v < 0 ? 1.0f : 0.0f;
+        uint32_t px = std::min((uint32_t)(m_width * u), m_width - 1);
+        uint32_t py = std::min((uint32_t)(m_height * v), m_height - 1);
+        const float* t = &m_texels[((size_t)py * m_width + px) * 3];
+        SampledSpectrum ret;
+#ifndef Use_Spectral_Representation
+        ret.r = t[0]; ret.g = t[1]; ret.b = t[2];
+#else
+        ret = UpsampledContinuousSpectrum(t[0], t[1], t[2] / Upsampling::EqualEnergyReflectance).evaluate(wls);
+#endif
+        return ret;
+    }
+    RegularConstantContinuous2D* createIBLImportanceMap() const override { return nullptr; }
+};
+
 struct slr_oracle_scene {
     ArrayEnvTexture* envTexture = nullptr;
     IBLEmission* envEmission = nullptr;
@@ -199,6 +230,8 @@ slr_oracle_scene* slr_ref_create(const slrhip_scene_desc* d, int mode) {
         if (t.kind == SLRHIP_TEXTURE_CHECKER_SPECTRUM) s->texSpectrum[i] = new CheckerBoardSpectrumTexture(mapping, s->spectra[t.spectrum[0]], s->spectra[t.spectrum[1]]);
         else if (t.kind == SLRHIP_TEXTURE_CHECKER_FLOAT) s->texFloat[i] = new CheckerBoardFloatTexture(mapping, t.value[0], t.value[1]);
         else if (t.kind == SLRHIP_TEXTURE_CHECKER_NORMAL) s->texNormal[i] = new CheckerBoardNormal3DTexture(mapping, t.value[0], t.value[1] != 0.0f);
+        else if (t.kind == SLRHIP_TEXTURE_IMAGE_SPECTRUM && d->texture_texels && (uint64_t)t.reserved[2] + (uint64_t)t.reserved[0] * t.reserved[1] <= d->num_texture_texels)
+            s->texSpectrum[i] = new ArrayImageTexture(mapping, t.reserved[0], t.reserved[1], d->texture_texels + (size_t)t.reserved[2] * 3);
         else { delete s; return nullptr; }
     }
     auto tex = [&](int32_t idx) -> const SpectrumTexture* {

@@ -344,6 +344,7 @@ struct slr_oracle_scene {
     std::vector<slrhip_spectrum> spectra;
     std::vector<float> spectrumData;
     std::vector<slrhip_texture> textures;
+    std::vector<float> textureTexels;          // texels of the IMAGE_SPECTRUM textures, 3 floats each
     Camera camera;
     std::vector<uint32_t> lightTris;   // SurfaceObjectAggregate::m_lightList (SurfaceObject.cpp:232-249)
     Discrete1D lightDist;              // m_lightDist1D
@@ -1646,10 +1647,31 @@ float bsdfEvaluatePDF(const AnyBSDF<N>& f, const BSDFQuery<N>& q, V3 dir) {
 //  surface_material.h:65).  `scale * spectrum` with scale = 1.0f is an exact multiply.
 // A material's spectrum slot: a constant spectrum (ConstantSpectrumTexture) or, for SLRHIP_TEXTURE_REF values, a
 // CheckerBoardSpectrumTexture evaluated at the hit's texture coordinate (checker_board_textures.h:21-24).
+// ImageSpectrumTexture::evaluate (Textures/image_textures.cpp:13-79) behind an OffsetAndScale2DMapping (Core/textures.h:37-41):
+// the nearest texel, wrapped by fmod; RGB build: its three floats (:36-63), spectral build: (u, v, s) through
+// UpsampledContinuousSpectrum::evaluate (:23-32).  The texels are the caller's (image decoding is outside the boundary).
+inline const float* imageTexel(const Scene& s, const slrhip_texture& t, float texU, float texV) {
+    const float x = (texU + t.offset[0]) * t.scale[0], y = (texV + t.offset[1]) * t.scale[1];
+    float u = std::fmod(x, 1.0f);
+    float v = std::fmod(y, 1.0f);
+    u += u < 0 ? 1.0f : 0.0f;
+    v += v < 0 ? 1.0f : 0.0f;
+    const uint32_t w = t.reserved[0], h = t.reserved[1];
+    uint32_t px = std::min((uint32_t)(w * u), w - 1);
+    uint32_t py = std::min((uint32_t)(h * v), h - 1);
+    return &s.textureTexels[((size_t)t.reserved[2] + (size_t)py * w + px) * 3];
+}
+template <int N> Spec<N> imageTextureValue(const Scene& s, const float* x, const Wls<N>& wls);
+template <> inline Spec<3> imageTextureValue<3>(const Scene&, const float* x, const Wls<3>&) { Spec<3> r; r.c[0] = x[0]; r.c[1] = x[1]; r.c[2] = x[2]; return r; }
+template <> inline Spec<16> imageTextureValue<16>(const Scene& s, const float* x, const Wls<16>& wls) {
+    const float kEqualEnergyReflectance = 0.009355121400914532f;        // Upsampling::EqualEnergyReflectance, Spectrum.h
+    return evaluateUpsampled(s, x[0], x[1], x[2] / kEqualEnergyReflectance, wls);
+}
 template <int N>
 inline Spec<N> evalSlot(const Scene& s, int32_t slot, float texU, float texV, const Wls<N>& wls) {
     if (slot >= -1) return EvalSpectrum<N>::eval(s, slot, wls);
     const slrhip_texture& t = s.textures[-2 - slot];
+    if (t.kind == SLRHIP_TEXTURE_IMAGE_SPECTRUM) return imageTextureValue<N>(s, imageTexel(s, t, texU, texV), wls);
     return EvalSpectrum<N>::eval(s, t.spectrum[checkerIndex(t, texU, texV)], wls);
 }
 
@@ -2165,11 +2187,26 @@ slr_oracle_scene* slr_oracle_create(const slrhip_scene_desc* d, int mode) {
     if (d->spectra) s->spectra.assign(d->spectra, d->spectra + d->num_spectra);
     if (d->spectrum_data) s->spectrumData.assign(d->spectrum_data, d->spectrum_data + d->num_spectrum_data);
     if (d->textures) s->textures.assign(d->textures, d->textures + d->num_textures);
+    bool anyImageTexture = false;
     for (const slrhip_texture& t : s->textures) {              // every index a texture names must exist
-        bool ok = t.kind <= SLRHIP_TEXTURE_CHECKER_NORMAL;
+        bool ok = t.kind <= SLRHIP_TEXTURE_IMAGE_SPECTRUM;
         if (ok && t.kind == SLRHIP_TEXTURE_CHECKER_SPECTRUM)
             ok = t.spectrum[0] >= 0 && t.spectrum[1] >= 0 && (uint32_t)t.spectrum[0] < d->num_spectra && (uint32_t)t.spectrum[1] < d->num_spectra;
+        if (ok && t.kind == SLRHIP_TEXTURE_IMAGE_SPECTRUM) {
+            ok = t.reserved[0] > 0 && t.reserved[1] > 0 && d->texture_texels &&
+                 (uint64_t)t.reserved[2] + (uint64_t)t.reserved[0] * t.reserved[1] <= d->num_texture_texels && (mode != SLRHIP_MODE_SPECTRAL || d->upsampling);
+            anyImageTexture = true;
+        }
         if (!ok) { delete s; return nullptr; }
+    }
+    if (anyImageTexture) s->textureTexels.assign(d->texture_texels, d->texture_texels + (size_t)d->num_texture_texels * 3);
+    if (mode == SLRHIP_MODE_SPECTRAL && d->upsampling && (anyImageTexture || d->env)) {
+        const slrhip_upsampling_tables* t = d->upsampling;
+        if (!t->cells || !t->point_uv || !t->point_spectrum) { delete s; return nullptr; }
+        s->gridWidth = t->grid_width; s->gridHeight = t->grid_height;
+        s->gridCells.assign(t->cells, t->cells + (size_t)t->grid_width * t->grid_height * 8);
+        s->pointUV.assign(t->point_uv, t->point_uv + (size_t)t->num_points * 2);
+        s->pointSpectrum.assign(t->point_spectrum, t->point_spectrum + (size_t)t->num_points * 95);
     }
     for (uint32_t i = 0; i < d->num_materials; ++i) {          // texture references of single-lobe materials
         const slrhip_material& m = s->materials[i];
@@ -2178,7 +2215,8 @@ slr_oracle_scene* slr_oracle_create(const slrhip_scene_desc* d, int mode) {
         if (ok && (m.reserved >> 16)) ok = s->textures[(m.reserved >> 16) - 1].kind == SLRHIP_TEXTURE_CHECKER_FLOAT;
         for (int k = 0; k < 3 && ok && m.type != SLRHIP_MATERIAL_MULTI; ++k)
             if (m.spectrum[k] < -1)
-                ok = (uint32_t)(-2 - m.spectrum[k]) < s->textures.size() && s->textures[-2 - m.spectrum[k]].kind == SLRHIP_TEXTURE_CHECKER_SPECTRUM;
+                ok = (uint32_t)(-2 - m.spectrum[k]) < s->textures.size() && (s->textures[-2 - m.spectrum[k]].kind == SLRHIP_TEXTURE_CHECKER_SPECTRUM ||
+                                                                                 s->textures[-2 - m.spectrum[k]].kind == SLRHIP_TEXTURE_IMAGE_SPECTRUM);
         if (!ok) { delete s; return nullptr; }
     }
     for (uint32_t i = 0; i < d->num_materials; ++i) {          // the restrictions include/slrhip.h states for MULTI
@@ -2221,14 +2259,7 @@ slr_oracle_scene* slr_oracle_create(const slrhip_scene_desc* d, int mode) {
         }
         s->envWidth = e.width; s->envHeight = e.height; s->envScale = e.scale;
         s->envTexels.assign(e.texels, e.texels + (size_t)e.width * e.height * 3);
-        if (mode == SLRHIP_MODE_SPECTRAL) {
-            const slrhip_upsampling_tables* t = d->upsampling;
-            if (!t || !t->cells || !t->point_uv || !t->point_spectrum) { delete s; return nullptr; }
-            s->gridWidth = t->grid_width; s->gridHeight = t->grid_height;
-            s->gridCells.assign(t->cells, t->cells + (size_t)t->grid_width * t->grid_height * 8);
-            s->pointUV.assign(t->point_uv, t->point_uv + (size_t)t->num_points * 2);
-            s->pointSpectrum.assign(t->point_spectrum, t->point_spectrum + (size_t)t->num_points * 95);
-        }
+        if (mode == SLRHIP_MODE_SPECTRAL && !d->upsampling) { delete s; return nullptr; }      // (tables copied above)
         // createIBLImportanceMap's pickFunc, image_textures.cpp:131: sin(M_PI * (y + 0.5f) / mapHeight) * luminance
         std::vector<float> values((size_t)e.map_width * e.map_height);
         for (uint32_t y = 0; y < e.map_height; ++y)

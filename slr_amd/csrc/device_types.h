@@ -115,8 +115,9 @@ struct alignas(16) DevSpectrum {
 };
 static_assert(sizeof(DevSpectrum) == 32, "DevSpectrum layout");
 
-// One slrhip_texture (checkerboard textures, pt_tex.h), 64 B = four float4; the RGB build's values of a CHECKER_SPECTRUM's two
-// spectra are resolved at upload, the spectral build reads the spectrum indices.
+// One slrhip_texture (checkerboard and image textures, pt_tex.h), 64 B = four float4; the RGB build's values of a CHECKER_SPECTRUM's two
+// spectra are resolved at upload, the spectral build reads the spectrum indices.  IMAGE_SPECTRUM: spec0 / spec1 = width / height,
+// pad = index of the image's first texel in DevScene::texTexels.
 struct alignas(16) DevTexture {
     uint32_t kind; float ox, oy, sx;
     float sy, v0, v1; int32_t spec0;

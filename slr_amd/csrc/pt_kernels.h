@@ -31,6 +31,7 @@ struct DevScene {
     const DevMatTex* matTex;      // per material
     const float4* triUV;          // per scene triangle: (u0, v0, u1, v1), (u2, v2, -, -)
     const float4* alphaTris;      // per alpha record (LeafTri::alpha): the same two float4 + the alpha texture index
+    const float* texTexels;       // texels of the image textures, 3 floats each: (r, g, b), spectral mode (u, v, s)
     uint32_t numTextures;
     uint32_t numSpectra;
     uint32_t numSpectrumData;     // floats in spectrumPool (padded to a multiple of 4 on upload)

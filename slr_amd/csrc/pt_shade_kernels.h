@@ -409,17 +409,29 @@ struct ShadeLds {
 #ifndef SLR_WAVES_RGB
 #define SLR_WAVES_RGB 2
 #endif
-// A CheckerBoardSpectrumTexture behind a material's spectrum slot (checker_board_textures.h:21-24): one of its two constant
-// spectra.  RGB build: their values are in the texture record; spectral build: evaluated at the path's wavelengths like any
-// other constant (tables in HBM: textured scenes run the kernel variant without LDS tables).
+// The texture behind a material's spectrum slot, evaluated at the hit's texture coordinate.
+//   CheckerBoardSpectrumTexture (checker_board_textures.h:21-24): one of its two constant spectra.  RGB build: their values are in
+//   the texture record; spectral build: evaluated at the path's wavelengths like any other constant (tables in HBM: textured
+//   scenes run the kernel variant without LDS tables).
+//   ImageSpectrumTexture (Textures/image_textures.cpp:13-79): the nearest texel; RGB build: its three floats; spectral build:
+//   UpsampledContinuousSpectrum(u, v, s / EqualEnergyReflectance) with its grid look-up at run time (:23-32), like the environment map.
 template <class S> struct TexSpectrum {
-    static __device__ __forceinline__ S eval(const DevScene& sc, const DevTexture& t, int which, float wlOffset) {
-        return evalSpectrum<S>(sc.spectra, sc.spectrumPool, which ? t.spec1 : t.spec0, wlOffset);
+    static __device__ __forceinline__ S eval(const DevScene& sc, const DevTexture& t, float texU, float texV, float wlOffset) {
+        if (t.kind == SLRHIP_TEXTURE_IMAGE_SPECTRUM) {
+            const float* x = sc.texTexels + (size_t)imageTexel(t, texU, texV) * 3;
+            const float kEqualEnergyReflectance = 0.009355121400914532f;                 // Upsampling::EqualEnergyReflectance
+            return evaluateUpsampledRuntime<S>(sc, x[0], x[1], x[2] / kEqualEnergyReflectance, wlOffset);
+        }
+        return evalSpectrum<S>(sc.spectra, sc.spectrumPool, checkerIndex(t, texU, texV) ? t.spec1 : t.spec0, wlOffset);
     }
 };
 template <> struct TexSpectrum<RGB> {
-    static __device__ __forceinline__ RGB eval(const DevScene&, const DevTexture& t, int which, float) {
-        return which ? RGB(t.rgb1[0], t.rgb1[1], t.rgb1[2]) : RGB(t.rgb0[0], t.rgb0[1], t.rgb0[2]);
+    static __device__ __forceinline__ RGB eval(const DevScene& sc, const DevTexture& t, float texU, float texV, float) {
+        if (t.kind == SLRHIP_TEXTURE_IMAGE_SPECTRUM) {
+            const float* x = sc.texTexels + (size_t)imageTexel(t, texU, texV) * 3;
+            return RGB(x[0], x[1], x[2]);
+        }
+        return checkerIndex(t, texU, texV) ? RGB(t.rgb1[0], t.rgb1[1], t.rgb1[2]) : RGB(t.rgb0[0], t.rgb0[1], t.rgb0[2]);
     }
 };
 
@@ -429,9 +441,9 @@ template <class S>
 __device__ __forceinline__ int32_t texturizeMat(const DevScene& sc, Mat<S>& mm, uint32_t matIndex, float texU, float texV, float wlOffset) {
     mm.type &= ~kMatTexturedBit;
     const int4 mt = *reinterpret_cast<const int4*>(sc.matTex + matIndex);
-    if (mt.x >= 0) { const DevTexture t = loadTexture(sc.textures, (uint32_t)mt.x); mm.a = 1.0f * TexSpectrum<S>::eval(sc, t, checkerIndex(t, texU, texV), wlOffset); }
-    if (mt.y >= 0) { const DevTexture t = loadTexture(sc.textures, (uint32_t)mt.y); mm.b = TexSpectrum<S>::eval(sc, t, checkerIndex(t, texU, texV), wlOffset); }
-    if (mt.z >= 0) { const DevTexture t = loadTexture(sc.textures, (uint32_t)mt.z); mm.c = TexSpectrum<S>::eval(sc, t, checkerIndex(t, texU, texV), wlOffset); }
+    if (mt.x >= 0) { const DevTexture t = loadTexture(sc.textures, (uint32_t)mt.x); mm.a = 1.0f * TexSpectrum<S>::eval(sc, t, texU, texV, wlOffset); }
+    if (mt.y >= 0) { const DevTexture t = loadTexture(sc.textures, (uint32_t)mt.y); mm.b = TexSpectrum<S>::eval(sc, t, texU, texV, wlOffset); }
+    if (mt.z >= 0) { const DevTexture t = loadTexture(sc.textures, (uint32_t)mt.z); mm.c = TexSpectrum<S>::eval(sc, t, texU, texV, wlOffset); }
     return mt.w;
 }
 

@@ -23,7 +23,7 @@ __device__ __forceinline__ DevTexture loadTexture(const DevTexture* textures, ui
     t.kind = __float_as_uint(a.x); t.ox = a.y; t.oy = a.z; t.sx = a.w;
     t.sy = b.x; t.v0 = b.y; t.v1 = b.z; t.spec0 = (int32_t)__float_as_uint(b.w);
     t.spec1 = (int32_t)__float_as_uint(c.x); t.rgb0[0] = c.y; t.rgb0[1] = c.z; t.rgb0[2] = c.w;
-    t.rgb1[0] = d.x; t.rgb1[1] = d.y; t.rgb1[2] = d.z; t.pad = 0;
+    t.rgb1[0] = d.x; t.rgb1[1] = d.y; t.rgb1[2] = d.z; t.pad = __float_as_uint(d.w);
     return t;
 }
 
@@ -33,6 +33,20 @@ __device__ __forceinline__ int checkerIndex(const DevTexture& t, float texU, flo
     const float x = (texU + t.ox) * t.sx, y = (texV + t.oy) * t.sy;
     const int idx = ((int)(x * 2) + (int)(y * 2)) % 2;
     return idx < 0 ? -idx : idx;
+}
+
+// ImageSpectrumTexture::evaluate's texel address (Textures/image_textures.cpp:14-20) after OffsetAndScale2DMapping::map: nearest
+// texel, coordinates wrapped by fmod.  An image texture record carries width / height in spec0 / spec1 and its first texel in pad.
+__device__ __forceinline__ uint32_t imageTexel(const DevTexture& t, float texU, float texV) {
+    const float x = (texU + t.ox) * t.sx, y = (texV + t.oy) * t.sy;
+    float u = fmodf(x, 1.0f);
+    float v = fmodf(y, 1.0f);
+    u += u < 0 ? 1.0f : 0.0f;
+    v += v < 0 ? 1.0f : 0.0f;
+    const uint32_t w = (uint32_t)t.spec0, h = (uint32_t)t.spec1;
+    const uint32_t px = min((uint32_t)((float)w * u), w - 1u);
+    const uint32_t py = min((uint32_t)((float)h * v), h - 1u);
+    return t.pad + py * w + px;
 }
 
 // CheckerBoardNormal3DTexture::evaluate, checker_board_textures.cpp:16-43 (stepWidth = v0, reverse = v1 != 0); returns the

@@ -119,6 +119,7 @@ struct slrhip_ctx {
     DevArray<DevTexture> textures;
     DevArray<DevMatTex> matTex;
     DevArray<float4> triUV, alphaTris;
+    DevArray<float> texTexels;
     DevArray<LeafTri> leafTris;
     DevArray<ShadeTri> shadeTris;
     DevArray<LightTri> lightTris;
@@ -243,20 +244,22 @@ int slrhip_upload_scene(slrhip_ctx* ctx, const slrhip_scene_desc* d) {
     if (!ctx || !d) return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: null argument");
     if (!d->vertices || !d->triangles || !d->materials || !d->spectra || d->num_triangles == 0 || d->num_vertices == 0)
         return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: empty scene");
+    // the Meng-15 tables, wherever they are given: the kernels index with these bytes
+    if (ctx->config.mode == SLRHIP_MODE_SPECTRAL && d->upsampling) {
+        const slrhip_upsampling_tables* t = d->upsampling;
+        if (!t->cells || !t->point_uv || !t->point_spectrum || t->grid_width == 0 || t->grid_height == 0 || t->num_points == 0 || t->num_points > 255)
+            return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: incomplete slrhip_scene_desc::upsampling");
+        for (size_t c = 0; c < (size_t)t->grid_width * t->grid_height; ++c) {
+            const uint8_t* cell = t->cells + c * 8;
+            if (cell[1] > 6) return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: upsampling cell with more than 6 points");
+            for (int k = 0; k < (cell[0] ? 4 : cell[1]); ++k)
+                if (cell[2 + k] >= t->num_points) return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: upsampling point index out of range");
+        }
+    }
     if (d->env) {
         const slrhip_envmap& e = *d->env;
-        if (ctx->config.mode == SLRHIP_MODE_SPECTRAL) {
-            const slrhip_upsampling_tables* t = d->upsampling;
-            if (!t || !t->cells || !t->point_uv || !t->point_spectrum || t->grid_width == 0 || t->grid_height == 0 || t->num_points == 0 ||
-                t->num_points > 255)
-                return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: an environment map in spectral mode needs slrhip_scene_desc::upsampling");
-            for (size_t c = 0; c < (size_t)t->grid_width * t->grid_height; ++c) {          // the kernels index with these bytes
-                const uint8_t* cell = t->cells + c * 8;
-                if (cell[1] > 6) return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: upsampling cell with more than 6 points");
-                for (int k = 0; k < (cell[0] ? 4 : cell[1]); ++k)
-                    if (cell[2 + k] >= t->num_points) return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: upsampling point index out of range");
-            }
-        }
+        if (ctx->config.mode == SLRHIP_MODE_SPECTRAL && !d->upsampling)
+            return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: an environment map in spectral mode needs slrhip_scene_desc::upsampling");
         if (!e.texels || !e.importance || e.width == 0 || e.height == 0 || e.map_width == 0 || e.map_height == 0 ||
             e.width > 32768 || e.height > 32768 || e.map_width > 32768 || e.map_height > 32768)
             return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: bad environment map");
@@ -275,6 +278,7 @@ int slrhip_upload_scene(slrhip_ctx* ctx, const slrhip_scene_desc* d) {
     const uint32_t numTextures = d->textures ? d->num_textures : 0u;
     if (numTextures > 32767u) return fail(SLRHIP_ERR_UNSUPPORTED, "slrhip_upload_scene: more than 32767 textures");
     std::vector<DevTexture> devTextures(numTextures);
+    bool anyImageTexture = false;
     for (uint32_t i = 0; i < numTextures; ++i) {
         const slrhip_texture& t = d->textures[i];
         DevTexture dt;
@@ -294,6 +298,16 @@ int slrhip_upload_scene(slrhip_ctx* ctx, const slrhip_scene_desc* d) {
         else if (t.kind == SLRHIP_TEXTURE_CHECKER_NORMAL) {
             if (!(t.value[0] > 0.0f && t.value[0] <= 1.0f))        // SLRAssert of the reference's constructor
                 return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: checkerboard normal texture needs stepWidth in (0, 1]");
+        }
+        else if (t.kind == SLRHIP_TEXTURE_IMAGE_SPECTRUM) {
+            // ImageSpectrumTexture: width, height and the first texel travel in the record (DevTexture, device_types.h)
+            const uint64_t w = t.reserved[0], h = t.reserved[1], first = t.reserved[2];
+            if (w == 0 || h == 0 || w > 65535 || h > 65535 || !d->texture_texels || first + w * h > d->num_texture_texels)
+                return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: image texture outside slrhip_scene_desc::texture_texels");
+            if (spectral && !d->upsampling)
+                return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: image textures in spectral mode need slrhip_scene_desc::upsampling");
+            dt.spec0 = (int32_t)w; dt.spec1 = (int32_t)h; dt.pad = (uint32_t)first;
+            anyImageTexture = true;
         }
         else if (t.kind != SLRHIP_TEXTURE_CHECKER_FLOAT) return fail(SLRHIP_ERR_UNSUPPORTED, "slrhip_upload_scene: unknown texture kind");
         devTextures[i] = dt;
@@ -319,8 +333,8 @@ int slrhip_upload_scene(slrhip_ctx* ctx, const slrhip_scene_desc* d) {
         for (int k = 0; k < 3 && m.type != SLRHIP_MATERIAL_MULTI; ++k) {
             if (m.spectrum[k] >= -1) continue;
             const uint32_t t = (uint32_t)(-2 - m.spectrum[k]);
-            if (t >= numTextures || d->textures[t].kind != SLRHIP_TEXTURE_CHECKER_SPECTRUM)
-                return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: material spectrum slot names a texture that is not a CHECKER_SPECTRUM");
+            if (t >= numTextures || (d->textures[t].kind != SLRHIP_TEXTURE_CHECKER_SPECTRUM && d->textures[t].kind != SLRHIP_TEXTURE_IMAGE_SPECTRUM))
+                return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: material spectrum slot names a texture that is not a spectrum texture");
             mt.slot[k] = (int32_t)t;
         }
         matTex[i] = mt;
@@ -625,6 +639,11 @@ int slrhip_upload_scene(slrhip_ctx* ctx, const slrhip_scene_desc* d) {
     }
     if (!deviceBuild) HIP_TRY(ctx->leafTris.upload(bvh.leafTris));
     HIP_TRY(ctx->textures.upload(devTextures));
+    {
+        std::vector<float> texels;
+        if (anyImageTexture) texels.assign(d->texture_texels, d->texture_texels + (size_t)d->num_texture_texels * 3);
+        HIP_TRY(ctx->texTexels.upload(texels));
+    }
     HIP_TRY(ctx->matTex.upload(matTex));
     HIP_TRY(ctx->triUV.upload(triUV));
     HIP_TRY(ctx->alphaTris.upload(alphaTris));
@@ -674,7 +693,7 @@ int slrhip_upload_scene(slrhip_ctx* ctx, const slrhip_scene_desc* d) {
     sc.spectrumPool = ctx->spectrumPool.ptr;
     sc.lightPMF = ctx->lightPMF.ptr;
     sc.lightCDF = ctx->lightCDF.ptr;
-    sc.textures = ctx->textures.ptr; sc.matTex = ctx->matTex.ptr; sc.triUV = ctx->triUV.ptr; sc.alphaTris = ctx->alphaTris.ptr;
+    sc.textures = ctx->textures.ptr; sc.matTex = ctx->matTex.ptr; sc.triUV = ctx->triUV.ptr; sc.alphaTris = ctx->alphaTris.ptr; sc.texTexels = ctx->texTexels.ptr;
     sc.numTextures = numTextures;
     sc.numNodes = numNodes;
     sc.nodesQ = quant ? reinterpret_cast<const float4*>(ctx->nodesQ.ptr) : nullptr;
@@ -699,7 +718,7 @@ int slrhip_upload_scene(slrhip_ctx* ctx, const slrhip_scene_desc* d) {
         std::vector<uint8_t> cells;
         std::vector<float> puv, psp;
         sc.gridWidth = sc.gridHeight = 0;
-        if (d->env && spectral) {
+        if ((d->env || anyImageTexture) && spectral) {
             const slrhip_upsampling_tables* t = d->upsampling;
             cells.assign(t->cells, t->cells + (size_t)t->grid_width * t->grid_height * 8);
             puv.assign(t->point_uv, t->point_uv + (size_t)t->num_points * 2);

@@ -57,6 +57,7 @@ class SceneBuilder:
         self.num_vertices = 0
         self.sset = spectra.SpectrumSet()     # every constant carries its RGB value and its spectral descriptor
         self.textures = []
+        self.texture_texels, self.texture_texels_uvs = [], []
 
     # --- spectra (the scene language's Spectrum(...) overloads, libSLRSceneGraph/API.cpp:286-441) -------
     def spectrum_rgb(self, r, g, b, uvs=None):
@@ -101,6 +102,20 @@ class SceneBuilder:
     def checker_normal(self, step_width, reverse=False, offset=(0.0, 0.0), scale=(1.0, 1.0)):
         """CheckerBoardNormal3DTexture (texture index: use as normal_map=)."""
         return self._texture(abi.TEX_CHECKER_NORMAL, offset, scale, value=(step_width, 1.0 if reverse else 0.0))
+
+    def image_spectrum(self, texels_rgb, texels_uvs, offset=(0.0, 0.0), scale=(1.0, 1.0)):
+        """ImageSpectrumTexture (Textures/image_textures.cpp:13-79) over an OffsetAndScale2DMapping: nearest texel, wrap by fmod.
+        texels_rgb [h][w][3]: what the RGB build's look-up returns (8-bit images: byte / 255); texels_uvs [h][w][3]: the (u, v, s)
+        the spectral build stores for the same image (halves).  Returns the VALUE to put in a material's spectrum slot."""
+        rgb = np.asarray(texels_rgb, dtype=np.float32)
+        uvs = np.asarray(texels_uvs, dtype=np.float32)
+        assert rgb.shape == uvs.shape and rgb.ndim == 3 and rgb.shape[2] == 3
+        first = sum(len(t) for t in self.texture_texels)
+        self.texture_texels.append(rgb.reshape(-1, 3))
+        self.texture_texels_uvs.append(uvs.reshape(-1, 3))
+        t = self._texture(abi.TEX_IMAGE_SPECTRUM, offset, scale)
+        self.textures[t]["reserved"] = (rgb.shape[1], rgb.shape[0], first)
+        return abi.texture_ref(t)
 
     # --- materials -----------------------------------------------------------------
     def material(self, mtype, spectra=(-1, -1, -1), param=-1.0, emittance=-1, param2=0.0, normal_map=None, alpha_map=None):
@@ -218,7 +233,9 @@ class SceneBuilder:
                          np.array(self.materials, dtype=abi.material_dtype),
                          np.array(self.sset.records, dtype=abi.spectrum_dtype),
                          np.array(self.sset.data, dtype=np.float32), camera, env, name,
-                         textures=np.array(self.textures, dtype=abi.texture_dtype) if self.textures else None)
+                         textures=np.array(self.textures, dtype=abi.texture_dtype) if self.textures else None,
+                         texture_texels=np.concatenate(self.texture_texels) if self.texture_texels else None,
+                         texture_texels_uvs=np.concatenate(self.texture_texels_uvs) if self.texture_texels_uvs else None)
 
 
 # RGB-mode constants of the scene's named spectra.  In the reference these come from
@@ -296,6 +313,48 @@ def cornell_textured(aspect=1.0, segments=16, rings=8):
     lattice = b.with_maps(b.matte(b.spectrum_srgb_nonlinear(0.3, 0.5, 0.8)), alpha_map=b.checker_float(1.0, 0.0, (0.0, 0.0), (3.0, 3.0)))
     b.add_quad([(-1.0, 0.2, -1.9), (1.0, 0.2, -1.9), (1.0, 1.8, -1.9), (-1.0, 1.8, -1.9)], (0, 0, 1), (1, 0, 0), lattice)
     return b.build(cornell_camera(aspect), name="cornell_textured")
+
+
+def synthetic_image(width, height, seed):
+    """A deterministic test image in both stored forms: (texels_rgb, texels_uvs).  RGB: 8-bit values / 255, what the RGB build's
+    ImageSpectrumTexture::evaluate returns for an RGB8x3 image (image_textures.cpp:36-42).  uvs: UpsampledContinuousSpectrum's
+    (u, v, s) of the same colour taken as a linear-sRGB reflectance, rounded to binary16 as the spectral build's image stores it
+    (Core/Image.h:39-40) — the reference converts at image load, outside the boundary; here both forms are scene inputs."""
+    r = np.random.default_rng(seed)
+    bytes_ = r.integers(0, 256, size=(height, width, 3))
+    yy, xx = np.mgrid[0:height, 0:width]
+    bytes_ = (bytes_ // 2 + 64 * (((xx // 2) + (yy // 2)) % 2)[..., None]).clip(0, 255)      # coarse checks under the noise, so that the mapping shows
+    rgb = (bytes_.astype(np.float32) / np.float32(255.0)).astype(np.float32)
+    uvs = np.zeros_like(rgb)
+    for y in range(height):
+        for x in range(width):
+            u, v, scale = spectra.upsample(spectra.REFLECTANCE, spectra.SRGB, *[float(c) for c in rgb[y, x]])
+            uvs[y, x] = (u, v, np.float32(scale) * spectra.EQUAL_ENERGY_REFLECTANCE)      # the image stores s = X + Y + Z; evaluate divides it back
+    return rgb, _f16(uvs)
+
+
+def cornell_image_textured(aspect=1.0, segments=12, rings=6):
+    """SURVEY 8 row f3, image textures in material slots (ImageSpectrumTexture, Textures/image_textures.cpp:13-79): the Cornell walls
+    with an IMAGE on the floor (16 x 12 texels through an offset-and-scale mapping that repeats it, so the fmod wrap is on the
+    path), a matte sphere wrapped in a second image and a mirror sphere whose coefficient is an image."""
+    b = SceneBuilder()
+    red = b.matte(b.spectrum_srgb_nonlinear(0.75, 0.25, 0.25))
+    blue = b.matte(b.spectrum_srgb_nonlinear(0.25, 0.25, 0.75))
+    white = b.matte(b.spectrum_srgb_nonlinear(0.75, 0.75, 0.75))
+    floor = b.matte(b.image_spectrum(*synthetic_image(16, 12, 5), offset=(0.125, -0.25), scale=(2.0, 3.0)))
+    b.add_quad([(-1.5, 0, 2.55), (-1.5, 0, -2.55), (-1.5, 2.5, -2.55), (-1.5, 2.5, 2.55)], (1, 0, 0), (0, 0, -1), red)
+    b.add_quad([(1.5, 0, -2.55), (1.5, 0, 2.55), (1.5, 2.5, 2.55), (1.5, 2.5, -2.55)], (-1, 0, 0), (0, 0, 1), blue)
+    b.add_quad([(-1.5, 0, 2.55), (1.5, 0, 2.55), (1.5, 0, -2.55), (-1.5, 0, -2.55)], (0, 1, 0), (1, 0, 0), floor)
+    b.add_quad([(-1.5, 0, -2.55), (1.5, 0, -2.55), (1.5, 2.5, -2.55), (-1.5, 2.5, -2.55)], (0, 0, 1), (1, 0, 0), white)
+    b.add_quad([(-1.5, 2.5, -2.55), (1.5, 2.5, -2.55), (1.5, 2.5, 2.55), (-1.5, 2.5, 2.55)], (0, -1, 0), (1, 0, 0), white)
+    light = b.matte(b.spectrum_srgb_nonlinear(0.9, 0.9, 0.9), emittance=b.spectrum_d65(4.0, D65_RGB))
+    b.add_quad([(-0.5, 2.499, -0.5), (0.5, 2.499, -0.5), (0.5, 2.499, 0.5), (-0.5, 2.499, 0.5)], (0, -1, 0), (1, 0, 0), light)
+    wrapped = b.matte(b.image_spectrum(*synthetic_image(8, 8, 6)), sigma=0.3)
+    b.add_uv_sphere(segments, rings, wrapped, _translate(0.7, 0, 0) @ _scale(0.5) @ _translate(0, 1, 0))
+    mirror = b.metal(b.image_spectrum(*synthetic_image(6, 4, 7), scale=(3.0, 2.0)), b.spectrum_ior("Aluminium", 0, ALUMINIUM_ETA_RGB),
+                     b.spectrum_ior("Aluminium", 1, ALUMINIUM_K_RGB))
+    b.add_uv_sphere(segments, rings, mirror, _translate(-0.7, 0, -1.05) @ _scale(0.5) @ _translate(0, 1, 0))
+    return b.build(cornell_camera(aspect), name="cornell_image_textured")
 
 
 def tiny_box(aspect=1.0):

@@ -31,6 +31,8 @@ def scene_arrays(sc):
             env.update(env_texels_uvs=sc.env_texels_uvs.astype(np.float16), env_importance_uvs=sc.env_importance_uvs)
     if len(sc.textures):
         env["textures"] = sc.textures
+    if len(sc.texture_texels):
+        env["texture_texels"], env["texture_texels_uvs"] = sc.texture_texels, sc.texture_texels_uvs
     return dict(env, vertices=sc.vertices, triangles=sc.triangles, materials=sc.materials, spectra=sc.spectra,
                 spectrum_data=sc.spectrum_data,
                 camera=np.array(list(cam.local_to_world) + list(cam.world_to_local) +
@@ -290,6 +292,12 @@ def main_round3(only):
         make("rgb_multi_nested", scenes.cornell_multi_nested(1.0, 12, 6), lib, 40, 40, 8, 2)
     if not only or "spectral_multi_nested" in only:
         make("spectral_multi_nested", scenes.cornell_multi_nested(1.0, 10, 5), spec, 32, 32, 8, 2)
+    # image textures in material slots: the texel addressing is the shim's restatement (ImageSpectrumTexture needs OpenEXR half),
+    # everything after the texel is the compiled reference's
+    if not only or "rgb_image_textured" in only:
+        make("rgb_image_textured", scenes.cornell_image_textured(1.0, 12, 6), lib, 48, 48, 8, 2)
+    if not only or "spectral_image_textured" in only:
+        make("spectral_image_textured", scenes.cornell_image_textured(1.0, 10, 5), spec, 40, 40, 8, 2)
 
 
 if __name__ == "__main__":

@@ -36,7 +36,10 @@ def scene_from_golden(g, name="golden", prefix=""):
         if "env_texels_uvs" in g.files:
             env = env + (g["env_texels_uvs"].astype(np.float32), g["env_importance_uvs"])
     textures = g["textures"] if "textures" in g.files else None
-    return abi.Scene(g["vertices"], g["triangles"], g["materials"], g["spectra"], g["spectrum_data"], cam, env, name, textures=textures)
+    texels = g["texture_texels"] if "texture_texels" in g.files else None
+    texels_uvs = g["texture_texels_uvs"] if "texture_texels_uvs" in g.files else None
+    return abi.Scene(g["vertices"], g["triangles"], g["materials"], g["spectra"], g["spectrum_data"], cam, env, name, textures=textures,
+                     texture_texels=texels, texture_texels_uvs=texels_uvs)
 
 
 def bits(a):

@@ -477,6 +477,35 @@ def test_textured_scene_matches_reference_golden(name):
     assert int(k.extension_rays) == int(ctr.extension_rays) and int(k.shadow_rays) == int(ctr.shadow_rays)
 
 
+@pytest.mark.parametrize("name", ["rgb_image_textured", "spectral_image_textured"])
+def test_image_textured_scene_matches_reference_golden(name):
+    """SURVEY 8 row f3, image textures in material slots: nearest texel of an image behind an offset-and-scale mapping
+    (ImageSpectrumTexture, Textures/image_textures.cpp:13-79), RGB texels in the RGB build, (u, v, s) through the run-time Meng-15
+    look-up in the spectral build.  No float libm beyond fmod on the path: the frame is expected bit-exact against the golden
+    (compiled reference; its texel addressing is the shim's restatement — OpenEXR half is absent — so that step is unpinned) and,
+    on a larger frame with the automatic stripe count, equal to the oracle's up to the stripes' summation order."""
+    g = load_golden(name)
+    mode = abi.MODE_SPECTRAL if name.startswith("spectral") else abi.MODE_RGB
+    st = ob.settings(int(g["width"]), int(g["height"]), int(g["seed"]))
+    c = Context(mode=mode, stripes=1)
+    try:
+        fb = c.render_image(scene_from_golden(g), st, int(g["spp"]))
+        assert_bit_equal(fb, g["framebuffer"], name + " frame")
+    finally:
+        c.close()
+    sc2 = scenes.cornell_image_textured(4.0 / 3.0, 16, 8)
+    st2 = ob.settings(160, 120, seed=8)
+    want, ctr = ob.load("oracle", mode).scene(sc2).render(st2, 8)
+    c = Context(mode=mode)
+    try:
+        fb = c.render_image(sc2, st2, 8)
+        k = c.counters()
+    finally:
+        c.close()
+    assert np.allclose(fb, want, rtol=2e-6, atol=1e-9)
+    assert int(k.extension_rays) == int(ctr.extension_rays) and int(k.shadow_rays) == int(ctr.shadow_rays)
+
+
 def test_errors_are_loud(ctx):
     import ctypes as C
     from slr_amd.binding import SlrHipError
