@@ -171,25 +171,25 @@ struct GGX {
     float alpha_g;
     SLR_DEV float evaluate(V3 m) const {                                         // :176-183
         if (m.z <= 0) return 0.0f;
-        float theta_m = acosf(m.z);
+        float theta_m = slrAcos(m.z);
         float cosTheta_m = m.z;
-        float tanTheta_m = tanf(theta_m);
+        float tanTheta_m = slrTan(theta_m);
         double c2 = (double)cosTheta_m * (double)cosTheta_m;
         double s = (double)(alpha_g * alpha_g + tanTheta_m * tanTheta_m);
         return (float)((double)(alpha_g * alpha_g) / (kPi * (c2 * c2) * (s * s)));      // std::pow(x, 4), std::pow(x, 2) in double
     }
     SLR_DEV float evaluateSmithG1(V3 v, V3 m) const {                            // :264-268
         float chi = (dot(v, m) / v.z) > 0 ? 1 : 0;
-        float theta_v = acosf(fminf(1.0f, fmaxf(-1.0f, v.z)));
-        double t = (double)(alpha_g * tanf(theta_v));
+        float theta_v = slrAcos(fminf(1.0f, fmaxf(-1.0f, v.z)));
+        double t = (double)(alpha_g * slrTan(theta_v));
         return (float)((double)(chi * 2) / (1 + sqrt(1 + t * t)));
     }
     SLR_DEV float evaluatePDF(V3 v, V3 m) const { return evaluateSmithG1(v, m) * absDot(v, m) * evaluate(m) / fabsf(v.z); }   // :260-262
     SLR_DEV float sample(V3 v, float u0, float u1, V3* m, float* normalPDF) const {     // :191-258
         float alpha_gx = alpha_g, alpha_gy = alpha_g;
         V3 sv = normalize(V3(alpha_gx * v.x, alpha_gy * v.y, v.z));
-        float theta_sv = acosf(sv.z);
-        float phi_sv = atan2f(sv.y, sv.x);
+        float theta_sv = slrAcos(sv.z);
+        float phi_sv = slrAtan2(sv.y, sv.x);
         if (sv.z > 0.99999f) { theta_sv = 0.0f; phi_sv = 0.0f; }
         float slope_x, slope_y;
         if ((double)theta_sv < 0.0001) {
@@ -217,8 +217,8 @@ struct GGX {
             const float z = (float)((w * (w * (w * 0.27385 - 0.73369) + 0.46341)) / (w * (w * (w * 0.093073 + 0.309420) - 1.000000) + 0.597999));
             slope_y = (float)((double)(S * z) * sqrt(1.0 + (double)(slope_x * slope_x)));
         }
-        float tmp = cosf(phi_sv) * slope_x - sinf(phi_sv) * slope_y;
-        slope_y = sinf(phi_sv) * slope_x + cosf(phi_sv) * slope_y;
+        float tmp = slrCos(phi_sv) * slope_x - slrSin(phi_sv) * slope_y;
+        slope_y = slrSin(phi_sv) * slope_x + slrCos(phi_sv) * slope_y;
         slope_x = tmp;
         slope_x *= alpha_gx;
         slope_y *= alpha_gy;
@@ -264,7 +264,7 @@ SLR_DEV float wardNumerator(const Mat<S>& m, V3 halfv, V3 dirL, float* dotHI, fl
     float hy_ay = halfv.y / m.onA;
     *dotHN = fabsf(halfv.z);
     *dotHI = dot(halfv, dirL);
-    return expf(-(hx_ax * hx_ax + hy_ay * hy_ay) / (*dotHN * *dotHN));
+    return slrExp(-(hx_ax * hx_ax + hy_ay * hy_ay) / (*dotHN * *dotHN));
 }
 template <class S>
 SLR_DEV void ashikhminWeights(const Mat<S>& m, uint32_t wl, float absCos, float* specularWeight, float* diffuseWeight) {
@@ -277,7 +277,7 @@ SLR_DEV void ashikhminWeights(const Mat<S>& m, uint32_t wl, float absCos, float*
 template <class S>
 SLR_DEV float ashikhminCommon(const Mat<S>& m, V3 halfv, float dotHV) {
     float e = (m.param * halfv.x * halfv.x + m.onA * halfv.y * halfv.y) / (1 - halfv.z * halfv.z);
-    return (float)((double)sqrtf((m.param + 1) * (m.onA + 1)) / (8 * kPi * (double)dotHV) * (double)powf(fabsf(halfv.z), e));
+    return (float)((double)sqrtf((m.param + 1) * (m.onA + 1)) / (8 * kPi * (double)dotHV) * (double)slrPow(fabsf(halfv.z), e));
 }
 template <class S>
 SLR_DEV S ashikhminFs(const Mat<S>& m, float commonTerm, float dotHV, float zQuery, float zDir) {
@@ -329,11 +329,11 @@ SLR_DEV S bsdfSampleInternal(const Mat<S>& m, uint32_t type, V3 dirOut, V3 gNorm
         if (!MF) return S();
         // ModifiedWardDurBRDF::sampleInternal :11-40
         float quad = (float)(2 * kPi * (double)u1);
-        float phi_h = atan2f(m.onA * sinf(quad), m.param * cosf(quad));
-        float cosphi_ax = cosf(phi_h) / m.param;
-        float sinphi_ay = sinf(phi_h) / m.onA;
-        float theta_h = atanf(sqrtf(-logf(1 - u0) / (cosphi_ax * cosphi_ax + sinphi_ay * sinphi_ay)));
-        V3 halfv(sinf(theta_h) * cosf(phi_h), sinf(theta_h) * sinf(phi_h), cosf(theta_h));
+        float phi_h = slrAtan2(m.onA * slrSin(quad), m.param * slrCos(quad));
+        float cosphi_ax = slrCos(phi_h) / m.param;
+        float sinphi_ay = slrSin(phi_h) / m.onA;
+        float theta_h = slrAtan(sqrtf(-slrLog(1 - u0) / (cosphi_ax * cosphi_ax + sinphi_ay * sinphi_ay)));
+        V3 halfv(slrSin(theta_h) * slrCos(phi_h), slrSin(theta_h) * slrSin(phi_h), slrCos(theta_h));
         halfv.z *= dirOut.z > 0 ? 1 : -1;
         res->dir_sn = (2 * dot(dirOut, halfv)) * halfv - dirOut;
         if (res->dir_sn.z * dirOut.z <= 0) { res->dirPDF = 0.0f; return S(); }
@@ -355,12 +355,12 @@ SLR_DEV S bsdfSampleInternal(const Mat<S>& m, uint32_t type, V3 dirOut, V3 gNorm
         if (uComp * sumWeights < specularWeight) {
             res->dirType = DT_Reflection | DT_HighFreq;
             float quad = (float)(2 * kPi * (double)u1);
-            float phi_h = atan2f(sqrtf(m.param + 1) * sinf(quad), sqrtf(m.onA + 1) * cosf(quad));
-            float cosphi = cosf(phi_h);
-            float sinphi = sinf(phi_h);
-            float theta_h = acosf(powf(1 - u0, 1.0f / (m.param * cosphi * cosphi + m.onA * sinphi * sinphi + 1)));
+            float phi_h = slrAtan2(sqrtf(m.param + 1) * slrSin(quad), sqrtf(m.onA + 1) * slrCos(quad));
+            float cosphi = slrCos(phi_h);
+            float sinphi = slrSin(phi_h);
+            float theta_h = slrAcos(slrPow(1 - u0, 1.0f / (m.param * cosphi * cosphi + m.onA * sinphi * sinphi + 1)));
             if (dirOut.z < 0) theta_h = (float)(kPi - (double)theta_h);
-            V3 halfv(sinf(theta_h) * cosf(phi_h), sinf(theta_h) * sinf(phi_h), cosf(theta_h));
+            V3 halfv(slrSin(theta_h) * slrCos(phi_h), slrSin(theta_h) * slrSin(phi_h), slrCos(theta_h));
             res->dir_sn = (2 * dot(dirOut, halfv)) * halfv - dirOut;
             if (res->dir_sn.z * dirOut.z <= 0) { res->dirPDF = 0.0f; return S(); }
             float dotHV = dot(halfv, dirOut);

@@ -144,6 +144,26 @@ SLR_DEV Spec16 operator/(const Spec16& a, float s) { float r = 1 / s; return Spe
 SLR_DEV Spec16 operator+(const Spec16& a, float s) { return a + Spec16(s); }
 SLR_DEV Spec16 operator-(const Spec16& a, float s) { return a - Spec16(s); }
 
+// ---- float libm on the device ------------------------------------------------------------------------------------------------
+// The reference calls glibc's float functions; the device library's answers differ from glibc's in the last bit on a share of
+// the arguments.  SLR_LIBM_DOUBLE (a bit mask, variant builds and the default below) evaluates a function through the device's
+// DOUBLE routine and rounds once — the correctly rounded float, which is what glibc returns except where glibc itself is off
+// by one (measured on 2 x 10^7 arguments per function against glibc 2.35, the image's: expf 0.06 %, powf 0.12 %, logf 0.3 %,
+// sinf / cosf 1.3 %, tanf 3.7 %, atanf 4.3 %, acosf 7.8 %, atan2f 16 % — profiles/r03_h_libm_via_double.txt has the GPU side).
+//   1 sin / cos   2 tan   4 acos   8 atan / atan2   16 exp / log   32 pow
+#ifndef SLR_LIBM_DOUBLE
+#define SLR_LIBM_DOUBLE 0
+#endif
+SLR_DEV float slrSin(float x) { return (SLR_LIBM_DOUBLE & 1) ? (float)sin((double)x) : sinf(x); }
+SLR_DEV float slrCos(float x) { return (SLR_LIBM_DOUBLE & 1) ? (float)cos((double)x) : cosf(x); }
+SLR_DEV float slrTan(float x) { return (SLR_LIBM_DOUBLE & 2) ? (float)tan((double)x) : tanf(x); }
+SLR_DEV float slrAcos(float x) { return (SLR_LIBM_DOUBLE & 4) ? (float)acos((double)x) : acosf(x); }
+SLR_DEV float slrAtan(float x) { return (SLR_LIBM_DOUBLE & 8) ? (float)atan((double)x) : atanf(x); }
+SLR_DEV float slrAtan2(float y, float x) { return (SLR_LIBM_DOUBLE & 8) ? (float)atan2((double)y, (double)x) : atan2f(y, x); }
+SLR_DEV float slrExp(float x) { return (SLR_LIBM_DOUBLE & 16) ? (float)exp((double)x) : expf(x); }
+SLR_DEV float slrLog(float x) { return (SLR_LIBM_DOUBLE & 16) ? (float)log((double)x) : logf(x); }
+SLR_DEV float slrPow(float x, float y) { return (SLR_LIBM_DOUBLE & 32) ? (float)pow((double)x, (double)y) : powf(x, y); }
+
 // importance(): RGBTypes.h:103-108 / SpectrumTypes.h:512-526 (marginal = (1 - primary) / (N - 1); N = 3 gives / 2)
 template <class S>
 SLR_DEV float importance(const S& s, uint32_t selectedLambda) {

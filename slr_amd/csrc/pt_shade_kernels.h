@@ -282,7 +282,7 @@ __device__ __forceinline__ float envAreaPDF(const DevScene& sc, float phi, float
     uint32_t iTop = min((uint32_t)(int32_t)(d1 * (float)sc.envMapHeight), sc.envMapHeight - 1);
     uint32_t iRow = min((uint32_t)(int32_t)(d0 * (float)sc.envMapWidth), sc.envMapWidth - 1);
     float uvPDF = sc.envTopPDF[iTop] * sc.envRowPDF[(size_t)idx1D * sc.envMapWidth + iRow];
-    return (float)((double)uvPDF / (2 * kPi * kPi * (double)sinf(theta)));
+    return (float)((double)uvPDF / (2 * kPi * kPi * (double)slrSin(theta)));
 }
 
 // SampledSpectrumSum sp of Job::contribution (PathTracingRenderer.cpp:141): see the note at its use in k_logic.
@@ -509,8 +509,8 @@ __device__ __forceinline__ void logicSlot(const DevScene& sc, const PathBuffers&
             if (state != ST_FINISH && sc.hasEnv) {
                 // the ray left the scene: Scene::intersect falls through to the environment sphere (SurfaceObject.cpp:411-414).
                 // InfiniteSphere::intersect / getSurfacePoint (Surface/InfiniteSphere.cpp:34-59), Vector3::toPolarYUp (Vector3.h:72-75)
-                float theta = acosf(fminf(1.0f, fmaxf(-1.0f, rayDir.y)));
-                float phi = fmodf((float)((double)atan2f(-rayDir.x, rayDir.z) + 2 * kPi), (float)(2 * kPi));
+                float theta = slrAcos(fminf(1.0f, fmaxf(-1.0f, rayDir.y)));
+                float phi = fmodf((float)((double)slrAtan2(-rayDir.x, rayDir.z) + 2 * kPi), (float)(2 * kPi));
                 float texU = (float)((double)phi / (2 * kPi)), texV = (float)((double)theta / kPi);
                 // emittance x IBLEDF::evaluate = 1 / pi (EDFs/IBLEDF.cpp:19-23)
                 S Le = envEmittanceS<S>(sc, texU, texV, wlOffset) * S((float)(1.0 / kPi));
@@ -650,12 +650,12 @@ __device__ __forceinline__ void logicSlot(const DevScene& sc, const PathBuffers&
                         float uvPDF = rowPDF * topPDF;
                         float phi = (float)((double)d0 * (2 * kPi));
                         float theta = (float)((double)d1 * kPi);
-                        lp = V3(-sinf(phi) * sinf(theta), cosf(theta), cosf(phi) * sinf(theta));
+                        lp = V3(-slrSin(phi) * slrSin(theta), slrCos(theta), slrCos(phi) * slrSin(theta));
                         lgn = -lp;
-                        lf.x = normalize(V3(-cosf(phi), 0.0f, -sinf(phi)));
+                        lf.x = normalize(V3(-slrCos(phi), 0.0f, -slrSin(phi)));
                         lf.z = lgn;
                         lf.y = cross(lf.z, lf.x);
-                        areaPDF = (float)((double)uvPDF / (2 * kPi * kPi * (double)sinf(theta)));
+                        areaPDF = (float)((double)uvPDF / (2 * kPi * kPi * (double)slrSin(theta)));
                         M = envEmittanceS<S>(sc, (float)((double)phi / (2 * kPi)), (float)((double)theta / kPi), wlOffset);
                         sdir = normalize(lp);                              // Scene::testVisibility :421-423: [eps, FLT_MAX]
                         shadowTmax = 3.402823466e+38f;

@@ -78,3 +78,10 @@ def test_cpp_host_reduces_tile_shards_over_rccl():
     out = subprocess.run([exe, "5", "200", "136", "8", os.path.join(ROOT, "slr_amd", "data", "upsampling_tables.bin")], text=True, capture_output=True, env=env, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "0 differ" in out.stdout
+    # the N-process flow (children forked before any GPU call, ncclUniqueId over a pipe, one device per rank) with the one rank this
+    # box has a device for; the same code path an 8-GPU node runs with --ranks 8
+    import torch
+    ranks = min(torch.cuda.device_count(), 2)
+    out = subprocess.run([exe, "--ranks", str(ranks), "200", "136", "8", os.path.join(ROOT, "slr_amd", "data", "upsampling_tables.bin")], text=True, capture_output=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "%d ranks (communicator size %d)" % (ranks, ranks) in out.stdout and " 0 differ" in out.stdout
