@@ -102,8 +102,8 @@ struct Builder {
         stack.push_back(first);
         const int kBins = 16;
         // development knobs (tree-quality experiments): largest leaf and the leaf-versus-split bias
-        static const uint32_t maxLeaf = [] { const char* e = getenv("SLRHIP_BVH_MAXLEAF"); int v = e ? atoi(e) : (int)kMaxLeafTris; return (uint32_t)std::min((int)kMaxLeafTris, std::max(1, v)); }();
-        static const float leafBias = [] { const char* e = getenv("SLRHIP_BVH_LEAFBIAS"); return e ? (float)atof(e) : 0.125f; }();
+        static const uint32_t maxLeaf = [] { const char* e = tuningEnv("SLRHIP_BVH_MAXLEAF"); int v = e ? atoi(e) : (int)kMaxLeafTris; return (uint32_t)std::min((int)kMaxLeafTris, std::max(1, v)); }();
+        static const float leafBias = [] { const char* e = tuningEnv("SLRHIP_BVH_LEAFBIAS"); return e ? (float)atof(e) : 0.125f; }();
         while (!stack.empty()) {
             Job j = stack.back();
             stack.pop_back();
@@ -260,7 +260,7 @@ int buildQBVH(const slrhip_vertex* verts, const slrhip_triangle* tris, uint32_t 
     const bool useSbvh = spatialSplits || envSbvh;
     auto tB = tA;
     if (useSbvh) {
-        const char* e = getenv("SLRHIP_SBVH_BUDGET");
+        const char* e = tuningEnv("SLRHIP_SBVH_BUDGET");
         SbvhStats st;
         buildBinarySBVH(verts, tris, numTris, e ? (float)atof(e) : 1.3f, &b.nodes, &b.prims, &st);
         out->spatialSplits = st.spatialSplits;

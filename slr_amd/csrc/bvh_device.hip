@@ -402,7 +402,7 @@ int buildGeometryDevice(const slrhip_vertex* hVerts, uint32_t numVerts, const sl
     bt.left = left.p; bt.right = right.p; bt.first = first.p; bt.count = count.p; bt.box = boxes.p; bt.ready = ready.p;
     // Leaf packets: runs of up to maxLeaf triangles that are neighbours in Morton order.  Measured on the 10 M-triangle grid
     // (SLRHIP_LBVH_LEAF, profiles/r03_f_*): DESIGN.md has nodes / triangles per ray and the traversal time for each size.
-    static const uint32_t envLeaf = [] { const char* e = getenv("SLRHIP_LBVH_LEAF"); const int v = e ? atoi(e) : 0; return (uint32_t)(v >= 1 && v <= (int)kMaxLeafTris ? v : 0); }();
+    static const uint32_t envLeaf = [] { const char* e = tuningEnv("SLRHIP_LBVH_LEAF"); const int v = e ? atoi(e) : 0; return (uint32_t)(v >= 1 && v <= (int)kMaxLeafTris ? v : 0); }();
     bt.maxLeaf = envLeaf ? envLeaf : 2u;      // 10 M-triangle grid, traversal us per launch at 1 / 2 / 4: 3 590 / 3 498 / 3 866 (host SAH tree: 3 338)
     hipLaunchKernelGGL(k_hierarchy, dim3(G), dim3(B), 0, nullptr, keysSorted.p, n, bt);
     hipLaunchKernelGGL(k_refit_leaves, dim3(G), dim3(B), 0, nullptr, primBoxes.p, valsSorted.p, n, bt);

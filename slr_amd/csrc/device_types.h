@@ -13,8 +13,21 @@
 //             inline, so shading a hit is six 16-byte loads and no vertex indirection.
 #pragma once
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace slrhip {
+
+// Measurement knobs (SLRHIP_WS_NC, SLRHIP_QUANT, SLRHIP_PAIRS, ...: the values the defaults were chosen against) are read
+// only by libraries built with -DSLR_TUNING_KNOBS (tools/build_variant.sh).  The shipped library reads five environment variables:
+// SLRHIP_BVH (host | device | sbvh), SLRHIP_BVH_TIMING, SLRHIP_TAIL_SLOTS, SLRHIP_GRAPH, SLRHIP_ITER_LOG.
+inline const char* tuningEnv(const char* name) {
+#ifdef SLR_TUNING_KNOBS
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
 
 static const uint32_t kInvalidChild = 0xFFFFFFFFu;
 static const uint32_t kLeafFlag = 0x80000000u;

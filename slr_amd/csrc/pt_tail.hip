@@ -1,5 +1,5 @@
 // pt_tail.hip — launcher of the tail kernel (pt_tail_kernels.h): picks the instantiation that matches the k_shade variant of the
-// scene (launchShade, pt_shade.hip); the instantiations are in pt_tail_{rgb,spec16}.hip and pt_tail_{multi,tex}_rgb.hip.
+// scene (launchShade, pt_shade.hip); the instantiations are in pt_tail_{rgb,spec16}.hip and pt_tail_{multi,tex}_{rgb,spec}.hip.
 #include <algorithm>
 
 #include "pt_tail_kernels.h"
@@ -33,8 +33,10 @@ void launchTailRGB(const DevScene& sc, const PathBuffers& pb, const RenderParams
 void launchTailSpec16(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, bool lds, bool glossy, uint32_t blocks, hipStream_t stream);
 void launchTailMultiRGB(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t blocks, hipStream_t stream);
 void launchTailTexRGB(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t blocks, hipStream_t stream);
+void launchTailMultiSpec(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t blocks, hipStream_t stream);
+void launchTailTexSpec(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t blocks, hipStream_t stream);
 
-bool tailKernelAvailable(const DevScene& sc, bool spectral) { return !(spectral && (sc.hasMulti || sc.numTextures)); }
+bool tailKernelAvailable(const DevScene&, bool) { return true; }      // every shade-kernel variant has its tail kernel
 
 void launchTail(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t liveSlots, int numCUs, hipStream_t stream) {
     if (rp.numSlots == 0 || liveSlots == 0) return;
@@ -44,10 +46,8 @@ void launchTail(const DevScene& sc, const PathBuffers& pb, const RenderParams& r
     const bool ldsTables = sc.numMaterials <= (uint32_t)kLdsMaterials && sc.numLights <= (uint32_t)kLdsLights &&
                            (!rp.spectral || (sc.numSpectra <= (uint32_t)kLdsSpectra && sc.numSpectrumData <= (uint32_t)kLdsPoolFloats));
     const bool glossy = sc.hasMicrofacet != 0;
-    // (spectral scenes with MultiBSDF materials or textures never enter tail mode — tailKernelAvailable: that instantiation alone
-    // takes nine minutes to compile for a 1 % gain on scenes no BASELINE config has)
-    if (sc.numTextures) launchTailTexRGB(sc, pb, rp, blocks, stream);
-    else if (sc.hasMulti) launchTailMultiRGB(sc, pb, rp, blocks, stream);
+    if (sc.numTextures) { if (rp.spectral) launchTailTexSpec(sc, pb, rp, blocks, stream); else launchTailTexRGB(sc, pb, rp, blocks, stream); }
+    else if (sc.hasMulti) { if (rp.spectral) launchTailMultiSpec(sc, pb, rp, blocks, stream); else launchTailMultiRGB(sc, pb, rp, blocks, stream); }
     else if (rp.spectral) launchTailSpec16(sc, pb, rp, ldsTables, glossy, blocks, stream);
     else launchTailRGB(sc, pb, rp, ldsTables, glossy, blocks, stream);
 }

@@ -1,0 +1,10 @@
+// pt_tail_tex_spec.hip — one k_tail instantiation (see pt_tail_kernels.h); one per file: each takes minutes to compile
+#include "pt_tail_kernels.h"
+
+namespace slrhip {
+
+void launchTailTexSpec(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t blocks, hipStream_t stream) {
+    hipLaunchKernelGGL((k_tail<Spec16, false, true, true, true>), dim3(blocks), dim3(kShadeBlock), 0, stream, sc, pb, rp);
+}
+
+} // namespace slrhip

@@ -78,14 +78,14 @@ struct WsLds {
 
 int traceWsBlocksPerCU(bool quantized) {
     static const bool init = [] {
-        if (const char* e = getenv("SLRHIP_WS_REFILL")) g_refill = (uint32_t)atoi(e);
-        if (const char* e = getenv("SLRHIP_WS_NC")) { const int n = atoi(e); g_consumers = n == 3 ? 3 : n == 15 ? 15 : n == 7 ? 7 : 0; }
+        if (const char* e = tuningEnv("SLRHIP_WS_REFILL")) g_refill = (uint32_t)atoi(e);
+        if (const char* e = tuningEnv("SLRHIP_WS_NC")) { const int n = atoi(e); g_consumers = n == 3 ? 3 : n == 15 ? 15 : n == 7 ? 7 : 0; }
         if (g_refill < 1) g_refill = 1;
         if (g_refill > 64) g_refill = 64;
         return true;
     }();
     (void)init;
-    if (const char* e = getenv("SLRHIP_WS_BLOCKS_PER_CU")) { const int b = atoi(e); if (b >= 1 && b <= 8) return b; }   // experiments
+    if (const char* e = tuningEnv("SLRHIP_WS_BLOCKS_PER_CU")) { const int b = atoi(e); if (b >= 1 && b <= 8) return b; }   // experiments
     const int nc = wsConsumers(quantized);
     // 18.5 / 39.5 / 64.5 KiB of LDS per workgroup, 32 waves per CU either way (<= 64 VGPR); fewer where staged nodes (SLR_WS_TOP) need the room
     const size_t lds = nc == 15 ? sizeof(WsLds<15>) : nc == 7 ? sizeof(WsLds<7>) : sizeof(WsLds<3>);

@@ -177,7 +177,7 @@ static int readTotals(slrhip_ctx* ctx, uint64_t* out) {
         out[k] = 0;
         for (uint32_t sh = 0; sh < kShards; ++sh) out[k] += raw[totalIndex(k, sh)];
     }
-    if (getenv("SLRHIP_DEBUG_WS") && out[T_WS_STEPS])
+    if (tuningEnv("SLRHIP_DEBUG_WS") && out[T_WS_STEPS])
         fprintf(stderr, "ws closest: rays %llu nodes %llu tris %llu | consumer wave-steps %llu refills %llu idle spins %llu | "
                         "consumer wave cycles %llu x64, idle %llu x64 | producer waits %llu | node blocks %llu tri blocks %llu active lanes %llu | shadow rays %llu nodes %llu tris %llu\n",
                 (unsigned long long)out[T_EXT_RAYS], (unsigned long long)out[T_NODES_CLOSEST], (unsigned long long)out[T_TRIS_CLOSEST],
@@ -581,8 +581,8 @@ int slrhip_upload_scene(slrhip_ctx* ctx, const slrhip_scene_desc* d) {
 
     // --- upload ----------------------------------------------------------------------------------------------
     // trees beyond the L2 (>= 64 Ki nodes = 8 MiB) are also stored with 8-bit child boxes: half the bytes per node visit
-    static const bool noQuant = [] { const char* e = getenv("SLRHIP_QUANT"); return e && std::string(e) == "0"; }();
-    static const bool forceQuant = [] { const char* e = getenv("SLRHIP_QUANT"); return e && std::string(e) == "1"; }();   // experiment: small trees too
+    static const bool noQuant = [] { const char* e = tuningEnv("SLRHIP_QUANT"); return e && std::string(e) == "0"; }();
+    static const bool forceQuant = [] { const char* e = tuningEnv("SLRHIP_QUANT"); return e && std::string(e) == "1"; }();   // experiment: small trees too
     bool quant = false;
     uint32_t numNodes = 0, treeDepth = 0;
     uint64_t leafRefs = 0;
@@ -774,7 +774,7 @@ int slrhip_render_begin(slrhip_ctx* ctx, const slrhip_render_settings* st, slrhi
         // for the eighth of the image a rank owns at N = 8).  Measured with the fused shade kernel, 16 vs 32 stripes at 1280x720
         // (profiles/r03_e_*): Cornell 2 709 vs 2 719, environment light 5 630 vs 6 061, 10 M-triangle grid 1 954 vs 1 981 Msamples/s.
         const uint32_t target = ctx->config.mode == SLRHIP_MODE_SPECTRAL ? 7372800u : 22118400u;
-        static const long envStripes = [] { const char* e = getenv("SLRHIP_AUTO_STRIPES"); return e ? atol(e) : 0L; }();      // measurement: force the automatic choice
+        static const long envStripes = [] { const char* e = tuningEnv("SLRHIP_AUTO_STRIPES"); return e ? atol(e) : 0L; }();      // measurement: force the automatic choice
         stripes = 1u;
         while (stripes < 64u && (uint64_t)numPixels * stripes < target) stripes *= 2u;
         if (numPixels == 0) stripes = 1u;
@@ -791,7 +791,7 @@ int slrhip_render_begin(slrhip_ctx* ctx, const slrhip_render_settings* st, slrhi
     HIP_TRY(ctx->pixelXY.upload(pixels));
     // SLRHIP_PAIRS (bit 0: ray origin + direction, bit 1: the path's radiance sum + its compensation, bit 2: sample header + RNG state): the two records of a pair
     // interleaved in one array, one 32-byte sector per slot (PathBuffers::rayStride / spStride)
-    static const int envPairs = [] { const char* e = getenv("SLRHIP_PAIRS"); return e ? atoi(e) : kDefaultPairs; }();
+    static const int envPairs = [] { const char* e = tuningEnv("SLRHIP_PAIRS"); return e ? atoi(e) : kDefaultPairs; }();
     const uint32_t rayStride = (envPairs & 1) ? 2u : 1u, spStride = (envPairs & 2) ? 2u : 1u, hdrStride = (envPairs & 4) ? 2u : 1u;
     HIP_TRY(ctx->rayOrg.alloc(numSlots * rayStride, true)); HIP_TRY(ctx->rayDir.alloc(rayStride == 2 ? 1 : numSlots, true)); HIP_TRY(ctx->hit.alloc(numSlots, true));
     HIP_TRY(ctx->alpha.alloc(numSlots * planes, true)); HIP_TRY(ctx->spR.alloc(numSlots * planes * spStride, true)); HIP_TRY(ctx->spC.alloc(spStride == 2 ? 1 : numSlots * planes, true));

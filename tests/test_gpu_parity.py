@@ -968,9 +968,7 @@ def test_tail_kernel_variants_match_the_wavefront_iterations_bit_for_bit():
             ctr, prof = c.counters(), c.profile()
             out.append((fb, (int(ctr.samples), int(ctr.extension_rays), int(ctr.shadow_rays)), int(prof.launches[2])))
             c.close()
-        # spectral scenes with MultiBSDF materials or textures have no tail kernel (not built: compile time) and stay on the wavefront
-        expect = 0 if name in ("multi spectral", "textured spectral") else 1
-        assert out[0][2] == 0 and out[1][2] == expect, (name, out[0][2], out[1][2])
+        assert out[0][2] == 0 and out[1][2] == 1, (name, out[0][2], out[1][2])
         assert out[0][1] == out[1][1], (name, out[0][1], out[1][1])
         assert_bit_equal(out[1][0], out[0][0], "tail kernel vs wavefront iterations, one stripe: " + name)
         assert out[0][0].sum() > 0, name

@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools/build_variant.sh NAME "EXTRA FLAGS" FILE.hip [FILE.hip ...] — an alternate libslrhip with the named translation units
-# rebuilt with extra -D flags, for A/B timing on the GPU box:
+# rebuilt with extra -D flags (and -DSLR_TUNING_KNOBS: the measurement environment variables are read), for A/B timing on the GPU box:
 #     SLRHIP_LIBRARY=slr_amd/csrc/variants/libslrhip_NAME.so python bench.py ...
 set -e
 cd "$(dirname "$0")/../slr_amd/csrc"
@@ -14,7 +14,7 @@ for o in $objs; do
   rebuilt=0
   for f in "$@"; do if [ "$f" = "$src" ]; then rebuilt=1; fi; done
   if [ $rebuilt = 1 ]; then
-    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-function $extra -c $src -o variants/$name/$o &
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-function -fno-slp-vectorize -DSLR_TUNING_KNOBS $extra -c $src -o variants/$name/$o &
     link="$link variants/$name/$o"
   else link="$link $o"; fi
 done

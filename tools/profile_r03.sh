@@ -30,7 +30,7 @@ if [ "$quick" != quick ]; then
   traffic ibl_1280x720_2048spp --workload ibl
   traffic grid10m_1280x720_4096spp --workload grid10m
 fi
-for wl in "cornell:--spp 256" "grid10m:--workload grid10m --spp 256"; do
+for wl in "cornell:--spp 256" "grid10m:--workload grid10m --spp 256" "boxes_spectral:--workload boxes_spectral --spp 128"; do
   n=${wl%%:*}; a=${wl#*:}
   counters ${n}_sq_cycles "$a" SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM
   counters ${n}_sq_insts "$a" SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT
