@@ -245,7 +245,7 @@ void quantizeNodes(QBVH* out) {
     for (std::thread& th : pool) th.join();
 }
 
-int buildQBVH(const slrhip_vertex* verts, const slrhip_triangle* tris, uint32_t numTris, QBVH* out, bool spatialSplits) {
+int buildQBVH(const slrhip_vertex* verts, const slrhip_triangle* tris, uint32_t numTris, QBVH* out, bool spatialSplits, bool wide8) {
     if (!verts || !tris || numTris == 0 || numTris > kLeafIndexMask) return 1;
     std::vector<Box> primBox(numTris);
     for (uint32_t i = 0; i < numTris; ++i) {
@@ -290,10 +290,13 @@ int buildQBVH(const slrhip_vertex* verts, const slrhip_triangle* tris, uint32_t 
     std::vector<Kids> kidsOf;
     std::vector<uint32_t> depthOf;
     uint32_t leafCursor = 0;
+    std::vector<uint32_t> leafRefOf(wide8 ? b.nodes.size() : 0, 0u);      // the leaf packet of every binary leaf, for the eight-wide tree
     auto leafRef = [&](const BNode& leaf) -> uint32_t {
         uint32_t first = leafCursor;
         leafCursor += leaf.count;
-        return kLeafFlag | (leaf.count << kLeafCountShift) | first;
+        const uint32_t ref = kLeafFlag | (leaf.count << kLeafCountShift) | first;
+        if (wide8) leafRefOf[&leaf - b.nodes.data()] = ref;
+        return ref;
     };
     const BNode& root = b.nodes[0];
     if (root.count > 0) {
@@ -403,6 +406,75 @@ int buildQBVH(const slrhip_vertex* verts, const slrhip_triangle* tris, uint32_t 
     }
     if (getenv("SLRHIP_BVH_TIMING")) fprintf(stderr, "bvh: collapse %.2f s, emit %.2f s\n", std::chrono::duration<double>(tD - tC).count(),
         std::chrono::duration<double>(std::chrono::steady_clock::now() - tD).count());
+
+    // ---- the same binary tree as EIGHT-wide quantized nodes (QNode8), breadth-first, over the same leaf packets ------------------
+    out->nodes8.clear();
+    out->depth8 = 0;
+    if (wide8 && root.count == 0) {
+        struct Pending { uint32_t bnode, depth; };
+        std::vector<Pending> queue(1, Pending{0u, 1u});
+        out->nodes8.reserve(b.nodes.size() / 4 + 1);
+        for (size_t qi = 0; qi < queue.size(); ++qi) {
+            const BNode& bn = b.nodes[queue[qi].bnode];
+            out->depth8 = std::max(out->depth8, queue[qi].depth);
+            uint32_t kids[8] = {bn.left, bn.right, 0, 0, 0, 0, 0, 0};
+            int nk = 2;
+            while (nk < 8) {          // open the inner child with the largest surface area, as the four-wide collapse does
+                int best = -1;
+                float bestArea = -1.0f;
+                for (int i = 0; i < nk; ++i) {
+                    const BNode& c = b.nodes[kids[i]];
+                    if (c.count > 0) continue;
+                    const float a = c.box.area();
+                    if (a > bestArea) { bestArea = a; best = i; }
+                }
+                if (best < 0) break;
+                const BNode& c = b.nodes[kids[best]];
+                kids[best] = c.left;
+                kids[nk++] = c.right;
+            }
+            QNode8 q;
+            std::memset(&q, 0, sizeof(q));
+            float org[3], scl[3];
+            for (int a = 0; a < 3; ++a) {
+                float bmin = INFINITY, bmax = -INFINITY;
+                for (int c = 0; c < nk; ++c) { bmin = std::fmin(bmin, b.nodes[kids[c]].box.lo[a]); bmax = std::fmax(bmax, b.nodes[kids[c]].box.hi[a]); }
+                org[a] = bmin;
+                float sc = (bmax - bmin) / 255.0f;
+                while (sc > 0.0f && dequant(255, sc, bmin) < bmax) sc = std::nextafter(sc, INFINITY);
+                scl[a] = sc;
+            }
+            uint32_t* qlo[3] = {q.qlox, q.qloy, q.qloz};
+            uint32_t* qhi[3] = {q.qhix, q.qhiy, q.qhiz};
+            for (int c = 0; c < 8; ++c) {
+                if (c >= nk) {
+                    q.child[c] = kInvalidChild;
+                    for (int a = 0; a < 3; ++a) { qlo[a][c >> 2] |= 255u << (8 * (c & 3)); }      // inverted box (hi stays 0): never entered
+                    continue;
+                }
+                const BNode& cn = b.nodes[kids[c]];
+                for (int a = 0; a < 3; ++a) {
+                    uint32_t l = 0, h = 0;
+                    if (scl[a] > 0.0f) {
+                        l = (uint32_t)std::fmin(255.0f, std::fmax(0.0f, std::floor((cn.box.lo[a] - org[a]) / scl[a])));
+                        h = (uint32_t)std::fmin(255.0f, std::fmax(0.0f, std::ceil((cn.box.hi[a] - org[a]) / scl[a])));
+                        while (l > 0 && dequant(l, scl[a], org[a]) > cn.box.lo[a]) --l;
+                        while (h < 255 && dequant(h, scl[a], org[a]) < cn.box.hi[a]) ++h;
+                    }
+                    qlo[a][c >> 2] |= l << (8 * (c & 3));
+                    qhi[a][c >> 2] |= h << (8 * (c & 3));
+                }
+                if (cn.count > 0) q.child[c] = leafRefOf[kids[c]];
+                else {
+                    q.child[c] = (uint32_t)queue.size();
+                    queue.push_back(Pending{kids[c], queue[qi].depth + 1});
+                }
+            }
+            q.ox = org[0]; q.oy = org[1]; q.oz = org[2];
+            q.sx = scl[0]; q.sy = scl[1]; q.sz = scl[2];
+            out->nodes8.push_back(q);
+        }
+    }
     return 0;
 }
 

@@ -12,6 +12,8 @@ namespace slrhip {
 struct QBVH {
     std::vector<QNode> nodes;        // breadth-first; nodes[0] is the root
     std::vector<QNodeQ> quantized;   // same nodes, 8-bit child boxes (quantizeNodes); empty unless asked for
+    std::vector<QNode8> nodes8;      // the same binary tree collapsed to eight-wide quantized nodes (buildQBVH's wide8 argument); same leaf packets
+    uint32_t depth8 = 0;
     std::vector<LeafTri> leafTris;   // leaf packets, contiguous per leaf
     uint32_t depth = 0;              // levels of 4-wide nodes
     uint64_t spatialSplits = 0;      // spatial-split build only: splits in space, and leaf references (>= triangles: duplicates)
@@ -65,6 +67,6 @@ int buildGeometryDevice(const slrhip_vertex* verts, uint32_t numVerts, const slr
                         uint32_t numLights, bool wantQuantized, DeviceGeometry* out, std::string* err);
 
 // Returns 0 on success.
-int buildQBVH(const slrhip_vertex* verts, const slrhip_triangle* tris, uint32_t numTris, QBVH* out, bool spatialSplits = false);
+int buildQBVH(const slrhip_vertex* verts, const slrhip_triangle* tris, uint32_t numTris, QBVH* out, bool spatialSplits = false, bool wide8 = false);
 
 } // namespace slrhip

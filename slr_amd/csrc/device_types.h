@@ -56,6 +56,22 @@ struct alignas(16) QNodeQ {
 };
 static_assert(sizeof(QNodeQ) == 64, "QNodeQ must be half a 128-byte line");
 
+// QNode8 128 B = one line: an EIGHT-wide node with the child boxes quantized like QNodeQ's (8 bits per plane inside the box of all
+// children).  Half the levels of the four-wide tree: fewer dependent node visits per ray, the same seven 16-byte loads per visit as
+// a float QNode.  Measured against the four-wide trees in DESIGN.md (k_trace_ws<.., WIDE8>); float4 index inside the node:
+//   0: ox oy oz sx | 1: sy sz lox[0-3] lox[4-7] | 2: loy[0-3] loy[4-7] loz[0-3] loz[4-7] | 3: hix hix hiy hiy | 4: hiz hiz - - |
+//   5: child[0-3] | 6: child[4-7] | 7: unused
+struct alignas(16) QNode8 {
+    float ox, oy, oz, sx;
+    float sy, sz; uint32_t qlox[2];
+    uint32_t qloy[2], qloz[2];
+    uint32_t qhix[2], qhiy[2];
+    uint32_t qhiz[2], pad0[2];
+    uint32_t child[8];
+    uint32_t pad1[4];
+};
+static_assert(sizeof(QNode8) == 128, "QNode8 must be one 128-byte line");
+
 struct alignas(16) LeafTri {
     float v0[3]; uint32_t tri;
     float e1[3]; uint32_t alpha;         // index into the alpha records (Triangle::m_alphaTex, pt_tex.h), kNoAlpha = none

@@ -21,6 +21,7 @@ struct DevScene {
     const float* lightCDF;        // numLights + 1 entries
     uint32_t numNodes;
     const float4* nodesQ;         // QNodeQ array (4 x float4 per node) or nullptr: large scenes traverse this one
+    const float4* nodes8;         // QNode8 array (8 x float4 per node) or nullptr: the eight-wide quantized tree (k_trace_ws only)
     uint32_t numMaterials;
     uint32_t numLights;
     uint32_t lightPow2;           // prevPowerOf2(numLights)

@@ -156,7 +156,7 @@ struct WsCounts {
     uint32_t nodes[2] = {0, 0}, tris[2] = {0, 0};   // [0] closest, [1] shadow
 };
 
-template <bool COUNT, int NC, bool QUANT>
+template <bool COUNT, int NC, bool QUANT, bool WIDE8>
 __device__ __forceinline__ void wsConsume(const DevScene& sc, const PathBuffers& pb, WsLds<NC>& lds, uint32_t refill, uint32_t numTop, WsCounts& cnt, WsDebug& dbg) {
     const uint64_t tStart = COUNT ? __builtin_readcyclecounter() : 0;
     constexpr uint32_t kRing = WsLds<NC>::kRing;
@@ -251,6 +251,62 @@ __device__ __forceinline__ void wsConsume(const DevScene& sc, const PathBuffers&
             const bool leafAtTop = (cur & kLeafFlag) != 0;
             if (!leafAtTop) {
                 if (COUNT) { const bool sh = (slot & kShadowBit) != 0; cnt.nodes[0] += sh ? 0u : 1u; cnt.nodes[1] += sh ? 1u : 0u; }
+                if (WIDE8) {
+                    // Eight-wide quantized node (device_types.h QNode8): seven 16-byte loads, then the children one after the other —
+                    // dequantize the near and far planes (fma(byte, scale, origin), rounded outwards by the host: supersets of the float
+                    // boxes, same hits), slab test, keep the nearest hit child as the next node and push the others as they come
+                    const char* nb = reinterpret_cast<const char*>(sc.nodes8);
+                    const uint32_t nOff = cur * 128u;
+                    const float4 v0 = *reinterpret_cast<const float4*>(nb + nOff);
+                    const float4 v1 = *reinterpret_cast<const float4*>(nb + (nOff + 16u));
+                    const float4 v2 = *reinterpret_cast<const float4*>(nb + (nOff + 32u));
+                    const float4 v3 = *reinterpret_cast<const float4*>(nb + (nOff + 48u));
+                    const float4 v4 = *reinterpret_cast<const float4*>(nb + (nOff + 64u));
+                    const float4 ca = *reinterpret_cast<const float4*>(nb + (nOff + 80u));
+                    const float4 cb = *reinterpret_cast<const float4*>(nb + (nOff + 96u));
+                    const bool px = idx > 0.0f, py = idy > 0.0f, pz = idz > 0.0f;                   // QBVH.h:66-71
+                    const uint32_t lox[2] = {__float_as_uint(v1.z), __float_as_uint(v1.w)}, loy[2] = {__float_as_uint(v2.x), __float_as_uint(v2.y)},
+                                   loz[2] = {__float_as_uint(v2.z), __float_as_uint(v2.w)}, hix[2] = {__float_as_uint(v3.x), __float_as_uint(v3.y)},
+                                   hiy[2] = {__float_as_uint(v3.z), __float_as_uint(v3.w)}, hiz[2] = {__float_as_uint(v4.x), __float_as_uint(v4.y)};
+                    const uint32_t cc[8] = {__float_as_uint(ca.x), __float_as_uint(ca.y), __float_as_uint(ca.z), __float_as_uint(ca.w),
+                                            __float_as_uint(cb.x), __float_as_uint(cb.y), __float_as_uint(cb.z), __float_as_uint(cb.w)};
+                    float best = INFINITY;
+                    uint32_t next = kInvalidChild;
+#define WS_PUSH8(cond, ref)                                                             \
+                    if (cond) {                                                         \
+                        if (sp < kWsLdsStack) { stack[sp * 64] = (ref); ++sp; }         \
+                        else if (!kNoSpill && sp < kWsLdsStack + kWsSpill) { spill[sp - kWsLdsStack] = (ref); ++sp; } \
+                        else atomicOr(pb.errorWord, ERR_STACK_OVERFLOW);      /* the host falls back to the four-wide tree for deeper ones */ \
+                    }
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        const int w = c >> 2, sh = 8 * (c & 3);
+                        const uint32_t nqx = px ? lox[w] : hix[w], fqx = px ? hix[w] : lox[w];
+                        const uint32_t nqy = py ? loy[w] : hiy[w], fqy = py ? hiy[w] : loy[w];
+                        const uint32_t nqz = pz ? loz[w] : hiz[w], fqz = pz ? hiz[w] : loz[w];
+                        const float nX = __builtin_fmaf((float)((nqx >> sh) & 0xFFu), v0.w, v0.x), fX = __builtin_fmaf((float)((fqx >> sh) & 0xFFu), v0.w, v0.x);
+                        const float nY = __builtin_fmaf((float)((nqy >> sh) & 0xFFu), v1.x, v0.y), fY = __builtin_fmaf((float)((fqy >> sh) & 0xFFu), v1.x, v0.y);
+                        const float nZ = __builtin_fmaf((float)((nqz >> sh) & 0xFFu), v1.y, v0.z), fZ = __builtin_fmaf((float)((fqz >> sh) & 0xFFu), v1.y, v0.z);
+                        const float tn = fmaxf(fmaxf((nX - ox) * idx, (nY - oy) * idy), fmaxf((nZ - oz) * idz, tmin));
+                        const float tf = fminf(fminf((fX - ox) * idx, (fY - oy) * idy), fminf((fZ - oz) * idz, tmax));
+                        const bool hit = tn <= tf && cc[c] != kInvalidChild;
+                        const bool closer = hit && tn < best;
+                        const uint32_t displaced = closer ? next : cc[c];
+                        const bool doPush = hit && displaced != kInvalidChild;
+                        best = closer ? tn : best;
+                        next = closer ? cc[c] : next;
+                        WS_PUSH8(doPush, displaced)
+                    }
+#undef WS_PUSH8
+                    if (next != kInvalidChild) cur = next;
+                    else if (sp == 0) finished = true;
+                    else {
+                        --sp;
+                        if (kNoSpill || sp < kWsLdsStack) cur = stack[sp * 64];
+                        else cur = spill[sp - kWsLdsStack];
+                    }
+                }
+                else {
                 // float4 index inside a 128-byte node: 0..2 = min xyz, 3..5 = max xyz, 6 = children (QBVH.h:66-71 folded into offsets)
                 float4 nX, nY, nZ, fX, fY, fZ, ch;
                 if (QUANT) {
@@ -360,6 +416,7 @@ __device__ __forceinline__ void wsConsume(const DevScene& sc, const PathBuffers&
                     --sp;
                     if (kNoSpill || sp < kWsLdsStack) cur = stack[sp * 64];
                     else cur = spill[sp - kWsLdsStack];
+                }
                 }
             }
             // kChain: a lane whose node step ended on a leaf tests that leaf's first triangle in the same iteration
@@ -526,7 +583,7 @@ __device__ __forceinline__ void wsProduce(const PathBuffers& pb, LDS& lds, uint3
 //            iff its state is FIRST_HIT or NEXT_HIT (flag values 2 and 3, pt_shade_kernels.h).
 //   phase 2, shadow rays: Scene::testVisibility (SurfaceObject.cpp:418-430) = "no hit in [eps, d(1-eps)]"; workgroup b
 //            serves queue region b % kShards (gridDim is a multiple of kShards).
-template <bool COUNT, int NC, bool QUANT>
+template <bool COUNT, int NC, bool QUANT, bool WIDE8 = false>
 __global__ __launch_bounds__(64 * (NC + 1)) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_trace_ws(DevScene sc, PathBuffers pb, uint32_t numSlots, uint32_t shardCapacity, uint32_t parity, uint32_t refill,
                                                                                                               uint32_t tailSlots) {
     __shared__ WsLds<NC> lds;
@@ -548,7 +605,7 @@ __global__ __launch_bounds__(64 * (NC + 1)) __attribute__((amdgpu_waves_per_eu(8
     WsDebug dbg;
     if (threadIdx.x < 64) wsProduce(pb, lds, numSlots, shardCapacity, parity, extRays, shadowRays, dbg);
     else {
-        wsConsume<COUNT, NC, QUANT>(sc, pb, lds, refill, numTop, cnt, dbg);
+        wsConsume<COUNT, NC, QUANT, WIDE8>(sc, pb, lds, refill, numTop, cnt, dbg);
     }
     wsBlockAdd(pb.totals, T_EXT_RAYS, extRays, lds.red);
     wsBlockAdd(pb.totals, T_SHADOW_RAYS, shadowRays, lds.red);
@@ -572,6 +629,10 @@ __global__ __launch_bounds__(64 * (NC + 1)) __attribute__((amdgpu_waves_per_eu(8
 template <bool COUNT, int NC>
 static void launchTraceWsT(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, uint32_t blocks, hipStream_t stream) {
     const dim3 grid(blocks), block(64 * (NC + 1));
+#ifdef SLR_TUNING_KNOBS
+    // the eight-wide quantized tree (measurement, DESIGN.md: -2 % on the headline, +3..6 % slower elsewhere): instantiated in variant builds only
+    if (sc.nodes8) { hipLaunchKernelGGL((k_trace_ws<COUNT, NC, false, true>), grid, block, 0, stream, sc, pb, rp.numSlots, rp.shardCapacity, parity, g_refill, rp.tailSlots); return; }
+#endif
     if (sc.nodesQ) hipLaunchKernelGGL((k_trace_ws<COUNT, NC, true>), grid, block, 0, stream, sc, pb, rp.numSlots, rp.shardCapacity, parity, g_refill, rp.tailSlots);
     else hipLaunchKernelGGL((k_trace_ws<COUNT, NC, false>), grid, block, 0, stream, sc, pb, rp.numSlots, rp.shardCapacity, parity, g_refill, rp.tailSlots);
 }

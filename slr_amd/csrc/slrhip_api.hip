@@ -116,6 +116,7 @@ struct slrhip_ctx {
     // scene
     DevArray<QNode> nodes;
     DevArray<QNodeQ> nodesQ;
+    DevArray<QNode8> nodes8;
     DevArray<DevTexture> textures;
     DevArray<DevMatTex> matTex;
     DevArray<float4> triUV, alphaTris;
@@ -471,7 +472,8 @@ int slrhip_upload_scene(slrhip_ctx* ctx, const slrhip_scene_desc* d) {
     const bool deviceBuild = wantDevice && !anyAlpha && d->num_triangles >= 1024;
     QBVH bvh;
     if (!deviceBuild) {
-        if (buildQBVH(d->vertices, d->triangles, d->num_triangles, &bvh, (ctx->config.flags & SLRHIP_FLAG_BVH_SPATIAL_SPLITS) != 0) != 0)
+        static const bool wide8 = [] { const char* e = tuningEnv("SLRHIP_WIDE8"); return e && std::string(e) == "1"; }();      // measurement: the eight-wide quantized tree
+        if (buildQBVH(d->vertices, d->triangles, d->num_triangles, &bvh, (ctx->config.flags & SLRHIP_FLAG_BVH_SPATIAL_SPLITS) != 0, wide8) != 0)
             return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: BVH build failed");
         if (3 * bvh.depth + 1 > 64)
             return fail(SLRHIP_ERR_UNSUPPORTED, "slrhip_upload_scene: tree deeper than the 64-entry traversal stack (QBVH.h:299)");
@@ -583,7 +585,7 @@ int slrhip_upload_scene(slrhip_ctx* ctx, const slrhip_scene_desc* d) {
     // trees beyond the L2 (>= 64 Ki nodes = 8 MiB) are also stored with 8-bit child boxes: half the bytes per node visit
     static const bool noQuant = [] { const char* e = tuningEnv("SLRHIP_QUANT"); return e && std::string(e) == "0"; }();
     static const bool forceQuant = [] { const char* e = tuningEnv("SLRHIP_QUANT"); return e && std::string(e) == "1"; }();   // experiment: small trees too
-    bool quant = false;
+    bool quant = false, useWide8 = false;
     uint32_t numNodes = 0, treeDepth = 0;
     uint64_t leafRefs = 0;
     if (deviceBuild) {
@@ -610,6 +612,8 @@ int slrhip_upload_scene(slrhip_ctx* ctx, const slrhip_scene_desc* d) {
         quant = (bvh.nodes.size() >= 65536 || forceQuant) && !noQuant;
         if (quant) { quantizeNodes(&bvh); HIP_TRY(ctx->nodesQ.upload(bvh.quantized)); }
         numNodes = (uint32_t)bvh.nodes.size(); treeDepth = bvh.depth; leafRefs = bvh.leafTris.size();
+        useWide8 = !bvh.nodes8.empty() && 7 * bvh.depth8 + 1 <= 64;          // up to seven pushes per level on the 64-entry stack
+        if (useWide8) HIP_TRY(ctx->nodes8.upload(bvh.nodes8));
     }
     // alpha textures (Triangle::m_alphaTex): one record per triangle that has one, named by its leaf entries; texture coordinates
     // of every triangle for the textured shading kernels
@@ -697,6 +701,7 @@ int slrhip_upload_scene(slrhip_ctx* ctx, const slrhip_scene_desc* d) {
     sc.numTextures = numTextures;
     sc.numNodes = numNodes;
     sc.nodesQ = quant ? reinterpret_cast<const float4*>(ctx->nodesQ.ptr) : nullptr;
+    sc.nodes8 = useWide8 ? reinterpret_cast<const float4*>(ctx->nodes8.ptr) : nullptr;
     sc.numMaterials = (uint32_t)mats.size();
     sc.numSpectra = (uint32_t)devSpectra.size();
     sc.numLights = (uint32_t)lights.size();
