@@ -73,6 +73,8 @@ def parse():
     ap.add_argument("--workload", default="cornell", choices=["cornell", "boxes_spectral", "ibl", "grid10m"],
                     help="cornell = BASELINE configs[1] (the headline metric); the others are configs[2..4], measured the same way")
     ap.add_argument("--grid-n", type=int, default=2236, help="grid10m: cells per side (2 n^2 triangles)")
+    ap.add_argument("--instanced", action="store_true",
+                    help="grid10m as BASELINE configs[4] words it, an INSTANCED mesh: one 8 192-triangle patch placed 1 250 times (two-level traversal)")
     ap.add_argument("--stripes", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--no-parity", action="store_true")
@@ -89,7 +91,7 @@ def traffic_entry(args, W, H, spp):
     the end of a render — and with it the average bytes per launch — changes with the pass count); {} when no pass covers it,
     and the roofline figure is then a modelled one under its own key, never `frac`."""
     table = json.load(open(args.traffic_json))
-    return table.get("%s_%dx%d_%dspp" % (args.workload, W, H, spp), {})
+    return table.get("%s%s_%dx%d_%dspp" % (args.workload, "_instanced" if args.instanced else "", W, H, spp), {})
 
 
 def self_launch(args):
@@ -147,8 +149,13 @@ def main():
         what = "BASELINE configs[3]: IBL_Test-shaped, 24-patch floor + mirror sphere under a synthetic 2048x1024 binary16 sky (scale 4)"
     else:
         spp = args.spp or 4096
-        scene = scenes.displaced_grid(args.grid_n, W / H)
-        what = "BASELINE configs[4]: one displaced grid (hash-noise heightfield, seed 20240611), matte, one area light, thin lens r=0.025"
+        if args.instanced:
+            scene = scenes.instanced_grid(25, 50, 64, W / H)
+            what = ("BASELINE configs[4], instanced: one 8 192-triangle heightfield patch placed 1 250 times (non-uniform scales, half turns), "
+                    "matte, one area light, thin lens r=0.025")
+        else:
+            scene = scenes.displaced_grid(args.grid_n, W / H)
+            what = "BASELINE configs[4]: one displaced grid (hash-noise heightfield, seed 20240611), matte, one area light, thin lens r=0.025"
     settings = abi.RenderSettings(W, H, 0.0, 0.0, 1.0, abi.DEFAULT_SEED)
     build_flag = abi.FLAG_BVH_DEVICE_BUILD if args.tree == "device" else 0
     if args.tree == "host":
@@ -205,7 +212,7 @@ def main():
 
     out = {
         "metric": "Msamples/sec @1024spp 1280x720 (unidirectional path tracing, Cornell_Box_Spheres-shaped scene)" if args.workload == "cornell"
-                  else "Msamples/sec @%dspp %dx%d (unidirectional path tracing, workload %s)" % (spp, W, H, args.workload),
+                  else "Msamples/sec @%dspp %dx%d (unidirectional path tracing, workload %s)" % (spp, W, H, args.workload + (" instanced" if args.instanced else "")),
         "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 3), "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",

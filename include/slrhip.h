@@ -246,6 +246,21 @@ typedef struct slrhip_upsampling_tables {
     const float* point_spectrum;           /* num_points * 95 */
 } slrhip_upsampling_tables;
 
+/* ---- instancing ------------------------------------------------------------------- */
+/* TransformedSurfaceObject over a mesh's aggregate (libSLR/Core/SurfaceObject.cpp:303-392, StaticTransform only:
+ * Transform.h:38-87): the mesh is a RANGE of slrhip_scene_desc::triangles given in the mesh's local space; a ray is taken to
+ * local space with world_to_local (`invert(sampledTF) * ray`: origin as a point, direction as a vector, NOT renormalised, so
+ * distances stay world distances), intersected with the mesh there, and the surface point comes back through local_to_world
+ * (`sampledTF * surfPt`, geometry.cpp:63-78: p as a point, the geometric normal through the inverse transpose, the shading
+ * frame's axes as vectors, each re-normalised).  Ranges of two instances are either equal (one mesh, many placements — the
+ * mesh's tree is built once) or disjoint; triangles inside an instanced range are not objects of the top-level aggregate.
+ * Instanced triangles must not emit.  Matrices are column-major like slrhip_camera's.                                       */
+typedef struct slrhip_instance {
+    uint32_t first_triangle, num_triangles;
+    float local_to_world[16];
+    float world_to_local[16];
+} slrhip_instance;
+
 /* ---- scene ----------------------------------------------------------------------- */
 typedef struct slrhip_scene_desc {
     const slrhip_vertex* vertices;
@@ -265,6 +280,8 @@ typedef struct slrhip_scene_desc {
     uint32_t num_textures;
     const float* texture_texels;                  /* texels of the IMAGE_SPECTRUM textures, 3 floats each (appended in version 7) */
     uint32_t num_texture_texels;                  /* number of TEXELS                                                        */
+    const slrhip_instance* instances;             /* NULL / 0 = no instanced mesh (appended in version 7)                    */
+    uint32_t num_instances;
 } slrhip_scene_desc;
 
 /* ---- render settings -------------------------------------------------------------- */

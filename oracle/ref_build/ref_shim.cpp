@@ -161,6 +161,12 @@ struct slr_oracle_scene {
     std::vector<SVFresnel*> fresnels;
     std::vector<SVMicrofacetDistribution*> mfDists;
     SurfaceObjectAggregate* aggregate = nullptr;
+    // slrhip_instance: one SurfaceObjectAggregate per distinct mesh (triangle range), one TransformedSurfaceObject per placement
+    std::vector<std::vector<SurfaceObject*>> meshObjs;
+    std::vector<SurfaceObjectAggregate*> meshAggregates;
+    std::vector<StaticTransform*> instanceTFs;
+    std::vector<SurfaceObject*> topObjs;                 // what the top-level aggregate was built over
+    std::vector<SurfaceObject*> instanceObjs;
     PerspectiveCamera* camera = nullptr;
     StaticTransform* cameraTF = nullptr;
     Scene scene;
@@ -330,7 +336,40 @@ slr_oracle_scene* slr_ref_create(const slrhip_scene_desc* d, int mode) {
         s->objs.push_back(o);
         s->objIndex[o] = i;
     }
-    s->aggregate = new SurfaceObjectAggregate(s->objs);
+    // instances: the triangles of an instanced range form their own aggregate (TriangleMeshNode under a transformed InternalNode,
+    // libSLRSceneGraph) and reach the top level only through TransformedSurfaceObjects (Core/SurfaceObject.cpp:303-392)
+    std::vector<char> instanced(d->num_triangles, 0);
+    std::vector<std::pair<uint32_t, uint32_t>> meshRange;
+    std::vector<uint32_t> meshOf;
+    for (uint32_t k = 0; k < d->num_instances && d->instances; ++k) {
+        const slrhip_instance& in = d->instances[k];
+        if (in.num_triangles == 0 || (uint64_t)in.first_triangle + in.num_triangles > d->num_triangles) { slr_ref_destroy(s); return nullptr; }
+        uint32_t m = 0;
+        for (; m < meshRange.size(); ++m) if (meshRange[m].first == in.first_triangle && meshRange[m].second == in.num_triangles) break;
+        if (m == meshRange.size()) {
+            meshRange.push_back(std::make_pair(in.first_triangle, in.num_triangles));
+            s->meshObjs.push_back(std::vector<SurfaceObject*>());
+            for (uint32_t t = 0; t < in.num_triangles; ++t) {
+                if (instanced[in.first_triangle + t]) { slr_ref_destroy(s); return nullptr; }      // overlapping ranges
+                instanced[in.first_triangle + t] = 1;
+                s->meshObjs.back().push_back(s->objs[in.first_triangle + t]);
+            }
+            s->meshAggregates.push_back(new SurfaceObjectAggregate(s->meshObjs.back()));
+        }
+        meshOf.push_back(m);
+    }
+    for (uint32_t i = 0; i < d->num_triangles; ++i) if (!instanced[i]) s->topObjs.push_back(s->objs[i]);
+    for (uint32_t k = 0; k < meshOf.size(); ++k) {
+        const slrhip_instance& in = d->instances[k];
+        float m[16], mi[16];
+        for (int i = 0; i < 16; ++i) { m[i] = in.local_to_world[i]; mi[i] = in.world_to_local[i]; }
+        StaticTransform* tf = new StaticTransform(Matrix4x4(m), Matrix4x4(mi));
+        s->instanceTFs.push_back(tf);
+        SurfaceObject* o = new TransformedSurfaceObject(s->meshAggregates[meshOf[k]], tf);
+        s->topObjs.push_back(o);
+        s->instanceObjs.push_back(o);
+    }
+    s->aggregate = new SurfaceObjectAggregate(s->topObjs);
 
     const slrhip_camera& c = d->camera;
     s->camera = new PerspectiveCamera(c.sensitivity, c.aspect, c.fov_y, c.lens_radius, c.img_plane_distance, c.obj_plane_distance);
@@ -356,6 +395,9 @@ void slr_ref_destroy(slr_oracle_scene* s) {
     delete s->camera;
     delete s->cameraTF;
     delete s->aggregate;
+    for (auto* o : s->instanceObjs) delete o;
+    for (auto* a : s->meshAggregates) delete a;
+    for (auto* t : s->instanceTFs) delete t;
     for (auto* o : s->objs) delete o;
     for (auto* m : s->ownedMaterials) delete m;
     for (auto* e : s->emitters) delete e;
@@ -536,6 +578,7 @@ int slr_ref_trace(slr_oracle_scene* s, const slr_oracle_ray* rays, uint32_t n, s
         Intersection isect;
         const SurfaceObject* agg = s->aggregate;
         if (agg->intersect(r, &isect)) {
+            if (!s->objIndex.count(isect.obj.top())) isect.obj.pop();      // a TransformedSurfaceObject: the triangle's object is below it
             hits[i].triangle = s->objIndex.at(isect.obj.top());
             hits[i].dist = isect.dist;
             hits[i].b0 = isect.u;

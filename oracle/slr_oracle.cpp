@@ -19,7 +19,8 @@
  * Deliberate differences (documented in DESIGN.md):
  *   - accelerator: own binary BVH; the reference result does not depend on the tree
  *      except among hits at exactly equal distance, where the reference
- *     keeps the last one tested (TriangleMesh.cpp:158).  Here: larger triangle index wins.
+ *     keeps the last one tested (TriangleMesh.cpp:158).  Here: larger triangle index wins
+ *     (with instances: the larger (instance, triangle) pair, loose triangles = instance -1).
  *   - one xorshift128 stream per (pixel, sample), seeded by slrhip_sample_seed
  *     (the reference has one stream per worker thread, PathTracingRenderer.cpp:33-38).
  */
@@ -306,8 +307,9 @@ struct Isect {             // Core/geometry.h:206-221 (fields the path uses)
     float u, v;
     float texU, texV;      // Intersection::texCoord (TriangleMesh.cpp:160-161,174)
     uint32_t tri;
+    int32_t inst;          // TransformedSurfaceObject the hit went through (index into the scene's instances), -1 = none
     bool atInfinity;
-    Isect() : dist(INFINITY), u(0), v(0), texU(0), texV(0), tri(0xFFFFFFFFu), atInfinity(false) {}
+    Isect() : dist(INFINITY), u(0), v(0), texU(0), texV(0), tri(0xFFFFFFFFu), inst(-1), atInfinity(false) {}
 };
 
 struct SurfPt {            // Core/geometry.h:239-258
@@ -348,8 +350,13 @@ struct slr_oracle_scene {
     Camera camera;
     std::vector<uint32_t> lightTris;   // SurfaceObjectAggregate::m_lightList (SurfaceObject.cpp:232-249)
     Discrete1D lightDist;              // m_lightDist1D
-    std::vector<BVHNode> nodes;
+    std::vector<BVHNode> nodes;        // top level: the loose triangles and the instances (primitive id >= tris.size())
     std::vector<uint32_t> triOrder;
+    // instancing (TransformedSurfaceObject, SurfaceObject.cpp:303-392): per instance its mesh; per mesh its own tree
+    std::vector<slrhip_instance> instances;
+    struct Mesh { uint32_t first, count; std::vector<BVHNode> nodes; std::vector<uint32_t> order; float bmin[3], bmax[3]; };
+    std::vector<Mesh> meshes;
+    std::vector<uint32_t> meshOfInstance;
     bool hasEnv;
     // InfiniteSphereSurfaceObject (SurfaceObject.cpp:137-141): texture, scale, importance distribution
     uint32_t envWidth = 0, envHeight = 0;
@@ -370,26 +377,34 @@ inline V3 vpos(const Scene& s, uint32_t vi) { const float* p = s.vertices[vi].po
 inline V3 vnrm(const Scene& s, uint32_t vi) { const float* p = s.vertices[vi].normal; return V3(p[0], p[1], p[2]); }
 inline V3 vtan(const Scene& s, uint32_t vi) { const float* p = s.vertices[vi].tangent; return V3(p[0], p[1], p[2]); }
 
+// Matrix4x4 x Point3D / Vector3D (Matrix4x4.h:71-81) and StaticTransform x Normal3D (Transform.h:47-52); column-major m
+inline V3 mulPoint(const float* m, V3 p) {
+    float x = m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12] * 1.0f;
+    float y = m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13] * 1.0f;
+    float z = m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14] * 1.0f;
+    float w = m[3] * p.x + m[7] * p.y + m[11] * p.z + m[15] * 1.0f;
+    if (w != 1.0f) { float r = 1.0f / w; x *= r; y *= r; z *= r; }
+    return V3(x, y, z);
+}
+inline V3 mulVector(const float* m, V3 v) {   // Matrix4x4.h:71-73
+    return V3(m[0] * v.x + m[4] * v.y + m[8] * v.z, m[1] * v.x + m[5] * v.y + m[9] * v.z, m[2] * v.x + m[6] * v.y + m[10] * v.z);
+}
+inline V3 mulNormal(const float* mi, V3 n) {  // Transform.h:47-52 (rows of the inverse)
+    return V3(mi[0] * n.x + mi[1] * n.y + mi[2] * n.z, mi[4] * n.x + mi[5] * n.y + mi[6] * n.z, mi[8] * n.x + mi[9] * n.y + mi[10] * n.z);
+}
+
 // ------------------------------------------------------------------------------------------
 // Accelerator (oracle's own): binary BVH, median split on the widest centroid axis.
 // ------------------------------------------------------------------------------------------
-void buildBVH(Scene& s) {
-    uint32_t n = (uint32_t)s.tris.size();
-    s.triOrder.resize(n);
-    std::vector<float> cen(3 * (size_t)n), bmin(3 * (size_t)n), bmax(3 * (size_t)n);
-    for (uint32_t i = 0; i < n; ++i) {
-        s.triOrder[i] = i;
-        for (int a = 0; a < 3; ++a) {
-            float p0 = vpos(s, s.tris[i].v[0])[a], p1 = vpos(s, s.tris[i].v[1])[a], p2 = vpos(s, s.tris[i].v[2])[a];
-            float lo = std::fmin(p0, std::fmin(p1, p2)), hi = std::fmax(p0, std::fmax(p1, p2));
-            bmin[3 * (size_t)i + a] = lo; bmax[3 * (size_t)i + a] = hi; cen[3 * (size_t)i + a] = 0.5f * (lo + hi);
-        }
-    }
-    s.nodes.clear();
-    s.nodes.reserve(2 * (size_t)n);
+// `order` starts as the list of primitive ids; bmin / bmax / cen are indexed by primitive id
+void buildBVHOver(std::vector<BVHNode>& nodes, std::vector<uint32_t>& order, const std::vector<float>& bmin, const std::vector<float>& bmax,
+                  const std::vector<float>& cen) {
+    const uint32_t n = (uint32_t)order.size();
+    nodes.clear();
+    nodes.reserve(2 * (size_t)n + 1);
     struct Job { uint32_t node, begin, end; };
     std::vector<Job> stack;
-    s.nodes.push_back(BVHNode());
+    nodes.push_back(BVHNode());
     stack.push_back({0, 0, n});
     while (!stack.empty()) {
         Job j = stack.back(); stack.pop_back();
@@ -397,7 +412,7 @@ void buildBVH(Scene& s) {
         float cmin[3] = {INFINITY, INFINITY, INFINITY}, cmax[3] = {-INFINITY, -INFINITY, -INFINITY};
         for (int a = 0; a < 3; ++a) { nd.bmin[a] = INFINITY; nd.bmax[a] = -INFINITY; }
         for (uint32_t k = j.begin; k < j.end; ++k) {
-            uint32_t t = s.triOrder[k];
+            uint32_t t = order[k];
             for (int a = 0; a < 3; ++a) {
                 nd.bmin[a] = std::fmin(nd.bmin[a], bmin[3 * (size_t)t + a]);
                 nd.bmax[a] = std::fmax(nd.bmax[a], bmax[3 * (size_t)t + a]);
@@ -411,21 +426,76 @@ void buildBVH(Scene& s) {
         for (int a = 1; a < 3; ++a) if (cmax[a] - cmin[a] > ext) { ext = cmax[a] - cmin[a]; axis = a; }
         if (cnt <= 4 || !(ext > 0.0f)) {
             nd.left = j.begin; nd.count = cnt;
-            s.nodes[j.node] = nd;
+            nodes[j.node] = nd;
             continue;
         }
         uint32_t mid = j.begin + cnt / 2;
-        std::nth_element(s.triOrder.begin() + j.begin, s.triOrder.begin() + mid, s.triOrder.begin() + j.end,
+        std::nth_element(order.begin() + j.begin, order.begin() + mid, order.begin() + j.end,
                          [&](uint32_t a, uint32_t b) {
                              float ca = cen[3 * (size_t)a + axis], cb = cen[3 * (size_t)b + axis];
                              return ca < cb || (ca == cb && a < b);
                          });
-        nd.left = (uint32_t)s.nodes.size(); nd.count = 0;
-        s.nodes[j.node] = nd;
-        s.nodes.push_back(BVHNode()); s.nodes.push_back(BVHNode());
+        nd.left = (uint32_t)nodes.size(); nd.count = 0;
+        nodes[j.node] = nd;
+        nodes.push_back(BVHNode()); nodes.push_back(BVHNode());
         stack.push_back({nd.left, j.begin, mid});
         stack.push_back({nd.left + 1, mid, j.end});
     }
+}
+
+void buildBVH(Scene& s) {
+    const uint32_t n = (uint32_t)s.tris.size(), ni = (uint32_t)s.instances.size();
+    std::vector<float> cen(3 * (size_t)(n + ni)), bmin(3 * (size_t)(n + ni)), bmax(3 * (size_t)(n + ni));
+    std::vector<char> instanced(n, 0);
+    for (uint32_t i = 0; i < n; ++i) {
+        for (int a = 0; a < 3; ++a) {
+            float p0 = vpos(s, s.tris[i].v[0])[a], p1 = vpos(s, s.tris[i].v[1])[a], p2 = vpos(s, s.tris[i].v[2])[a];
+            float lo = std::fmin(p0, std::fmin(p1, p2)), hi = std::fmax(p0, std::fmax(p1, p2));
+            bmin[3 * (size_t)i + a] = lo; bmax[3 * (size_t)i + a] = hi; cen[3 * (size_t)i + a] = 0.5f * (lo + hi);
+        }
+    }
+    // one tree per distinct mesh (triangle range), in the mesh's local space
+    s.meshes.clear();
+    s.meshOfInstance.assign(ni, 0);
+    for (uint32_t k = 0; k < ni; ++k) {
+        const slrhip_instance& in = s.instances[k];
+        uint32_t m = 0;
+        for (; m < s.meshes.size(); ++m) if (s.meshes[m].first == in.first_triangle && s.meshes[m].count == in.num_triangles) break;
+        if (m == s.meshes.size()) {
+            Scene::Mesh mesh;
+            mesh.first = in.first_triangle; mesh.count = in.num_triangles;
+            mesh.order.resize(mesh.count);
+            for (int a = 0; a < 3; ++a) { mesh.bmin[a] = INFINITY; mesh.bmax[a] = -INFINITY; }
+            for (uint32_t t = 0; t < mesh.count; ++t) {
+                mesh.order[t] = mesh.first + t;
+                instanced[mesh.first + t] = 1;
+                for (int a = 0; a < 3; ++a) {
+                    mesh.bmin[a] = std::fmin(mesh.bmin[a], bmin[3 * (size_t)(mesh.first + t) + a]);
+                    mesh.bmax[a] = std::fmax(mesh.bmax[a], bmax[3 * (size_t)(mesh.first + t) + a]);
+                }
+            }
+            buildBVHOver(mesh.nodes, mesh.order, bmin, bmax, cen);
+            s.meshes.push_back(std::move(mesh));
+        }
+        s.meshOfInstance[k] = m;
+        // the instance's world box: the eight corners of the mesh box through the transform (StaticTransform x BoundingBox3D, Transform.h:54-65)
+        const Scene::Mesh& mesh = s.meshes[m];
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int c = 0; c < 8; ++c) {
+            V3 p = mulPoint(in.local_to_world, V3((c & 4) ? mesh.bmax[0] : mesh.bmin[0], (c & 2) ? mesh.bmax[1] : mesh.bmin[1], (c & 1) ? mesh.bmax[2] : mesh.bmin[2]));
+            for (int a = 0; a < 3; ++a) { lo[a] = std::fmin(lo[a], p[a]); hi[a] = std::fmax(hi[a], p[a]); }
+        }
+        for (int a = 0; a < 3; ++a) {
+            // a hair of slack: the local-space traversal rounds differently from a world-space box test
+            const float pad = 1e-5f * std::fmax(1.0f, std::fmax(std::fabs(lo[a]), std::fabs(hi[a])));
+            bmin[3 * (size_t)(n + k) + a] = lo[a] - pad; bmax[3 * (size_t)(n + k) + a] = hi[a] + pad; cen[3 * (size_t)(n + k) + a] = 0.5f * (lo[a] + hi[a]);
+        }
+    }
+    // top level: loose triangles + instances
+    s.triOrder.clear();
+    for (uint32_t i = 0; i < n; ++i) if (!instanced[i]) s.triOrder.push_back(i);
+    for (uint32_t k = 0; k < ni; ++k) s.triOrder.push_back(n + k);
+    buildBVHOver(s.nodes, s.triOrder, bmin, bmax, cen);
 }
 
 // Core/geometry.h:112-126 BoundingBox3D::intersect (slab test)
@@ -485,7 +555,7 @@ inline const slrhip_texture* alphaMapOf(const Scene& s, const slrhip_material& m
     return t ? &s.textures[t - 1] : nullptr;
 }
 
-inline bool triIntersect(const Scene& s, uint32_t ti, const Ray& ray, Isect* isect) {
+inline bool triIntersect(const Scene& s, uint32_t ti, const Ray& ray, Isect* isect, int32_t inst = -1) {
     const Tri& tri = s.tris[ti];
     V3 p0 = vpos(s, tri.v[0]), p1 = vpos(s, tri.v[1]), p2 = vpos(s, tri.v[2]);
     V3 edge01 = p1 - p0;
@@ -502,7 +572,8 @@ inline bool triIntersect(const Scene& s, uint32_t ti, const Ray& ray, Isect* ise
     if (b2 < 0.0f || b1 + b2 > 1.0f) return false;
     float tt = dot(edge02, q) * invDet;
     if (tt < ray.distMin || tt > ray.distMax) return false;
-    if (tt == ray.distMax && isect->tri != 0xFFFFFFFFu && ti < isect->tri) return false;  // tie rule
+    // tie rule (file header): at equal distance the later object wins — larger (instance, triangle) pair
+    if (tt == ray.distMax && isect->tri != 0xFFFFFFFFu && (inst < isect->inst || (inst == isect->inst && ti < isect->tri))) return false;
     float b0 = 1.0f - b1 - b2;
     // TexCoord2D texCoord = b0 * v0.texCoord + b1 * v1.texCoord + b2 * v2.texCoord  (:160-161), from the ORIGINAL barycentrics
     const float* tc0 = s.vertices[tri.v[0]].texcoord;
@@ -521,14 +592,49 @@ inline bool triIntersect(const Scene& s, uint32_t ti, const Ray& ray, Isect* ise
     isect->u = b0;
     isect->v = b1;
     isect->tri = ti;
+    isect->inst = inst;
     isect->atInfinity = false;
     return true;
 }
 
 // SurfaceObjectAggregate::intersect -> Accelerator::intersect (Core/SurfaceObject.cpp:267-269).
 // On every accepted hit ray.distMax = isect->dist (SBVH.h:417-442 / QBVH.h:334-336).
+// TransformedSurfaceObject::intersect (SurfaceObject.cpp:307-317): localRay = invert(TF) * ray — origin as a point, direction as a
+// vector, distMin / distMax unchanged (Transform.h:53) — the mesh's aggregate intersects it, ray.distMax = localRay.distMax.
+bool instanceIntersect(const Scene& s, uint32_t k, Ray& ray, Isect* isect, slr_oracle_counters* ctr) {
+    const slrhip_instance& in = s.instances[k];
+    const Scene::Mesh& mesh = s.meshes[s.meshOfInstance[k]];
+    Ray local;
+    local.org = mulPoint(in.world_to_local, ray.org);
+    local.dir = mulVector(in.world_to_local, ray.dir);
+    local.distMin = ray.distMin; local.distMax = ray.distMax;
+    V3 invDir(1.0f / local.dir.x, 1.0f / local.dir.y, 1.0f / local.dir.z);
+    uint32_t stack[128];
+    int sp = 0;
+    stack[sp++] = 0;
+    bool any = false;
+    while (sp > 0) {
+        const BVHNode& nd = mesh.nodes[stack[--sp]];
+        if (ctr) ++ctr->nodes_visited;
+        if (!boxHit(nd, local, invDir)) continue;
+        if (nd.count) {
+            for (uint32_t t = 0; t < nd.count; ++t) {
+                if (ctr) ++ctr->tris_tested;
+                if (triIntersect(s, mesh.order[nd.left + t], local, isect, (int32_t)k)) { local.distMax = isect->dist; any = true; }
+            }
+        }
+        else {
+            stack[sp++] = nd.left;
+            stack[sp++] = nd.left + 1;
+        }
+    }
+    if (any) ray.distMax = local.distMax;
+    return any;
+}
+
 bool aggregateIntersect(const Scene& s, Ray& ray, Isect* isect, slr_oracle_counters* ctr) {
     V3 invDir(1.0f / ray.dir.x, 1.0f / ray.dir.y, 1.0f / ray.dir.z);   // Vector3.h:60 reciprocal()
+    const uint32_t numTris = (uint32_t)s.tris.size();
     uint32_t stack[128];
     int sp = 0;
     stack[sp++] = 0;
@@ -539,8 +645,10 @@ bool aggregateIntersect(const Scene& s, Ray& ray, Isect* isect, slr_oracle_count
         if (!boxHit(nd, ray, invDir)) continue;
         if (nd.count) {
             for (uint32_t k = 0; k < nd.count; ++k) {
+                const uint32_t prim = s.triOrder[nd.left + k];
+                if (prim >= numTris) { if (instanceIntersect(s, prim - numTris, ray, isect, ctr)) any = true; continue; }
                 if (ctr) ++ctr->tris_tested;
-                if (triIntersect(s, s.triOrder[nd.left + k], ray, isect)) { ray.distMax = isect->dist; any = true; }
+                if (triIntersect(s, prim, ray, isect)) { ray.distMax = isect->dist; any = true; }
             }
         }
         else {
@@ -707,6 +815,15 @@ void getSurfacePoint(const Scene& s, const Isect& isect, SurfPt* sp) {
         sp->frame.x = t;
         sp->frame.y = b;
         sp->frame.z = n;
+    }
+    if (isect.inst >= 0) {
+        // TransformedSurfaceObject::getSurfacePoint (SurfaceObject.cpp:329-336): *surfPt = sampledTF * *surfPt, geometry.cpp:63-78
+        const slrhip_instance& in = s.instances[isect.inst];
+        sp->p = mulPoint(in.local_to_world, sp->p);
+        sp->gNormal = normalize(mulNormal(in.world_to_local, sp->gNormal));
+        sp->frame.x = normalize(mulVector(in.local_to_world, sp->frame.x));
+        sp->frame.y = normalize(mulVector(in.local_to_world, sp->frame.y));
+        sp->frame.z = normalize(mulVector(in.local_to_world, sp->frame.z));
     }
 }
 
@@ -1802,21 +1919,6 @@ void setupCamera(Camera& c, const slrhip_camera& in) {
 }
 
 // Matrix4x4.h:75-81  mat * Point3 (column-major m[c*4+r])
-inline V3 mulPoint(const float* m, V3 p) {
-    float x = m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12] * 1.0f;
-    float y = m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13] * 1.0f;
-    float z = m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14] * 1.0f;
-    float w = m[3] * p.x + m[7] * p.y + m[11] * p.z + m[15] * 1.0f;
-    if (w != 1.0f) { float r = 1.0f / w; x *= r; y *= r; z *= r; }
-    return V3(x, y, z);
-}
-inline V3 mulVector(const float* m, V3 v) {   // Matrix4x4.h:71-73
-    return V3(m[0] * v.x + m[4] * v.y + m[8] * v.z, m[1] * v.x + m[5] * v.y + m[9] * v.z, m[2] * v.x + m[6] * v.y + m[10] * v.z);
-}
-inline V3 mulNormal(const float* mi, V3 n) {  // Transform.h:47-52 (rows of the inverse)
-    return V3(mi[0] * n.x + mi[1] * n.y + mi[2] * n.z, mi[4] * n.x + mi[5] * n.y + mi[6] * n.z, mi[8] * n.x + mi[9] * n.y + mi[10] * n.z);
-}
-
 // ------------------------------------------------------------------------------------------
 // Scene light selection (Core/SurfaceObject.cpp:279-299, 432-466)
 // ------------------------------------------------------------------------------------------
@@ -2237,13 +2339,34 @@ slr_oracle_scene* slr_oracle_create(const slrhip_scene_desc* d, int mode) {
         if (!ok) { delete s; return nullptr; }
     }
     s->tris.resize(d->num_triangles);
+    // instances (slrhip_instance): ranges inside the triangle array, pairwise equal or disjoint; an instanced triangle is not an
+    // object of the top-level aggregate, so it is not in its light list either — and must not emit (include/slrhip.h)
+    std::vector<char> instanced(d->num_triangles, 0);
+    if (d->instances && d->num_instances) {
+        s->instances.assign(d->instances, d->instances + d->num_instances);
+        for (size_t a = 0; a < s->instances.size(); ++a) {
+            const slrhip_instance& ia = s->instances[a];
+            bool ok = ia.num_triangles > 0 && (uint64_t)ia.first_triangle + ia.num_triangles <= d->num_triangles;
+            for (size_t b = 0; b < a && ok; ++b) {
+                const slrhip_instance& ib = s->instances[b];
+                const bool same = ia.first_triangle == ib.first_triangle && ia.num_triangles == ib.num_triangles;
+                const bool disjoint = ia.first_triangle + ia.num_triangles <= ib.first_triangle || ib.first_triangle + ib.num_triangles <= ia.first_triangle;
+                ok = same || disjoint;
+            }
+            for (uint32_t t = 0; t < ia.num_triangles && ok; ++t) {
+                instanced[ia.first_triangle + t] = 1;
+                ok = s->materials[d->triangles[ia.first_triangle + t].material].emittance < 0;
+            }
+            if (!ok) { delete s; return nullptr; }
+        }
+    }
     std::vector<float> importances;
     for (uint32_t i = 0; i < d->num_triangles; ++i) {
         Tri& t = s->tris[i];
         for (int k = 0; k < 3; ++k) t.v[k] = d->triangles[i].v[k];
         t.material = d->triangles[i].material;
         t.lightIndex = -1;
-        if (s->materials[t.material].emittance >= 0) {     // SurfaceObject.cpp:232-249
+        if (!instanced[i] && s->materials[t.material].emittance >= 0) {     // SurfaceObject.cpp:232-249
             t.lightIndex = (int32_t)s->lightTris.size();
             s->lightTris.push_back(i);
             importances.push_back(1.0f);                   // SingleSurfaceObject::importance :69-71

@@ -30,6 +30,7 @@ spectrum_dtype = np.dtype([("kind", "<u4"), ("rgb", "<f4", 3), ("u", "<f4"), ("v
 
 texture_dtype = np.dtype([("kind", "<u4"), ("offset", "<f4", 2), ("scale", "<f4", 2), ("spectrum", "<i4", 2), ("value", "<f4", 2),
                           ("reserved", "<u4", 3)])
+instance_dtype = np.dtype([("first_triangle", "<u4"), ("num_triangles", "<u4"), ("local_to_world", "<f4", 16), ("world_to_local", "<f4", 16)])
 TEX_CHECKER_SPECTRUM, TEX_CHECKER_FLOAT, TEX_CHECKER_NORMAL, TEX_IMAGE_SPECTRUM = 0, 1, 2, 3
 
 
@@ -65,7 +66,8 @@ class SceneDesc(C.Structure):
                 ("env", C.POINTER(EnvMap)),
                 ("upsampling", C.POINTER(UpsamplingTables)),
                 ("textures", C.c_void_p), ("num_textures", C.c_uint32),
-                ("texture_texels", C.c_void_p), ("num_texture_texels", C.c_uint32)]
+                ("texture_texels", C.c_void_p), ("num_texture_texels", C.c_uint32),
+                ("instances", C.c_void_p), ("num_instances", C.c_uint32)]
 
 
 class RenderSettings(C.Structure):
@@ -103,7 +105,7 @@ class Scene:
     """Flat scene (numpy arrays) + the ctypes view handed across the ABI."""
 
     def __init__(self, vertices, triangles, materials, spectra, spectrum_data, camera, env=None, name="scene", textures=None,
-                 texture_texels=None, texture_texels_uvs=None):
+                 texture_texels=None, texture_texels_uvs=None, instances=None):
         self.vertices = np.ascontiguousarray(vertices, dtype=vertex_dtype)
         self.triangles = np.ascontiguousarray(triangles, dtype=triangle_dtype)
         mats = np.asarray(materials)
@@ -117,6 +119,7 @@ class Scene:
         self.spectrum_data = np.ascontiguousarray(spectrum_data, dtype=np.float32)
         self.camera = camera
         self.textures = np.ascontiguousarray(textures if textures is not None else np.zeros(0, texture_dtype), dtype=texture_dtype)
+        self.instances = np.ascontiguousarray(instances if instances is not None else np.zeros(0, instance_dtype), dtype=instance_dtype)
         # texels of the image textures (TEX_IMAGE_SPECTRUM): [n][3] as the RGB build stores them, and as (u, v, s) for the spectral build
         self.texture_texels = np.ascontiguousarray(texture_texels if texture_texels is not None else np.zeros((0, 3)), dtype=np.float32).reshape(-1, 3)
         self.texture_texels_uvs = np.ascontiguousarray(texture_texels_uvs if texture_texels_uvs is not None else np.zeros((0, 3)), dtype=np.float32).reshape(-1, 3)
@@ -185,6 +188,7 @@ class Scene:
         d.upsampling = C.pointer(self.upsampling_tables()) if ((env is not None or len(texels)) and mode == MODE_SPECTRAL) else None
         d.textures, d.num_textures = (self.textures.ctypes.data if len(self.textures) else None), len(self.textures)
         d.texture_texels, d.num_texture_texels = (texels.ctypes.data if len(texels) else None), len(texels)
+        d.instances, d.num_instances = (self.instances.ctypes.data if len(self.instances) else None), len(self.instances)
         return d
 
 

@@ -43,6 +43,13 @@ struct Builder {
     std::vector<uint32_t> prims;
     std::vector<BNode> nodes;
 
+    uint32_t firstAlone = 0xFFFFFFFFu;      // primitives from this index on (instances) are never packed with others in a leaf
+    bool hasAlone(uint32_t begin, uint32_t end) const {
+        if (firstAlone >= primBox.size()) return false;
+        for (uint32_t k = begin; k < end; ++k) if (prims[k] >= firstAlone) return true;
+        return false;
+    }
+
     explicit Builder(const std::vector<Box>& pb) : primBox(pb) {
         size_t n = pb.size();
         cen.resize(3 * n);
@@ -160,7 +167,7 @@ struct Builder {
             uint32_t mid;
             if (bestAxis >= 0) {
                 float leafCost = box.area() * n;
-                if (n <= maxLeaf && bestCost + leafBias * box.area() >= leafCost) { nodes[j.node] = nd; continue; }
+                if (n <= maxLeaf && bestCost + leafBias * box.area() >= leafCost && !hasAlone(j.begin, j.end)) { nodes[j.node] = nd; continue; }
                 float ext = cbox.hi[bestAxis] - cbox.lo[bestAxis];
                 float scale = kBins / ext;
                 float lo = cbox.lo[bestAxis];
@@ -172,7 +179,7 @@ struct Builder {
                 mid = (uint32_t)(it - prims.begin());
             }
             else {
-                if (n <= maxLeaf) { nodes[j.node] = nd; continue; }
+                if (n <= maxLeaf && !hasAlone(j.begin, j.end)) { nodes[j.node] = nd; continue; }
                 mid = j.begin + n / 2;        // identical centroids: split the list
             }
             if (mid == j.begin || mid == j.end) mid = j.begin + n / 2;
@@ -245,19 +252,37 @@ void quantizeNodes(QBVH* out) {
     for (std::thread& th : pool) th.join();
 }
 
+namespace {
+// The build over a list of primitives: triangles (triIds, or 0 .. numTriPrims - 1 when null) followed by instBoxes.size() instances,
+// each of which ends up alone in a leaf whose child reference is kLeafFlag | instance index (count 0, device_types.h).
+int buildQBVHPrims(const slrhip_vertex* verts, const slrhip_triangle* tris, const uint32_t* triIds, uint32_t numTriPrims, const std::vector<Box>& instBoxes,
+                   QBVH* out, bool spatialSplits, bool wide8);
+}
+
 int buildQBVH(const slrhip_vertex* verts, const slrhip_triangle* tris, uint32_t numTris, QBVH* out, bool spatialSplits, bool wide8) {
     if (!verts || !tris || numTris == 0 || numTris > kLeafIndexMask) return 1;
+    return buildQBVHPrims(verts, tris, nullptr, numTris, std::vector<Box>(), out, spatialSplits, wide8);
+}
+
+namespace {
+int buildQBVHPrims(const slrhip_vertex* verts, const slrhip_triangle* tris, const uint32_t* triIds, uint32_t numTriPrims, const std::vector<Box>& instBoxes,
+                   QBVH* out, bool spatialSplits, bool wide8) {
+    const uint32_t numTris = numTriPrims + (uint32_t)instBoxes.size();       // primitives
+    if (numTris == 0) return 1;
+    if (!instBoxes.empty() || triIds) { spatialSplits = false; wide8 = false; }
+    const auto triOf = [&](uint32_t prim) -> uint32_t { return triIds ? triIds[prim] : prim; };
     std::vector<Box> primBox(numTris);
-    for (uint32_t i = 0; i < numTris; ++i) {
+    for (uint32_t i = 0; i < numTriPrims; ++i) {
         primBox[i].reset();
-        for (int k = 0; k < 3; ++k) primBox[i].grow(verts[tris[i].v[k]].position);
+        for (int k = 0; k < 3; ++k) primBox[i].grow(verts[tris[triOf(i)].v[k]].position);
     }
+    for (size_t i = 0; i < instBoxes.size(); ++i) primBox[numTriPrims + i] = instBoxes[i];
     auto tA = std::chrono::steady_clock::now();
     // Binary tree: binned SAH over object partitions (default), or with spatial splits (sbvh.cpp; SLRHIP_BVH=sbvh, reference budget
     // SLRHIP_SBVH_BUDGET x the triangle count, default 1.3).  Both feed the same 4-wide collapse below.
     struct Binary { std::vector<BNode> nodes; std::vector<uint32_t> prims; } b;
     static const bool envSbvh = [] { const char* e = getenv("SLRHIP_BVH"); return e && std::string(e) == "sbvh"; }();
-    const bool useSbvh = spatialSplits || envSbvh;
+    const bool useSbvh = (spatialSplits || envSbvh) && instBoxes.empty() && !triIds;
     auto tB = tA;
     if (useSbvh) {
         const char* e = tuningEnv("SLRHIP_SBVH_BUDGET");
@@ -271,6 +296,7 @@ int buildQBVH(const slrhip_vertex* verts, const slrhip_triangle* tris, uint32_t 
     }
     else {
         Builder sah(primBox);
+        if (!instBoxes.empty()) sah.firstAlone = numTriPrims;
         tB = std::chrono::steady_clock::now();
         sah.build();
         b.nodes.swap(sah.nodes);
@@ -292,6 +318,7 @@ int buildQBVH(const slrhip_vertex* verts, const slrhip_triangle* tris, uint32_t 
     uint32_t leafCursor = 0;
     std::vector<uint32_t> leafRefOf(wide8 ? b.nodes.size() : 0, 0u);      // the leaf packet of every binary leaf, for the eight-wide tree
     auto leafRef = [&](const BNode& leaf) -> uint32_t {
+        if (leaf.count == 1 && b.prims[leaf.first] >= numTriPrims) return kLeafFlag | (b.prims[leaf.first] - numTriPrims);      // an instance
         uint32_t first = leafCursor;
         leafCursor += leaf.count;
         const uint32_t ref = kLeafFlag | (leaf.count << kLeafCountShift) | first;
@@ -374,10 +401,10 @@ int buildQBVH(const slrhip_vertex* verts, const slrhip_triangle* tris, uint32_t 
                 const BNode& cn = b.nodes[kidsOf[qi].b[c]];
                 qn.minx[c] = cn.box.lo[0]; qn.miny[c] = cn.box.lo[1]; qn.minz[c] = cn.box.lo[2];
                 qn.maxx[c] = cn.box.hi[0]; qn.maxy[c] = cn.box.hi[1]; qn.maxz[c] = cn.box.hi[2];
-                if (!(qn.child[c] & kLeafFlag)) continue;
+                if (!(qn.child[c] & kLeafFlag) || ((qn.child[c] >> kLeafCountShift) & 0xFu) == 0u) continue;
                 uint32_t first = qn.child[c] & kLeafIndexMask;
                 for (uint32_t k = 0; k < cn.count; ++k) {
-                    uint32_t t = b.prims[cn.first + k];
+                    uint32_t t = triOf(b.prims[cn.first + k]);
                     const float* p0 = verts[tris[t].v[0]].position;
                     const float* p1 = verts[tris[t].v[1]].position;
                     const float* p2 = verts[tris[t].v[2]].position;
@@ -474,6 +501,104 @@ int buildQBVH(const slrhip_vertex* verts, const slrhip_triangle* tris, uint32_t 
             q.sx = scl[0]; q.sy = scl[1]; q.sz = scl[2];
             out->nodes8.push_back(q);
         }
+    }
+    return 0;
+}
+} // namespace
+
+// Matrix4x4 x Point3D (Matrix4x4.h:75-81), column-major m
+static void mulPointHost(const float* m, const float* p, float* o) {
+    float x = m[0] * p[0] + m[4] * p[1] + m[8] * p[2] + m[12] * 1.0f;
+    float y = m[1] * p[0] + m[5] * p[1] + m[9] * p[2] + m[13] * 1.0f;
+    float z = m[2] * p[0] + m[6] * p[1] + m[10] * p[2] + m[14] * 1.0f;
+    float w = m[3] * p[0] + m[7] * p[1] + m[11] * p[2] + m[15] * 1.0f;
+    if (w != 1.0f) { float r = 1.0f / w; x *= r; y *= r; z *= r; }
+    o[0] = x; o[1] = y; o[2] = z;
+}
+
+int buildInstancedQBVH(const slrhip_vertex* verts, const slrhip_triangle* tris, uint32_t numTris, const slrhip_instance* instances, uint32_t numInstances,
+                       QBVH* out, std::vector<DevInstance>* devInstances, std::string* err) {
+    if (!verts || !tris || numTris == 0 || numTris > kLeafIndexMask || !instances || numInstances == 0 || numInstances > kLeafIndexMask) { *err = "bad arguments"; return 1; }
+    struct Mesh { uint32_t first, count, root, depth; Box box; };
+    std::vector<Mesh> meshes;
+    std::vector<uint32_t> meshOf(numInstances);
+    std::vector<char> instanced(numTris, 0);
+    std::vector<QBVH> trees;
+    for (uint32_t k = 0; k < numInstances; ++k) {
+        const slrhip_instance& in = instances[k];
+        if (in.num_triangles == 0 || (uint64_t)in.first_triangle + in.num_triangles > numTris) { *err = "instance names triangles out of range"; return 1; }
+        for (int r = 0; r < 2; ++r) {
+            const float* m = r ? in.world_to_local : in.local_to_world;
+            if (m[3] != 0.0f || m[7] != 0.0f || m[11] != 0.0f || m[15] != 1.0f) { *err = "instance transforms must be affine (bottom row 0 0 0 1)"; return 1; }
+            for (int i = 0; i < 16; ++i) if (!std::isfinite(m[i])) { *err = "instance transform is not finite"; return 1; }
+        }
+        uint32_t m = 0;
+        for (; m < meshes.size(); ++m) if (meshes[m].first == in.first_triangle && meshes[m].count == in.num_triangles) break;
+        if (m == meshes.size()) {
+            for (uint32_t t = 0; t < in.num_triangles; ++t) {
+                if (instanced[in.first_triangle + t]) { *err = "instanced triangle ranges must be equal or disjoint"; return 1; }
+                instanced[in.first_triangle + t] = 1;
+            }
+            Mesh mesh;
+            mesh.first = in.first_triangle; mesh.count = in.num_triangles; mesh.root = 0; mesh.depth = 0;
+            mesh.box.reset();
+            std::vector<uint32_t> ids(in.num_triangles);
+            for (uint32_t t = 0; t < in.num_triangles; ++t) {
+                ids[t] = in.first_triangle + t;
+                for (int v = 0; v < 3; ++v) mesh.box.grow(verts[tris[ids[t]].v[v]].position);
+            }
+            trees.emplace_back();
+            if (buildQBVHPrims(verts, tris, ids.data(), in.num_triangles, std::vector<Box>(), &trees.back(), false, false) != 0) { *err = "mesh tree build failed"; return 1; }
+            mesh.depth = trees.back().depth;
+            meshes.push_back(mesh);
+        }
+        meshOf[k] = m;
+    }
+    // bounds() of a TransformedSurfaceObject = StaticTransform x BoundingBox3D (Transform.h:54-65): the box of the eight transformed
+    // corners of the mesh's box; a hair of slack because the local-space traversal rounds differently from a world-space box test
+    std::vector<Box> instBoxes(numInstances);
+    for (uint32_t k = 0; k < numInstances; ++k) {
+        const Box& mb = meshes[meshOf[k]].box;
+        Box wb; wb.reset();
+        for (int c = 0; c < 8; ++c) {
+            const float p[3] = {(c & 4) ? mb.hi[0] : mb.lo[0], (c & 2) ? mb.hi[1] : mb.lo[1], (c & 1) ? mb.hi[2] : mb.lo[2]};
+            float q[3];
+            mulPointHost(instances[k].local_to_world, p, q);
+            wb.grow(q);
+        }
+        for (int a = 0; a < 3; ++a) {
+            const float pad = 1e-5f * std::fmax(1.0f, std::fmax(std::fabs(wb.lo[a]), std::fabs(wb.hi[a])));
+            wb.lo[a] -= pad; wb.hi[a] += pad;
+        }
+        instBoxes[k] = wb;
+    }
+    std::vector<uint32_t> loose;
+    for (uint32_t i = 0; i < numTris; ++i) if (!instanced[i]) loose.push_back(i);
+    if (buildQBVHPrims(verts, tris, loose.data(), (uint32_t)loose.size(), instBoxes, out, false, false) != 0) { *err = "top-level tree build failed"; return 1; }
+    // the mesh trees go behind the top-level tree in the same arrays; their inner child indices and leaf packets are rebased
+    uint32_t maxMeshDepth = 0;
+    for (size_t m = 0; m < meshes.size(); ++m) {
+        const uint32_t nodeBase = (uint32_t)out->nodes.size(), leafBase = (uint32_t)out->leafTris.size();
+        if ((uint64_t)leafBase + trees[m].leafTris.size() > kLeafIndexMask) { *err = "too many leaf entries"; return 1; }
+        meshes[m].root = nodeBase;
+        for (QNode qn : trees[m].nodes) {
+            for (int c = 0; c < 4; ++c) {
+                if (qn.child[c] == kInvalidChild) continue;
+                if (qn.child[c] & kLeafFlag) qn.child[c] = (qn.child[c] & ~kLeafIndexMask) | ((qn.child[c] & kLeafIndexMask) + leafBase);
+                else qn.child[c] += nodeBase;
+            }
+            out->nodes.push_back(qn);
+        }
+        out->leafTris.insert(out->leafTris.end(), trees[m].leafTris.begin(), trees[m].leafTris.end());
+        maxMeshDepth = std::max(maxMeshDepth, meshes[m].depth);
+    }
+    out->depth += maxMeshDepth + 1;        // stack entries: the top level's, kPopInstance, the mesh's (slrhip_upload_scene checks 3 x depth + 1 <= 64)
+    devInstances->resize(numInstances);
+    for (uint32_t k = 0; k < numInstances; ++k) {
+        DevInstance& di = (*devInstances)[k];
+        std::memcpy(di.localToWorld, instances[k].local_to_world, sizeof(di.localToWorld));
+        std::memcpy(di.worldToLocal, instances[k].world_to_local, sizeof(di.worldToLocal));
+        di.rootNode = meshes[meshOf[k]].root; di.firstTriangle = instances[k].first_triangle; di.numTriangles = instances[k].num_triangles; di.mesh = meshOf[k];
     }
     return 0;
 }

@@ -69,4 +69,10 @@ int buildGeometryDevice(const slrhip_vertex* verts, uint32_t numVerts, const slr
 // Returns 0 on success.
 int buildQBVH(const slrhip_vertex* verts, const slrhip_triangle* tris, uint32_t numTris, QBVH* out, bool spatialSplits = false, bool wide8 = false);
 
+// Scenes with instanced meshes (slrhip_instance): one tree per distinct mesh in its local space and a top-level tree over the loose
+// triangles and the instances' world boxes, all in ONE node array and ONE leaf array (the top level first); an instance is a child
+// reference of its own kind (device_types.h).  depth = the top level's + 1 + the deepest mesh's.
+int buildInstancedQBVH(const slrhip_vertex* verts, const slrhip_triangle* tris, uint32_t numTris, const slrhip_instance* instances, uint32_t numInstances,
+                       QBVH* out, std::vector<DevInstance>* devInstances, std::string* err);
+
 } // namespace slrhip

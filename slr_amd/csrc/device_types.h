@@ -34,6 +34,10 @@ static const uint32_t kLeafFlag = 0x80000000u;
 static const uint32_t kLeafCountShift = 27;
 static const uint32_t kLeafIndexMask = (1u << 27) - 1;
 static const uint32_t kMaxLeafTris = 4;
+// Instanced scenes (slrhip_instance): a child reference with the leaf flag and a COUNT OF ZERO names an instance (index in the low
+// bits) instead of a packet of triangles; the traversal marks the place on its stack where it has to leave the instance's local
+// space again with kPopInstance (leaf flag, count 15: no packet has that count).
+static const uint32_t kPopInstance = 0xFFFFFFFEu;
 
 struct alignas(16) QNode {
     float minx[4], miny[4], minz[4];
@@ -89,6 +93,16 @@ struct alignas(16) ShadeTri {
     float t2[3]; float gnz;              // gNormal = normalize(cross(e01, e02)) (TriangleMesh.cpp:171)
 };
 static_assert(sizeof(ShadeTri) == 96, "ShadeTri is six float4");
+
+// One slrhip_instance (TransformedSurfaceObject over a mesh's aggregate, Core/SurfaceObject.cpp:303-392), 144 B = nine float4:
+// both matrices column-major as the ABI gives them (float4 k = column k; the kernels require the bottom row 0 0 0 1, checked at
+// upload), then the root of the mesh's tree in the scene's node array.
+struct alignas(16) DevInstance {
+    float localToWorld[16];
+    float worldToLocal[16];
+    uint32_t rootNode, firstTriangle, numTriangles, mesh;
+};
+static_assert(sizeof(DevInstance) == 144, "DevInstance is nine float4");
 
 // One emitting triangle (a "light" of SurfaceObjectAggregate's light list, SurfaceObject.cpp:232-249):
 // what Triangle::sample needs (TriangleMesh.cpp:224-255).

@@ -33,6 +33,8 @@ struct DevScene {
     const float4* triUV;          // per scene triangle: (u0, v0, u1, v1), (u2, v2, -, -)
     const float4* alphaTris;      // per alpha record (LeafTri::alpha): the same two float4 + the alpha texture index
     const float* texTexels;       // texels of the image textures, 3 floats each: (r, g, b), spectral mode (u, v, s)
+    const float4* instances;      // DevInstance as 9 x float4, or nullptr: the scene has no instanced mesh
+    uint32_t numInstances;
     uint32_t numTextures;
     uint32_t numSpectra;
     uint32_t numSpectrumData;     // floats in spectrumPool (padded to a multiple of 4 on upload)
@@ -92,6 +94,7 @@ struct PathBuffers {
     float4* rayOrg;               // extension / shadow ray origin, w = distMin
     float4* rayDir;               // extension ray direction, w = distMax
     float4* hit;                  // x = triangle (bits), y = t, z = b1, w = b2 (Moller-Trumbore's barycentrics)
+    int32_t* hitInstance;         // instanced scenes only (else nullptr): the instance the hit went through, -1 = a loose triangle
     // spectrum-valued records: RGB = one float4 per slot (scalar in .w); spectral = 4 planes of numSlots float4
     float4* alpha;                // path throughput (+ pdf of the sampled direction)
     float4* spR;                  // path radiance Kahan sum (sp) (+ camera weight)

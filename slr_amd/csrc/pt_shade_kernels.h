@@ -468,6 +468,7 @@ __device__ __forceinline__ void logicSlot(const DevScene& sc, const PathBuffers&
     SpecIO<S>::load(pb.alpha, pb.pdfPrev, slot, rp.numSlots, alpha, bsdfPDFprev);
     sp.begin(pb, slot, rp.numSlots, flags, F_SHADOW(flags) && vis);
     const float4 h = pb.hit[slot];
+    const int32_t hitInstance = sc.instances ? pb.hitInstance[slot] : -1;      // instanced scenes: the TransformedSurfaceObject of the hit
     const float4 o4 = pb.rayOrg[(size_t)slot * pb.rayStride], d4 = pb.rayDir[(size_t)slot * pb.rayStride];
     const float wlOffset = S::N == 3 ? 0.0f : __uint_as_float(pb.hdr[(size_t)slot * pb.hdrStride].z);
 
@@ -531,8 +532,12 @@ __device__ __forceinline__ void logicSlot(const DevScene& sc, const PathBuffers&
             }
         }
         else {
-            // Triangle::getSurfacePoint, Surface/TriangleMesh.cpp:180-215.  isect.p = org + dir * t (:170)
-            surf.p = rayOrg + rayDir * h.y;
+            // Triangle::getSurfacePoint, Surface/TriangleMesh.cpp:180-215.  isect.p = org + dir * t (:170) — of the ray the triangle
+            // was tested with: inside an instance that is the LOCAL ray, invert(sampledTF) * ray (SurfaceObject.cpp:307-311), and the
+            // whole surface point is taken to world space at the end (TransformedSurfaceObject::getSurfacePoint, below)
+            const float* instMats = hitInstance >= 0 ? reinterpret_cast<const float*>(sc.instances + (size_t)hitInstance * 9u) : nullptr;
+            if (instMats) surf.p = mulPoint(instMats + 16, rayOrg) + mulVector(instMats + 16, rayDir) * h.y;
+            else surf.p = rayOrg + rayDir * h.y;
             surf.gNormal = V3(q3.w, q4.w, q5.w);
             surf.material = __float_as_uint(q0.w);
             surf.light = (int32_t)__float_as_uint(q1.w);
@@ -568,6 +573,15 @@ __device__ __forceinline__ void logicSlot(const DevScene& sc, const PathBuffers&
                     const V3 nn = normalize(surf.frame.fromLocal(nLocal));
                     surf.frame.x = tt; surf.frame.y = bb; surf.frame.z = nn;
                 }
+            }
+            if (instMats) {
+                // *surfPt = sampledTF * *surfPt (SurfaceObject.cpp:329-336; SurfacePoint x StaticTransform, geometry.cpp:63-78): p as a
+                // point, the geometric normal through the inverse transpose (Transform.h:47-52), the frame's axes as vectors, re-normalised
+                surf.p = mulPoint(instMats, surf.p);
+                surf.gNormal = normalize(mulNormal(instMats + 16, surf.gNormal));
+                surf.frame.x = normalize(mulVector(instMats, surf.frame.x));
+                surf.frame.y = normalize(mulVector(instMats, surf.frame.y));
+                surf.frame.z = normalize(mulVector(instMats, surf.frame.z));
             }
             haveSurf = true;
             dirOut_sn = surf.frame.toLocal(-rayDir);

@@ -18,6 +18,7 @@
 namespace slrhip {
 
 // Stand-alone closest-hit batch (parity tests of the traversal alone; not on the render path).
+template <bool INST>
 __global__ __launch_bounds__(kTraceBlock) void k_trace_batch(DevScene sc, const float4* org, const float4* dir, float4* out, uint32_t n) {
     __shared__ TraceLds lds;
     const uint32_t numTop = stageTopNodes(sc, lds);
@@ -25,7 +26,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace_batch(DevScene sc, const 
     for (uint32_t i = blockIdx.x * kTraceBlock + threadIdx.x; i < n; i += gridDim.x * kTraceBlock) {
         const float4 o = org[i], d = dir[i];
         HitRec hit;
-        const bool found = traverse<false, false>(sc, sc.nodes, sc.leafTris, lds.top, numTop, V3(o.x, o.y, o.z), V3(d.x, d.y, d.z), o.w, d.w,
+        const bool found = traverse<false, false, INST>(sc, sc.nodes, sc.leafTris, lds.top, numTop, V3(o.x, o.y, o.z), V3(d.x, d.y, d.z), o.w, d.w,
                                                   &hit, lds.stack + threadIdx.x, &cnt);
         out[i] = found ? make_float4(__uint_as_float(hit.tri), hit.t, hit.b1, hit.b2) : make_float4(__uint_as_float(0xFFFFFFFFu), INFINITY, 0.f, 0.f);
     }
@@ -34,7 +35,8 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace_batch(DevScene sc, const 
 void launchTraceBatch(const DevScene& sc, const float4* org, const float4* dir, float4* out, uint32_t n, hipStream_t stream) {
     uint32_t blocks = (n + kTraceBlock - 1) / kTraceBlock;
     if (blocks > 1536) blocks = 1536;
-    hipLaunchKernelGGL(k_trace_batch, dim3(blocks), dim3(kTraceBlock), 0, stream, sc, org, dir, out, n);
+    if (sc.instances) hipLaunchKernelGGL(k_trace_batch<true>, dim3(blocks), dim3(kTraceBlock), 0, stream, sc, org, dir, out, n);
+    else hipLaunchKernelGGL(k_trace_batch<false>, dim3(blocks), dim3(kTraceBlock), 0, stream, sc, org, dir, out, n);
 }
 
 } // namespace slrhip

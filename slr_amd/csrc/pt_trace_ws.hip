@@ -156,7 +156,12 @@ struct WsCounts {
     uint32_t nodes[2] = {0, 0}, tris[2] = {0, 0};   // [0] closest, [1] shadow
 };
 
-template <bool COUNT, int NC, bool QUANT, bool WIDE8>
+// INST: the scene has instanced meshes (DevScene::instances).  A child reference that names an instance (leaf flag, count 0) takes
+// the lane's ray to the mesh's local space — TransformedSurfaceObject::intersect, Core/SurfaceObject.cpp:307-317: origin as a point,
+// direction as a vector and NOT renormalised, so distances stay world distances and tmin / tmax carry over — pushes kPopInstance
+// and goes on at the root of the mesh's tree (same node and leaf arrays).  When kPopInstance comes off the stack the mesh is done:
+// the world ray is read again from the slot's record (two 16-byte loads; keeping it in registers would cost six VGPRs of the 64).
+template <bool COUNT, int NC, bool QUANT, bool WIDE8, bool INST>
 __device__ __forceinline__ void wsConsume(const DevScene& sc, const PathBuffers& pb, WsLds<NC>& lds, uint32_t refill, uint32_t numTop, WsCounts& cnt, WsDebug& dbg) {
     const uint64_t tStart = COUNT ? __builtin_readcyclecounter() : 0;
     constexpr uint32_t kRing = WsLds<NC>::kRing;
@@ -172,6 +177,13 @@ __device__ __forceinline__ void wsConsume(const DevScene& sc, const PathBuffers&
     int sp = 0;
     uint32_t hitTri = 0xFFFFFFFFu;
     float hitT = INFINITY, hitB1 = 0.0f, hitB2 = 0.0f;
+    int32_t inst = -1, hitInst = -1;           // INST: the instance the lane is inside / the one its closest hit went through
+    // a reference that is a packet of triangles (INST: not an instance reference, not kPopInstance)
+    const auto isTriLeaf = [](uint32_t ref) -> bool {
+        if (!INST) return (ref & kLeafFlag) != 0;
+        const uint32_t n = (ref >> kLeafCountShift) & 0xFu;
+        return (ref & kLeafFlag) != 0 && n != 0u && n != 15u;
+    };
 #ifdef SLR_WS_NOSPILL
     uint32_t* spill = nullptr;      // timing experiment only: no scratch, pushes beyond the LDS part are dropped
 #else
@@ -211,6 +223,7 @@ __device__ __forceinline__ void wsConsume(const DevScene& sc, const PathBuffers&
                     idx = 1.0f / dx; idy = 1.0f / dy; idz = 1.0f / dz;          // Vector3.h:60 reciprocal()
                     cur = 0; sp = 0;
                     hitTri = 0xFFFFFFFFu; hitT = INFINITY; hitB1 = 0.0f; hitB2 = 0.0f;
+                    inst = -1; hitInst = -1;
                 }
                 // Ring space is handed back IN RESERVATION ORDER: `released` is a watermark, the producer overwrites
                 // everything below it, so this wave may only move it past its own entries once every earlier
@@ -246,9 +259,53 @@ __device__ __forceinline__ void wsConsume(const DevScene& sc, const PathBuffers&
             dbg.activeLanes += (uint32_t)__popcll(act);
             if (__ballot(slot != kIdle && !(cur & kLeafFlag))) ++dbg.nodeBlocks;
         }
-        if (slot != kIdle) {
+        if (INST && slot != kIdle && (cur & kLeafFlag) != 0 && !isTriLeaf(cur)) {
+            // one step = entering or leaving an instance
             bool finished = false;
-            const bool leafAtTop = (cur & kLeafFlag) != 0;
+            if (cur == kPopInstance) {
+                const uint32_t s = slot & ~kShadowBit;
+                const float4 o = pb.rayOrg[(size_t)s * pb.rayStride];
+                const float4 d = (slot & kShadowBit) ? pb.shadowDir[s] : pb.rayDir[(size_t)s * pb.rayStride];
+                ox = o.x; oy = o.y; oz = o.z;
+                dx = d.x; dy = d.y; dz = d.z;
+                inst = -1;
+                if (sp == 0) finished = true;
+                else {
+                    --sp;
+                    if (kNoSpill || sp < kWsLdsStack) cur = stack[sp * 64];
+                    else cur = spill[sp - kWsLdsStack];
+                }
+            }
+            else {
+                const uint32_t k = cur & kLeafIndexMask;
+                const float4* rec = sc.instances + (size_t)k * 9u + 4u;              // DevInstance::worldToLocal, columns
+                const float4 c0 = rec[0], c1 = rec[1], c2 = rec[2], c3 = rec[3], meta = rec[4];
+                // invert(sampledTF) * ray: Matrix4x4 x Point3D (Matrix4x4.h:75-81; the bottom row is 0 0 0 1, so w == 1 and there is
+                // no division) and Matrix4x4 x Vector3D (:71-73)
+                const float lx = c0.x * ox + c1.x * oy + c2.x * oz + c3.x * 1.0f;
+                const float ly = c0.y * ox + c1.y * oy + c2.y * oz + c3.y * 1.0f;
+                const float lz = c0.z * ox + c1.z * oy + c2.z * oz + c3.z * 1.0f;
+                const float mx = c0.x * dx + c1.x * dy + c2.x * dz;
+                const float my = c0.y * dx + c1.y * dy + c2.y * dz;
+                const float mz = c0.z * dx + c1.z * dy + c2.z * dz;
+                ox = lx; oy = ly; oz = lz;
+                dx = mx; dy = my; dz = mz;
+                if (sp < kWsLdsStack) { stack[sp * 64] = kPopInstance; ++sp; }
+                else if (!kNoSpill && sp < kWsLdsStack + kWsSpill) { spill[sp - kWsLdsStack] = kPopInstance; ++sp; }
+                else atomicOr(pb.errorWord, ERR_STACK_OVERFLOW);
+                cur = __float_as_uint(meta.x);
+                inst = (int32_t)k;
+            }
+            idx = 1.0f / dx; idy = 1.0f / dy; idz = 1.0f / dz;          // Vector3.h:60 reciprocal()
+            if (finished) {
+                if (slot & kShadowBit) pb.visible[slot & ~kShadowBit] = hitTri == 0xFFFFFFFFu ? 1u : 0u;
+                else { pb.hit[slot] = make_float4(__uint_as_float(hitTri), hitT, hitB1, hitB2); pb.hitInstance[slot] = hitInst; }
+                slot = kIdle;
+            }
+        }
+        else if (slot != kIdle) {
+            bool finished = false;
+            const bool leafAtTop = isTriLeaf(cur);
             if (!leafAtTop) {
                 if (COUNT) { const bool sh = (slot & kShadowBit) != 0; cnt.nodes[0] += sh ? 0u : 1u; cnt.nodes[1] += sh ? 1u : 0u; }
                 if (WIDE8) {
@@ -420,9 +477,9 @@ __device__ __forceinline__ void wsConsume(const DevScene& sc, const PathBuffers&
                 }
             }
             // kChain: a lane whose node step ended on a leaf tests that leaf's first triangle in the same iteration
-            if (COUNT && __ballot(!finished && (kChain ? (cur & kLeafFlag) != 0 : leafAtTop)) && (threadIdx.x & 63u) == (uint32_t)__ffsll((long long)__ballot(true)) - 1u)
+            if (COUNT && __ballot(!finished && (kChain ? isTriLeaf(cur) : leafAtTop)) && (threadIdx.x & 63u) == (uint32_t)__ffsll((long long)__ballot(true)) - 1u)
                 ++dbg.triBlocks;      // counted by the first active lane; summed over lanes at the end
-            if (!finished && (kChain ? (cur & kLeafFlag) != 0 : leafAtTop)) {
+            if (!finished && (kChain ? isTriLeaf(cur) : leafAtTop)) {
                 // ONE triangle of the leaf packet per step; the reference tests them in order (QBVH.h:322-327)
                 const uint32_t first = cur & kLeafIndexMask;
                 const uint32_t count = (cur >> kLeafCountShift) & 0xF;
@@ -456,10 +513,12 @@ __device__ __forceinline__ void wsConsume(const DevScene& sc, const PathBuffers&
                         hitTri = triIdx;
                         finished = true;
                     }
-                    else if (!(tt == tmax && hitTri != 0xFFFFFFFFu && triIdx < hitTri)) {
-                        // equal distance: the larger scene index wins (tree-independent tie rule)
+                    else if (!(tt == tmax && hitTri != 0xFFFFFFFFu && (INST ? (inst < hitInst || (inst == hitInst && triIdx < hitTri)) : triIdx < hitTri))) {
+                        // equal distance: the larger scene index wins — the larger (instance, triangle) pair in instanced scenes
+                        // (tree-independent tie rule)
                         tmax = tt;                                  // ray.distMax = isect->dist (QBVH.h:335)
                         hitTri = triIdx;
+                        if (INST) hitInst = inst;
                         hitT = tt;
                         hitB1 = b1;                                 // Intersection::u = 1 - b1 - b2, ::v = b1 (TriangleMesh.cpp:159,172-173)
                         hitB2 = b2;
@@ -477,7 +536,10 @@ __device__ __forceinline__ void wsConsume(const DevScene& sc, const PathBuffers&
             }
             if (finished) {
                 if (slot & kShadowBit) pb.visible[slot & ~kShadowBit] = hitTri == 0xFFFFFFFFu ? 1u : 0u;      // testVisibility
-                else pb.hit[slot] = make_float4(__uint_as_float(hitTri), hitT, hitB1, hitB2);
+                else {
+                    pb.hit[slot] = make_float4(__uint_as_float(hitTri), hitT, hitB1, hitB2);
+                    if (INST) pb.hitInstance[slot] = hitInst;
+                }
                 slot = kIdle;
             }
         }
@@ -583,7 +645,7 @@ __device__ __forceinline__ void wsProduce(const PathBuffers& pb, LDS& lds, uint3
 //            iff its state is FIRST_HIT or NEXT_HIT (flag values 2 and 3, pt_shade_kernels.h).
 //   phase 2, shadow rays: Scene::testVisibility (SurfaceObject.cpp:418-430) = "no hit in [eps, d(1-eps)]"; workgroup b
 //            serves queue region b % kShards (gridDim is a multiple of kShards).
-template <bool COUNT, int NC, bool QUANT, bool WIDE8 = false>
+template <bool COUNT, int NC, bool QUANT, bool WIDE8 = false, bool INST = false>
 __global__ __launch_bounds__(64 * (NC + 1)) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_trace_ws(DevScene sc, PathBuffers pb, uint32_t numSlots, uint32_t shardCapacity, uint32_t parity, uint32_t refill,
                                                                                                               uint32_t tailSlots) {
     __shared__ WsLds<NC> lds;
@@ -605,7 +667,7 @@ __global__ __launch_bounds__(64 * (NC + 1)) __attribute__((amdgpu_waves_per_eu(8
     WsDebug dbg;
     if (threadIdx.x < 64) wsProduce(pb, lds, numSlots, shardCapacity, parity, extRays, shadowRays, dbg);
     else {
-        wsConsume<COUNT, NC, QUANT, WIDE8>(sc, pb, lds, refill, numTop, cnt, dbg);
+        wsConsume<COUNT, NC, QUANT, WIDE8, INST>(sc, pb, lds, refill, numTop, cnt, dbg);
     }
     wsBlockAdd(pb.totals, T_EXT_RAYS, extRays, lds.red);
     wsBlockAdd(pb.totals, T_SHADOW_RAYS, shadowRays, lds.red);
@@ -633,6 +695,8 @@ static void launchTraceWsT(const DevScene& sc, const PathBuffers& pb, const Rend
     // the eight-wide quantized tree (measurement, DESIGN.md: -2 % on the headline, +3..6 % slower elsewhere): instantiated in variant builds only
     if (sc.nodes8) { hipLaunchKernelGGL((k_trace_ws<COUNT, NC, false, true>), grid, block, 0, stream, sc, pb, rp.numSlots, rp.shardCapacity, parity, g_refill, rp.tailSlots); return; }
 #endif
+    // instanced scenes: float nodes only (slrhip_upload_scene does not quantize them)
+    if (sc.instances) { hipLaunchKernelGGL((k_trace_ws<COUNT, NC, false, false, true>), grid, block, 0, stream, sc, pb, rp.numSlots, rp.shardCapacity, parity, g_refill, rp.tailSlots); return; }
     if (sc.nodesQ) hipLaunchKernelGGL((k_trace_ws<COUNT, NC, true>), grid, block, 0, stream, sc, pb, rp.numSlots, rp.shardCapacity, parity, g_refill, rp.tailSlots);
     else hipLaunchKernelGGL((k_trace_ws<COUNT, NC, false>), grid, block, 0, stream, sc, pb, rp.numSlots, rp.shardCapacity, parity, g_refill, rp.tailSlots);
 }

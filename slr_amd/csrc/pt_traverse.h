@@ -20,21 +20,27 @@ static const int kTopStride = 9;       // float4 per staged node: 8 + 1 pad -> 1
 struct HitRec {
     uint32_t tri;
     float t, b1, b2;       // Moller-Trumbore's own barycentrics: b0 = 1 - b1 - b2 is re-derived where it is needed (pt_shade_kernels.h)
+    int32_t inst;          // INST: the instance the hit went through, -1 = a loose triangle
 };
 struct TravCount {
     uint32_t nodes, tris;
 };
 
-template <bool ANY_HIT, bool COUNT>
+// INST: scenes with instanced meshes (DevScene::instances; see wsConsume in pt_trace_ws.hip for the scheme).  Here the world ray
+// stays in registers while the lane is inside an instance.
+template <bool ANY_HIT, bool COUNT, bool INST = false>
 __device__ __forceinline__ bool traverse(const DevScene& sc, const float4* __restrict__ nodes4, const float4* __restrict__ tris4, const float4* topNodes,
                                          uint32_t numTop, V3 org, V3 dir, float tmin, float tmax, HitRec* hit,
                                          uint32_t* ldsStack /* [kLdsStack][blockDim], this lane's column */, TravCount* cnt,
                                          uint32_t* errorWord = nullptr) {
-    const float idx = 1.0f / dir.x, idy = 1.0f / dir.y, idz = 1.0f / dir.z;      // Vector3.h:60 reciprocal()
+    float idx = 1.0f / dir.x, idy = 1.0f / dir.y, idz = 1.0f / dir.z;      // Vector3.h:60 reciprocal()
     // float4 index inside a node: 0..2 = min xyz, 3..5 = max xyz, 6 = children
-    const int nx = idx > 0.0f ? 0 : 3, fx = 3 - nx;
-    const int ny = idy > 0.0f ? 1 : 4, fy = 5 - ny;
-    const int nz = idz > 0.0f ? 2 : 5, fz = 7 - nz;
+    int nx = idx > 0.0f ? 0 : 3, fx = 3 - nx;
+    int ny = idy > 0.0f ? 1 : 4, fy = 5 - ny;
+    int nz = idz > 0.0f ? 2 : 5, fz = 7 - nz;
+    const V3 worldOrg = org, worldDir = dir;
+    int32_t inst = -1;
+    hit->inst = -1;
 
     uint32_t spill[kSpillStack];
     int sp = 0;
@@ -43,6 +49,36 @@ __device__ __forceinline__ bool traverse(const DevScene& sc, const float4* __res
     hit->tri = 0xFFFFFFFFu; hit->t = INFINITY; hit->b1 = 0.0f; hit->b2 = 0.0f;
 
     for (;;) {
+        if (INST && (cur & kLeafFlag) && (((cur >> kLeafCountShift) & 0xFu) == 0u || cur == kPopInstance)) {
+            const bool leaving = cur == kPopInstance;
+            if (leaving) { org = worldOrg; dir = worldDir; inst = -1; }
+            else {
+                // TransformedSurfaceObject::intersect (Core/SurfaceObject.cpp:307-317): invert(sampledTF) * ray
+                const uint32_t k = cur & kLeafIndexMask;
+                const float4* rec = sc.instances + (size_t)k * 9u + 4u;
+                const float4 c0 = rec[0], c1 = rec[1], c2 = rec[2], c3 = rec[3], meta = rec[4];
+                org = V3(c0.x * worldOrg.x + c1.x * worldOrg.y + c2.x * worldOrg.z + c3.x * 1.0f,
+                         c0.y * worldOrg.x + c1.y * worldOrg.y + c2.y * worldOrg.z + c3.y * 1.0f,
+                         c0.z * worldOrg.x + c1.z * worldOrg.y + c2.z * worldOrg.z + c3.z * 1.0f);
+                dir = V3(c0.x * worldDir.x + c1.x * worldDir.y + c2.x * worldDir.z, c0.y * worldDir.x + c1.y * worldDir.y + c2.y * worldDir.z,
+                         c0.z * worldDir.x + c1.z * worldDir.y + c2.z * worldDir.z);
+                inst = (int32_t)k;
+                if (sp < kLdsStack) ldsStack[sp * kTraceBlock] = kPopInstance;
+                else if (sp < kLdsStack + kSpillStack) spill[sp - kLdsStack] = kPopInstance;
+                else { if (errorWord) atomicOr(errorWord, ERR_STACK_OVERFLOW); --sp; }
+                ++sp;
+                cur = __float_as_uint(meta.x);      // the root of the mesh's tree
+            }
+            idx = 1.0f / dir.x; idy = 1.0f / dir.y; idz = 1.0f / dir.z;
+            nx = idx > 0.0f ? 0 : 3; fx = 3 - nx;
+            ny = idy > 0.0f ? 1 : 4; fy = 5 - ny;
+            nz = idz > 0.0f ? 2 : 5; fz = 7 - nz;
+            if (!leaving) continue;
+            if (sp == 0) break;
+            --sp;
+            cur = sp < kLdsStack ? ldsStack[sp * kTraceBlock] : spill[sp - kLdsStack];
+            continue;
+        }
         if (cur & kLeafFlag) {
             const uint32_t first = cur & kLeafIndexMask;
             const uint32_t count = (cur >> kLeafCountShift) & 0xF;
@@ -69,10 +105,11 @@ __device__ __forceinline__ bool traverse(const DevScene& sc, const float4* __res
                 if (__float_as_uint(b.w) != kNoAlpha && !alphaPasses(sc.alphaTris, sc.textures, __float_as_uint(b.w), b1, b2)) continue;
                 if (ANY_HIT) return true;
                 // equal distance: the larger scene index wins (tree-independent tie rule)
-                if (tt == tmax && found && triIdx < hit->tri) continue;
+                if (tt == tmax && found && (INST ? (inst < hit->inst || (inst == hit->inst && triIdx < hit->tri)) : triIdx < hit->tri)) continue;
                 found = true;
                 tmax = tt;                                  // ray.distMax = isect->dist (QBVH.h:335)
                 hit->tri = triIdx;
+                hit->inst = inst;
                 hit->t = tt;
                 hit->b1 = b1;                               // Intersection::u = 1 - b1 - b2, ::v = b1 (TriangleMesh.cpp:159,172-173)
                 hit->b2 = b2;

@@ -124,6 +124,7 @@ struct slrhip_ctx {
     DevArray<LeafTri> leafTris;
     DevArray<ShadeTri> shadeTris;
     DevArray<LightTri> lightTris;
+    DevArray<DevInstance> instances;
     DevArray<DevMaterial> materials;
     DevArray<DevMaterialS> materialsS;
     DevArray<DevSpectrum> spectra;
@@ -147,6 +148,7 @@ struct slrhip_ctx {
     DevArray<float> pdfPrev;
     DevArray<uint4> hdr;
     DevArray<uint32_t> nextSample;
+    DevArray<int32_t> hitInstance;
     DevArray<uint32_t> flags, visible, shadowQueue, tailList, queueCount, activeSlots, blockDead;
     DevArray<uint64_t> totals;
     DevArray<float> resolveScratch;
@@ -469,9 +471,29 @@ int slrhip_upload_scene(slrhip_ctx* ctx, const slrhip_scene_desc* d) {
     // automatic: from 2^20 triangles on (host build of 10 M triangles: 2.9 s on 16 cores; device: 0.13 s, traversal 5 % slower)
     const bool wantDevice = envBuild == "device" || (ctx->config.flags & SLRHIP_FLAG_BVH_DEVICE_BUILD) != 0 ||
                             (envBuild != "host" && envBuild != "sbvh" && !(ctx->config.flags & SLRHIP_FLAG_BVH_SPATIAL_SPLITS) && d->num_triangles >= (1u << 20));
-    const bool deviceBuild = wantDevice && !anyAlpha && d->num_triangles >= 1024;
+    const uint32_t numInstances = d->instances ? d->num_instances : 0u;
+    const bool deviceBuild = wantDevice && !anyAlpha && d->num_triangles >= 1024 && numInstances == 0;
     QBVH bvh;
-    if (!deviceBuild) {
+    std::vector<DevInstance> devInstances;
+    if (numInstances) {
+        // instanced meshes (TransformedSurfaceObject, Core/SurfaceObject.cpp:303-392): two-level tree in one node array (bvh.h)
+        for (uint32_t k = 0; k < numInstances; ++k) {
+            const slrhip_instance& in = d->instances[k];
+            if (in.num_triangles == 0 || (uint64_t)in.first_triangle + in.num_triangles > d->num_triangles)
+                return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: instance names triangles out of range");
+            for (uint32_t t = 0; t < in.num_triangles; ++t)
+                if (emitting[d->triangles[in.first_triangle + t].material])
+                    return fail(SLRHIP_ERR_UNSUPPORTED, "slrhip_upload_scene: instanced triangles must not emit");
+        }
+        std::string err;
+        if (buildInstancedQBVH(d->vertices, d->triangles, d->num_triangles, d->instances, numInstances, &bvh, &devInstances, &err) != 0)
+            return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: " + err);
+        if (3 * bvh.depth + 1 > 64)
+            return fail(SLRHIP_ERR_UNSUPPORTED, "slrhip_upload_scene: two-level tree deeper than the 64-entry traversal stack (QBVH.h:299)");
+        if ((uint64_t)bvh.nodes.size() * sizeof(QNode) >= (1ull << 32) || (uint64_t)bvh.leafTris.size() * sizeof(LeafTri) >= (1ull << 32))
+            return fail(SLRHIP_ERR_UNSUPPORTED, "slrhip_upload_scene: node or leaf array beyond the 4 GiB the traversal kernels address with 32-bit offsets");
+    }
+    else if (!deviceBuild) {
         static const bool wide8 = [] { const char* e = tuningEnv("SLRHIP_WIDE8"); return e && std::string(e) == "1"; }();      // measurement: the eight-wide quantized tree
         if (buildQBVH(d->vertices, d->triangles, d->num_triangles, &bvh, (ctx->config.flags & SLRHIP_FLAG_BVH_SPATIAL_SPLITS) != 0, wide8) != 0)
             return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_upload_scene: BVH build failed");
@@ -609,7 +631,7 @@ int slrhip_upload_scene(slrhip_ctx* ctx, const slrhip_scene_desc* d) {
     }
     else {
         HIP_TRY(ctx->nodes.upload(bvh.nodes));
-        quant = (bvh.nodes.size() >= 65536 || forceQuant) && !noQuant;
+        quant = (bvh.nodes.size() >= 65536 || forceQuant) && !noQuant && numInstances == 0;      // instanced scenes traverse float nodes
         if (quant) { quantizeNodes(&bvh); HIP_TRY(ctx->nodesQ.upload(bvh.quantized)); }
         numNodes = (uint32_t)bvh.nodes.size(); treeDepth = bvh.depth; leafRefs = bvh.leafTris.size();
         useWide8 = !bvh.nodes8.empty() && 7 * bvh.depth8 + 1 <= 64;          // up to seven pushes per level on the 64-entry stack
@@ -653,6 +675,7 @@ int slrhip_upload_scene(slrhip_ctx* ctx, const slrhip_scene_desc* d) {
     HIP_TRY(ctx->alphaTris.upload(alphaTris));
     if (!deviceBuild) HIP_TRY(ctx->shadeTris.upload(shade));
     HIP_TRY(ctx->lightTris.upload(lights));
+    HIP_TRY(ctx->instances.upload(devInstances));
     HIP_TRY(ctx->materials.upload(mats));
     HIP_TRY(ctx->materialsS.upload(matsS));
     {
@@ -699,6 +722,8 @@ int slrhip_upload_scene(slrhip_ctx* ctx, const slrhip_scene_desc* d) {
     sc.lightCDF = ctx->lightCDF.ptr;
     sc.textures = ctx->textures.ptr; sc.matTex = ctx->matTex.ptr; sc.triUV = ctx->triUV.ptr; sc.alphaTris = ctx->alphaTris.ptr; sc.texTexels = ctx->texTexels.ptr;
     sc.numTextures = numTextures;
+    sc.instances = numInstances ? reinterpret_cast<const float4*>(ctx->instances.ptr) : nullptr;
+    sc.numInstances = numInstances;
     sc.numNodes = numNodes;
     sc.nodesQ = quant ? reinterpret_cast<const float4*>(ctx->nodesQ.ptr) : nullptr;
     sc.nodes8 = useWide8 ? reinterpret_cast<const float4*>(ctx->nodes8.ptr) : nullptr;
@@ -806,6 +831,7 @@ int slrhip_render_begin(slrhip_ctx* ctx, const slrhip_render_settings* st, slrhi
     HIP_TRY(ctx->hdr.alloc(numSlots * hdrStride, true)); HIP_TRY(ctx->rng.alloc(hdrStride == 2 ? 1 : numSlots, true));
     HIP_TRY(ctx->nextSample.alloc((size_t)numPixels + 1, true));
     HIP_TRY(ctx->flags.alloc(numSlots, true)); HIP_TRY(ctx->visible.alloc(numSlots, true));
+    if (ctx->scene.instances) HIP_TRY(ctx->hitInstance.alloc(numSlots, true));
     // queue regions: slot block b appends to region b % kShards, so a region holds at most ceil(numBlocks / kShards) blocks
     const uint32_t numBlocks = (uint32_t)((numSlots + 255) / 256);
     const uint32_t shardCapacity = ((numBlocks + kShards - 1) / kShards) * 256;
@@ -829,6 +855,7 @@ int slrhip_render_begin(slrhip_ctx* ctx, const slrhip_render_settings* st, slrhi
     pb.alpha = ctx->alpha.ptr; pb.spR = ctx->spR.ptr; pb.spC = spStride == 2 ? ctx->spR.ptr + 1 : ctx->spC.ptr; pb.accR = ctx->accR.ptr; pb.accC = ctx->accR.ptr + 1;
     pb.nee = ctx->nee.ptr;
     pb.pdfPrev = spectral ? ctx->pdfPrev.ptr : nullptr; pb.hdr = ctx->hdr.ptr; pb.nextSample = ctx->nextSample.ptr; pb.shadowDir = ctx->shadowDir.ptr; pb.flags = ctx->flags.ptr;
+    pb.hitInstance = ctx->scene.instances ? ctx->hitInstance.ptr : nullptr;
     pb.visible = ctx->visible.ptr; pb.shadowQueue = ctx->shadowQueue.ptr; pb.tailList = ctx->tailList.ptr;
     pb.queueCount = ctx->queueCount.ptr; pb.activeSlots = ctx->activeSlots.ptr; pb.errorWord = ctx->activeSlots.ptr + 1; pb.tailMode = ctx->activeSlots.ptr + 3; pb.tailWords = ctx->activeSlots.ptr + 4; pb.blockDead = ctx->blockDead.ptr; pb.totals = ctx->totals.ptr;
     pb.pixelXY = ctx->pixelXY.ptr;

@@ -58,6 +58,7 @@ class SceneBuilder:
         self.sset = spectra.SpectrumSet()     # every constant carries its RGB value and its spectral descriptor
         self.textures = []
         self.texture_texels, self.texture_texels_uvs = [], []
+        self.instances = []
 
     # --- spectra (the scene language's Spectrum(...) overloads, libSLRSceneGraph/API.cpp:286-441) -------
     def spectrum_rgb(self, r, g, b, uvs=None):
@@ -102,6 +103,22 @@ class SceneBuilder:
     def checker_normal(self, step_width, reverse=False, offset=(0.0, 0.0), scale=(1.0, 1.0)):
         """CheckerBoardNormal3DTexture (texture index: use as normal_map=)."""
         return self._texture(abi.TEX_CHECKER_NORMAL, offset, scale, value=(step_width, 1.0 if reverse else 0.0))
+
+    # --- instancing (TransformedSurfaceObject, Core/SurfaceObject.cpp:303-392) -----------------------------------------
+    def num_triangles(self):
+        return sum(len(t) for t in self.triangles)
+
+    def add_instance(self, first_triangle, num_triangles, transform):
+        """Places the mesh = triangles [first, first + num) (given in the mesh's local space) with a 4x4 local-to-world matrix;
+        the inverse is computed here in double and rounded (the reference's StaticTransform(mat) inverts in float: both
+        matrices are scene inputs, the same on every side)."""
+        m = np.asarray(transform, dtype=np.float64)
+        rec = np.zeros((), dtype=abi.instance_dtype)
+        rec["first_triangle"], rec["num_triangles"] = first_triangle, num_triangles
+        rec["local_to_world"] = m.T.astype(np.float32).reshape(16)              # column-major
+        rec["world_to_local"] = np.linalg.inv(m).T.astype(np.float32).reshape(16)
+        self.instances.append(rec)
+        return len(self.instances) - 1
 
     def image_spectrum(self, texels_rgb, texels_uvs, offset=(0.0, 0.0), scale=(1.0, 1.0)):
         """ImageSpectrumTexture (Textures/image_textures.cpp:13-79) over an OffsetAndScale2DMapping: nearest texel, wrap by fmod.
@@ -235,7 +252,8 @@ class SceneBuilder:
                          np.array(self.sset.data, dtype=np.float32), camera, env, name,
                          textures=np.array(self.textures, dtype=abi.texture_dtype) if self.textures else None,
                          texture_texels=np.concatenate(self.texture_texels) if self.texture_texels else None,
-                         texture_texels_uvs=np.concatenate(self.texture_texels_uvs) if self.texture_texels_uvs else None)
+                         texture_texels_uvs=np.concatenate(self.texture_texels_uvs) if self.texture_texels_uvs else None,
+                         instances=np.array(self.instances, dtype=abi.instance_dtype) if self.instances else None)
 
 
 # RGB-mode constants of the scene's named spectra.  In the reference these come from
@@ -313,6 +331,35 @@ def cornell_textured(aspect=1.0, segments=16, rings=8):
     lattice = b.with_maps(b.matte(b.spectrum_srgb_nonlinear(0.3, 0.5, 0.8)), alpha_map=b.checker_float(1.0, 0.0, (0.0, 0.0), (3.0, 3.0)))
     b.add_quad([(-1.0, 0.2, -1.9), (1.0, 0.2, -1.9), (1.0, 1.8, -1.9), (-1.0, 1.8, -1.9)], (0, 0, 1), (1, 0, 0), lattice)
     return b.build(cornell_camera(aspect), name="cornell_textured")
+
+
+def cornell_instanced(aspect=1.0, segments=10, rings=5, copies=6):
+    """Instanced geometry (TransformedSurfaceObject over a mesh aggregate, SurfaceObject.cpp:303-392): ONE unit UV sphere mesh and
+    ONE small box mesh in their local spaces, placed several times in the Cornell box with rotations, NON-UNIFORM scales and
+    translations (so that the inverse-transpose of the normals and the un-normalised local ray direction are on the path), next to
+    the loose wall triangles and the area light.  Materials: matte, mirror (delta lobe through the instance transform)."""
+    b = SceneBuilder()
+    cornell_walls(b)
+    mirror = b.metal(b.spectrum_grey(0.9), b.spectrum_ior("Aluminium", 0, ALUMINIUM_ETA_RGB), b.spectrum_ior("Aluminium", 1, ALUMINIUM_K_RGB))
+    orange = b.matte(b.spectrum_srgb_nonlinear(0.8, 0.45, 0.15), sigma=0.3)
+    first_s = b.num_triangles()
+    b.add_uv_sphere(segments, rings, orange, np.eye(4))
+    n_s = b.num_triangles() - first_s
+    first_b = b.num_triangles()
+    b.add_box(mirror, _scale(0.5))
+    n_b = b.num_triangles() - first_b
+    r = np.random.default_rng(11)
+    for i in range(copies):
+        ang = float(r.uniform(0, 2 * np.pi))
+        c, s_ = np.cos(ang), np.sin(ang)
+        rot = np.array([[c, 0, s_, 0], [0, 1, 0, 0], [-s_, 0, c, 0], [0, 0, 0, 1]])
+        sc = np.diag([float(r.uniform(0.2, 0.45)), float(r.uniform(0.2, 0.5)), float(r.uniform(0.2, 0.45)), 1.0])
+        pos = _translate(float(r.uniform(-1.0, 1.0)), float(r.uniform(0.35, 1.6)), float(r.uniform(-1.8, 0.8)))
+        if i % 3 == 2:
+            b.add_instance(first_b, n_b, pos @ rot @ sc)
+        else:
+            b.add_instance(first_s, n_s, pos @ rot @ sc)
+    return b.build(cornell_camera(aspect), name="cornell_instanced")
 
 
 def synthetic_image(width, height, seed):
@@ -720,6 +767,47 @@ def hash_noise_heightfield(n, seed=20240611, octaves=6, base_cells=4):
         v01, v11 = _hash_lattice(ix0, iz0 + 1, seed + k), _hash_lattice(ix0 + 1, iz0 + 1, seed + k)
         height += ((v00 * (1 - wx) + v10 * wx) * (1 - wz) + (v01 * (1 - wx) + v11 * wx) * wz) * 0.5 ** k
     return height / (2.0 - 0.5 ** (octaves - 1))
+
+
+def instanced_grid(tiles_x=25, tiles_z=50, cells=64, aspect=16.0 / 9.0, seed=20240611, extent=4.0, relief=0.9):
+    """Config 5 of BASELINE.json as it is WRITTEN — an instanced mesh: ONE patch of 2 cells^2 triangles (64 -> 8 192; a seeded
+    hash-noise heightfield over [-1, 1]^2 in the patch's local space) placed tiles_x x tiles_z times (25 x 50 = 1 250 placements,
+    10.24 M triangles seen by the rays) side by side over the extent of displaced_grid, each through its own StaticTransform:
+    non-uniform scale (the tile is twice as long in x as in z, and every tile has its own relief), a half turn about y for every
+    other tile, a translation.  Same material, light and thin-lens camera as displaced_grid."""
+    n = cells
+    h = hash_noise_heightfield(n, seed)
+    t = np.linspace(-1.0, 1.0, n + 1)
+    x, z = np.meshgrid(t, t, indexing="xy")
+    step = 2.0 / n
+    dhdx = np.gradient(h, step, axis=1)
+    dhdz = np.gradient(h, step, axis=0)
+    nrm = np.stack([-dhdx, np.ones_like(h), -dhdz], axis=-1)
+    nrm /= np.linalg.norm(nrm, axis=-1, keepdims=True)
+    tan = np.stack([np.ones_like(h), dhdx, np.zeros_like(h)], axis=-1)
+    tan /= np.linalg.norm(tan, axis=-1, keepdims=True)
+    pos = np.stack([x, h, z], axis=-1).reshape(-1, 3)
+    uv = np.stack([(x + 1.0) / 2.0, (z + 1.0) / 2.0], axis=-1).reshape(-1, 2)
+    idx = (np.arange(n)[:, None] * (n + 1) + np.arange(n)[None, :]).reshape(-1)
+    a, b_, c, d = idx, idx + 1, idx + n + 2, idx + n + 1
+    faces = np.concatenate([np.stack([a, d, c], axis=1), np.stack([a, c, b_], axis=1)], axis=1).reshape(-1, 3)
+    b = SceneBuilder()
+    lm = b.matte(b.spectrum_grey(0.8), emittance=b.spectrum_d65(1.0, D65_RGB))
+    b.add_quad([(-1.0, 3.0, -1.0), (1.0, 3.0, -1.0), (1.0, 3.0, 1.0), (-1.0, 3.0, 1.0)], (0, -1, 0), (1, 0, 0), lm)
+    ground = b.matte(b.spectrum_srgb_nonlinear(0.72, 0.64, 0.5))
+    first = b.num_triangles()
+    b.add_mesh(pos, nrm.reshape(-1, 3), tan.reshape(-1, 3), uv, faces, ground)
+    count = b.num_triangles() - first
+    r = np.random.default_rng(seed)
+    sx, sz = extent / tiles_x, extent / tiles_z
+    for iz in range(tiles_z):
+        for ix in range(tiles_x):
+            turn = np.eye(4) if (ix + iz) % 2 == 0 else np.diag([-1.0, 1.0, -1.0, 1.0])        # half turn about y
+            scale = np.diag([sx, relief * float(r.uniform(0.05, 0.25)), sz, 1.0])
+            place = _translate(-extent + (2 * ix + 1) * sx, 0.0, -extent + (2 * iz + 1) * sz)
+            b.add_instance(first, count, place @ turn @ scale)
+    cam = make_camera(_translate(0.0, 2.4, 5.2) @ _rotate(3.1415926536, (0, 1, 0)) @ _rotate(0.42, (1, 0, 0)), aspect, 0.6, 0.025, 1.0, 5.4)
+    return b.build(cam, name="instanced_grid_%dx%d" % (tiles_x * tiles_z, count))
 
 
 def displaced_grid(n=2236, aspect=16.0 / 9.0, seed=20240611, extent=4.0, relief=0.9):

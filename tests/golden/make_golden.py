@@ -33,6 +33,8 @@ def scene_arrays(sc):
         env["textures"] = sc.textures
     if len(sc.texture_texels):
         env["texture_texels"], env["texture_texels_uvs"] = sc.texture_texels, sc.texture_texels_uvs
+    if len(sc.instances):
+        env["instances"] = sc.instances
     return dict(env, vertices=sc.vertices, triangles=sc.triangles, materials=sc.materials, spectra=sc.spectra,
                 spectrum_data=sc.spectrum_data,
                 camera=np.array(list(cam.local_to_world) + list(cam.world_to_local) +
@@ -298,6 +300,11 @@ def main_round3(only):
         make("rgb_image_textured", scenes.cornell_image_textured(1.0, 12, 6), lib, 48, 48, 8, 2)
     if not only or "spectral_image_textured" in only:
         make("spectral_image_textured", scenes.cornell_image_textured(1.0, 10, 5), spec, 40, 40, 8, 2)
+    # instanced meshes: TransformedSurfaceObjects over mesh aggregates (Core/SurfaceObject.cpp:303-392), the reference's own classes
+    if not only or "rgb_instanced" in only:
+        make("rgb_instanced", scenes.cornell_instanced(1.0, 12, 6), lib, 48, 48, 8, 2)
+    if not only or "spectral_instanced" in only:
+        make("spectral_instanced", scenes.cornell_instanced(1.0, 10, 5), spec, 40, 40, 8, 2)
 
 
 if __name__ == "__main__":

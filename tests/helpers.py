@@ -38,8 +38,9 @@ def scene_from_golden(g, name="golden", prefix=""):
     textures = g["textures"] if "textures" in g.files else None
     texels = g["texture_texels"] if "texture_texels" in g.files else None
     texels_uvs = g["texture_texels_uvs"] if "texture_texels_uvs" in g.files else None
+    instances = g["instances"] if "instances" in g.files else None
     return abi.Scene(g["vertices"], g["triangles"], g["materials"], g["spectra"], g["spectrum_data"], cam, env, name, textures=textures,
-                     texture_texels=texels, texture_texels_uvs=texels_uvs)
+                     texture_texels=texels, texture_texels_uvs=texels_uvs, instances=instances)
 
 
 def bits(a):

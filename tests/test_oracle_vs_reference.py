@@ -47,6 +47,31 @@ def test_random_rays_bit_exact(oracle_rgb, ref_rgb):
     assert_bit_equal(ho["dist"], hr["dist"], "dist")
 
 
+@pytest.mark.parametrize("mode", ["rgb", "spectral"])
+def test_instanced_scene_bit_exact(request, mode):
+    """TransformedSurfaceObject over mesh aggregates (Core/SurfaceObject.cpp:303-392) against the oracle's restatement on a fresh
+    scene: more placements than the fixture, frames and random rays."""
+    sc = scenes.cornell_instanced(4.0 / 3.0, 14, 7, copies=11)
+    so, sr = request.getfixturevalue("oracle_" + mode).scene(sc), request.getfixturevalue("ref_" + mode).scene(sc)
+    st = ob.settings(64, 48, seed=77)
+    fo, _ = so.render(st, 8)
+    fr, _ = sr.render(st, 8)
+    assert_bit_equal(fo, fr, "instanced " + mode)
+    rng = np.random.default_rng(5)
+    n = 8192
+    rays = np.zeros(n, dtype=ob.ray_dtype)
+    rays["org"] = rng.uniform([-1.4, 0.1, -2.4], [1.4, 2.4, 2.4], size=(n, 3))
+    d = rng.normal(size=(n, 3))
+    rays["dir"] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    rays["dist_min"], rays["dist_max"] = 1e-4, np.inf
+    ho, hr = so.trace(rays), sr.trace(rays)
+    same = ho["triangle"] == hr["triangle"]
+    tie = ~same & (ho["dist"] == hr["dist"])
+    assert (same | tie).all() and tie.sum() <= n // 500
+    assert_bit_equal(ho["dist"], hr["dist"], "dist")
+    assert (ho["triangle"][ho["triangle"] != 0xFFFFFFFF] >= int(sc.instances["first_triangle"].min())).mean() > 0.05
+
+
 @pytest.mark.parametrize("kind", ["oren_nayar", "ggx_metal", "ggx_glass"])
 def test_lobes_bit_exact(oracle_rgb, ref_rgb, kind):
     sc = scenes.cornell_lobes(kind, segments=24, rings=12)
