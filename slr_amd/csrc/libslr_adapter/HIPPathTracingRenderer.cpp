@@ -47,6 +47,8 @@ slrhip_scene_desc FlatScene::desc() const {
     d.upsampling = gridCells.empty() ? nullptr : &tables;
     d.textures = textures.empty() ? nullptr : textures.data();
     d.num_textures = (uint32_t)textures.size();
+    d.instances = instances.empty() ? nullptr : instances.data();
+    d.num_instances = (uint32_t)instances.size();
     return d;
 }
 
@@ -311,22 +313,71 @@ bool flattenScene(const Scene &scene, FlatScene* out, std::string* error, slrhip
     if (scene.m_envSphere) return f.fail("environment sphere: its image texture (Core/Image.h, OpenEXR half) is outside this build");
     const SurfaceObjectAggregate* agg = scene.m_aggregate;
     if (!agg) return f.fail("scene has no aggregate");
-    const std::vector<const SurfaceObject*>* list = nullptr;
-    if (const SBVH* a = dynamic_cast<const SBVH*>(agg->m_accelerator)) list = &a->m_objLists;
-    else if (const QBVH* a = dynamic_cast<const QBVH*>(agg->m_accelerator)) list = &a->m_objLists;
-    else if (const StandardBVH* a = dynamic_cast<const StandardBVH*>(agg->m_accelerator)) list = &a->m_objLists;
-    else return f.fail("unknown accelerator");
+    const auto objectList = [](const SurfaceObjectAggregate* a) -> const std::vector<const SurfaceObject*>* {
+        if (const SBVH* b = dynamic_cast<const SBVH*>(a->m_accelerator)) return &b->m_objLists;
+        if (const QBVH* b = dynamic_cast<const QBVH*>(a->m_accelerator)) return &b->m_objLists;
+        if (const StandardBVH* b = dynamic_cast<const StandardBVH*>(a->m_accelerator)) return &b->m_objLists;
+        return nullptr;
+    };
+    const auto bySurface = [](const SingleSurfaceObject* a, const SingleSurfaceObject* b) { return a->m_surface < b->m_surface; };
+    const std::vector<const SurfaceObject*>* list = objectList(agg);
+    if (!list) return f.fail("unknown accelerator");
 
-    // the distinct objects (spatial splits reference an object from several leaves), ordered by the address of their Surface
+    // the distinct objects (spatial splits reference an object from several leaves), ordered by the address of their Surface.
+    // A TransformedSurfaceObject over an aggregate of triangles with a StaticTransform (an instanced TriangleMeshNode,
+    // Core/SurfaceObject.cpp:303-392) becomes a slrhip_instance: the mesh's triangles follow the loose ones as one range per
+    // distinct aggregate, in their local space.
     std::vector<const SingleSurfaceObject*> objs;
+    std::vector<const TransformedSurfaceObject*> placements;
     for (const SurfaceObject* o : *list) {
+        if (const TransformedSurfaceObject* t = dynamic_cast<const TransformedSurfaceObject*>(o)) { placements.push_back(t); continue; }
         const SingleSurfaceObject* s = dynamic_cast<const SingleSurfaceObject*>(o);
         if (!s || dynamic_cast<const InfiniteSphereSurfaceObject*>(o))
-            return f.fail("only SingleSurfaceObjects over Triangles are on the hot path (no instancing or nested aggregates)");
+            return f.fail("only SingleSurfaceObjects over Triangles and TransformedSurfaceObjects over aggregates of them are on the hot path");
         objs.push_back(s);
     }
-    std::sort(objs.begin(), objs.end(), [](const SingleSurfaceObject* a, const SingleSurfaceObject* b) { return a->m_surface < b->m_surface; });
+    std::sort(objs.begin(), objs.end(), bySurface);
     objs.erase(std::unique(objs.begin(), objs.end()), objs.end());
+    const size_t numLoose = objs.size();
+    std::sort(placements.begin(), placements.end());
+    placements.erase(std::unique(placements.begin(), placements.end()), placements.end());
+    // distinct meshes, ordered like the loose triangles: by the address of their first Triangle
+    std::map<const SurfaceObject*, std::vector<const SingleSurfaceObject*>> meshObjs;
+    for (const TransformedSurfaceObject* t : placements) {
+        const SurfaceObjectAggregate* mesh = dynamic_cast<const SurfaceObjectAggregate*>(t->m_surfObj);
+        const StaticTransform* tf = dynamic_cast<const StaticTransform*>(t->m_transform);
+        if (!mesh || !tf) return f.fail("an instance must be a StaticTransform over an aggregate of triangles (no animated or chained transforms)");
+        if (mesh->isEmitting()) return f.fail("instanced triangles must not emit");
+        if (meshObjs.count(mesh)) continue;
+        const std::vector<const SurfaceObject*>* inner = objectList(mesh);
+        if (!inner) return f.fail("unknown accelerator inside an instance");
+        std::vector<const SingleSurfaceObject*> &mobjs = meshObjs[mesh];
+        for (const SurfaceObject* o : *inner) {
+            const SingleSurfaceObject* s = dynamic_cast<const SingleSurfaceObject*>(o);
+            if (!s || dynamic_cast<const InfiniteSphereSurfaceObject*>(o)) return f.fail("an instanced aggregate may hold only SingleSurfaceObjects over Triangles (one level of instancing)");
+            mobjs.push_back(s);
+        }
+        std::sort(mobjs.begin(), mobjs.end(), bySurface);
+        mobjs.erase(std::unique(mobjs.begin(), mobjs.end()), mobjs.end());
+        if (mobjs.empty()) return f.fail("empty instanced aggregate");
+    }
+    std::vector<const SurfaceObject*> meshOrder;
+    for (const auto &kv : meshObjs) meshOrder.push_back(kv.first);
+    std::sort(meshOrder.begin(), meshOrder.end(), [&](const SurfaceObject* a, const SurfaceObject* b) { return meshObjs[a].front()->m_surface < meshObjs[b].front()->m_surface; });
+    std::map<const SurfaceObject*, std::pair<uint32_t, uint32_t>> meshRange;
+    for (const SurfaceObject* mesh : meshOrder) {
+        meshRange[mesh] = std::make_pair((uint32_t)objs.size(), (uint32_t)meshObjs[mesh].size());
+        objs.insert(objs.end(), meshObjs[mesh].begin(), meshObjs[mesh].end());
+    }
+    out->instances.clear();
+    for (const TransformedSurfaceObject* t : placements) {
+        const StaticTransform* tf = static_cast<const StaticTransform*>(t->m_transform);
+        slrhip_instance in;
+        in.first_triangle = meshRange[t->m_surfObj].first; in.num_triangles = meshRange[t->m_surfObj].second;
+        std::memcpy(in.local_to_world, &tf->mat, sizeof(float) * 16);          // Matrix4x4: four column vectors, m[c * 4 + r]
+        std::memcpy(in.world_to_local, &tf->matInv, sizeof(float) * 16);
+        out->instances.push_back(in);
+    }
 
     // vertices: the distinct Vertex objects in address order (a mesh's vertices are one array: TriangleMeshNode.cpp:68-78)
     std::vector<const Vertex*> verts;
@@ -359,7 +410,7 @@ bool flattenScene(const Scene &scene, FlatScene* out, std::string* error, slrhip
     // out->triangles in the order of m_lightList (SurfaceObject.cpp:232-249)
     {
         size_t next = 0;
-        for (size_t i = 0; i < objs.size(); ++i) {
+        for (size_t i = 0; i < numLoose; ++i) {
             if (!objs[i]->isEmitting()) continue;
             if (agg->m_lightList[next] != objs[i]) return f.fail("light list order differs from the order of the Triangle objects in memory");
             ++next;

@@ -32,6 +32,7 @@ struct FlatScene {
     std::vector<slrhip_spectrum> spectra;
     std::vector<float> spectrumData;
     std::vector<slrhip_texture> textures;
+    std::vector<slrhip_instance> instances;
     slrhip_camera camera;
     // spectral build: libSLR's own Meng-15 tables (BasicTypes/Spectrum.h:197-575) in the layout of slrhip_upsampling_tables
     std::vector<uint8_t> gridCells;
@@ -44,7 +45,8 @@ struct FlatScene {
 // material / texture / spectrum objects behind them.  One slrhip_triangle per SingleSurfaceObject, in the order of the Triangle
 // objects in memory (= the order libSLRSceneGraph/TriangleMeshNode.cpp:80-112 created them in), which keeps the light list
 // (SurfaceObject.cpp:232-249) in the reference's order.  Returns false with a message for anything outside the hot path
-// (TransformedSurfaceObject, image textures, an environment sphere over an image texture, nested MultiBSDF materials).
+// (animated or nested instance transforms, image textures, an environment sphere over an image texture).  A TransformedSurfaceObject
+// with a StaticTransform over an aggregate of triangles becomes a slrhip_instance (its triangles form one range per distinct mesh).
 // Checkerboard spectrum textures in material slots, a BumpSingleSurfaceObject's checkerboard normal map and a Triangle's
 // checkerboard alpha texture become slrhip_texture records.  `resolve` = slrhip_resolve_upsampled of the HIP library (spectral build only; may be null in the RGB build).
 typedef int (*slrhip_resolve_upsampled_fn)(const slrhip_upsampling_tables*, float, float, uint32_t*, float*);

@@ -50,7 +50,7 @@ def _flatten(lib, ref_scene):
     out = dict(vertices=_array(d.vertices, d.num_vertices, abi.vertex_dtype), triangles=_array(d.triangles, d.num_triangles, abi.triangle_dtype),
                materials=_array(d.materials, d.num_materials, abi.material_dtype), spectra=_array(d.spectra, d.num_spectra, abi.spectrum_dtype),
                spectrum_data=_array(d.spectrum_data, d.num_spectrum_data, np.float32), camera=bytes(d.camera), has_tables=bool(d.upsampling),
-               textures=_array(d.textures, d.num_textures, abi.texture_dtype))
+               textures=_array(d.textures, d.num_textures, abi.texture_dtype), instances=_array(d.instances, d.num_instances, abi.instance_dtype))
     lib.lib.slr_ref_flat_free(h)
     return out
 
@@ -121,6 +121,7 @@ SCENES = {
     "cornell_multi": lambda: scenes.cornell_multi(1.0, 10, 5),
     "lobes_ward": lambda: scenes.cornell_lobes("ward", segments=8, rings=4),
     "textured": lambda: scenes.cornell_textured(1.0, 10, 5),          # checkerboard slots, BumpSingleSurfaceObject, alpha texture
+    "instanced": lambda: scenes.cornell_instanced(1.0, 8, 4),         # TransformedSurfaceObjects over two mesh aggregates
 }
 
 
@@ -147,6 +148,8 @@ def test_flatten_gives_back_the_scene_the_reference_objects_were_built_from(name
     for i, m in enumerate(got["materials"]):
         if int(m["type"]) == abi.MAT_MULTI:
             assert 0 <= m["spectrum"][0] < i and 0 <= m["spectrum"][1] < i
+    # instances: the same placements of the same triangle ranges (their order is the order of the objects in memory)
+    assert sorted(r.tobytes() for r in got["instances"]) == sorted(r.tobytes() for r in sc.instances)
     cam = abi.Camera.from_buffer_copy(got["camera"])
     assert bytes(cam.local_to_world) == bytes(sc.camera.local_to_world) and bytes(cam.world_to_local) == bytes(sc.camera.world_to_local)
     for f in ("aspect", "fov_y", "lens_radius", "img_plane_distance", "obj_plane_distance"):
@@ -165,12 +168,14 @@ def test_flatten_refuses_what_is_outside_the_hot_path_loudly():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", [abi.MODE_RGB, abi.MODE_SPECTRAL])
-def test_reference_scene_object_renders_on_the_hip_path_through_the_renderer_vtable(mode):
+@pytest.mark.parametrize("which", ["cornell_glass", "instanced"])
+def test_reference_scene_object_renders_on_the_hip_path_through_the_renderer_vtable(mode, which):
     """HostProgram/main.cpp:59 `renderer->render(*scene, settings)` with renderer = HIPPathTracingRenderer: the libSLR Scene
     object (pointer graph, SBVH and all) is flattened, rendered on the GPU and lands in the camera's ImageSensor."""
     from slr_amd import Context
     lib = _ref(mode)
-    sc = scenes.cornell_box_spheres(4.0 / 3.0, 16, 8, "glass")
+    # "instanced": the libSLR Scene holds TransformedSurfaceObjects over mesh aggregates; the adapter turns them into slrhip_instances
+    sc = scenes.cornell_box_spheres(4.0 / 3.0, 16, 8, "glass") if which == "cornell_glass" else scenes.cornell_instanced(4.0 / 3.0, 12, 6, copies=9)
     st = ob.settings(96, 72, seed=99)
     spp = 8
     rs = lib.scene(sc)
