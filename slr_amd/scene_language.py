@@ -301,6 +301,13 @@ class Node:
         self.children = []
 
 
+class ReferenceNode:
+    """createReferenceNode (API.cpp:745-752): a second placement of a node's subtree.  The reference turns it into a
+    TransformedSurfaceObject over the subtree's aggregate (libSLRSceneGraph/nodes.cpp:174-184); here it becomes a slrhip_instance."""
+    def __init__(self, node):
+        self.node = node
+
+
 class Function:
     def __init__(self, overloads):
         self.overloads = overloads          # list of (signature, callable(args dict) or AST body)
@@ -559,7 +566,7 @@ class Interpreter:
                            lambda a: Tuple([(None, a["position"]), (None, a["normal"]), (None, a["tangent"]), (None, a["texCoord"])])))
         f("createMesh", ([("vertices", TUP, D), ("matGroups", TUP, D)], self._create_mesh))
         f("createNode", ([], lambda a: Node()))
-        f("createReferenceNode", ([("node", Node, D)], lambda a: a["node"]))
+        f("createReferenceNode", ([("node", Node, D)], lambda a: ReferenceNode(a["node"])))
         f("setTransform", ([("node", Node, D), ("transform", np.ndarray, D)], self._set_transform))
         f("addChild", ([("parent", Node, D), ("child", ANY, D)], self._add_child))
         f("load3DModel", ([("path", STR, D), ("matProc", FUNC, None)], self._load_model))
@@ -714,12 +721,25 @@ class Interpreter:
             return idx
 
         cameras = []
+        mesh_ranges = {}        # referenced node -> its triangles (first, count), flattened once in the node's own space
 
-        def visit(node, world):
+        def visit(node, world, referenced=False):
             world = world @ node.transform
             for c in node.children:
                 if isinstance(c, Node):
-                    visit(c, world)
+                    visit(c, world, referenced)
+                elif isinstance(c, ReferenceNode):
+                    if referenced:
+                        raise UnsupportedFeature("a reference node inside a referenced subtree (one level of instancing)")
+                    if id(c.node) not in mesh_ranges:
+                        first = b.num_triangles()
+                        visit(c.node, np.eye(4), True)
+                        count = b.num_triangles() - first
+                        if count == 0:
+                            raise SceneLanguageError("createReferenceNode of a node without geometry")
+                        mesh_ranges[id(c.node)] = (first, count)
+                    first, count = mesh_ranges[id(c.node)]
+                    b.add_instance(first, count, world)
                 elif isinstance(c, Mesh):
                     pos = [v[0] for v in c.vertices]; nrm = [v[1] for v in c.vertices]
                     tan = [v[2] for v in c.vertices]; uv = [v[3] for v in c.vertices]
@@ -731,6 +751,8 @@ class Interpreter:
                     else:
                         b.add_box(material(c.material), world @ scenes._scale(2.0))     # models/box.assbin spans [-1, 1]^3
                 elif isinstance(c, Camera):
+                    if referenced:
+                        raise UnsupportedFeature("a camera inside a referenced subtree")
                     cameras.append((c, world))
                 else:
                     raise SceneLanguageError("unexpected child in the node graph")

@@ -200,6 +200,36 @@ def test_multi_materials_outside_the_supported_subset_are_refused(extra, used):
         it.build()
 
 
+def test_reference_nodes_become_instances():
+    """createReferenceNode (TestScenes/RTC3.txt:21-30 places its grass this way; API.cpp:745-752, nodes.cpp:174-184): the referenced
+    subtree is flattened ONCE in its own space — its static transforms baked into the vertices, as the reference does — and every
+    reference is a slrhip_instance of that triangle range with the transform of the nodes above it."""
+    script = cornell_script("matte") + '''
+        tuft = createNode();
+        setTransform(tuft, scale(0.5, 1.0, 0.5));
+        blade = load3DModel("models/box.assbin", crystal);
+        addChild(tuft, blade);
+        ref = createReferenceNode(tuft);
+        a = createNode(); setTransform(a, translate(0.4, 0.2, 1.0) * rotateY(0.3)); addChild(a, ref); addChild(box, a);
+        b = createNode(); setTransform(b, translate(-0.6, 0.4, 1.2) * scale(0.3, 0.6, 0.3)); addChild(b, createReferenceNode(tuft)); addChild(box, b);
+    '''
+    sc, _, _ = sl.load_scene(script, sphere_tessellation=(8, 4))
+    plain, _, _ = sl.load_scene(cornell_script("matte"), sphere_tessellation=(8, 4))
+    assert len(sc.instances) == 2 and len(sc.triangles) == len(plain.triangles) + 12          # the box once, not twice
+    first = len(plain.triangles)
+    assert all(int(i["first_triangle"]) == first and int(i["num_triangles"]) == 12 for i in sc.instances)
+    # the mesh sits in the referenced node's own space: the unit box under scale(0.5, 1, 0.5) x the model's own factor 2
+    p = sc.vertices["position"][np.unique(sc.triangles["v"][first:])]
+    assert np.allclose(np.abs(p).max(axis=0), [0.5, 1.0, 0.5])
+    m0 = sc.instances[0]["local_to_world"].reshape(4, 4).T
+    assert np.allclose(m0[:3, 3], [0.4, 0.2, 1.0]) and np.allclose(m0[:3, :3] @ m0[:3, :3].T, np.eye(3), atol=1e-6)
+    m1 = sc.instances[1]["local_to_world"].reshape(4, 4).T
+    assert np.allclose(np.diag(m1)[:3], [0.3, 0.6, 0.3])
+    assert np.allclose(sc.instances[1]["world_to_local"].reshape(4, 4).T @ m1, np.eye(4), atol=1e-6)
+    with pytest.raises(sl.UnsupportedFeature):
+        sl.load_scene(script + "inner = createNode(); addChild(inner, createReferenceNode(tuft)); addChild(root, createReferenceNode(inner));")
+
+
 def test_syntax_errors_are_reported():
     with pytest.raises(sl.SceneLanguageError):
         sl.Interpreter().run("a = (1, 2;")
