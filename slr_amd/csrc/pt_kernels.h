@@ -7,6 +7,12 @@
 
 namespace slrhip {
 
+// Limits of the shading tables staged in LDS by k_shade / k_tail (ShadeLds, pt_shade_kernels.h); larger scenes read them from HBM.
+static const int kLdsMaterials = 32;
+static const int kLdsLights = 16;
+static const int kLdsSpectra = 96;
+static const int kLdsPoolFloats = 6144;     // 24 KiB: the spectrum sample tables of a scene (spectral mode), staged per workgroup
+
 // Scene arrays resident in HBM (uploaded once by slrhip_upload_scene).
 struct DevScene {
     const float4* nodes;          // QNode as 8 x float4, breadth-first
@@ -33,6 +39,11 @@ struct DevScene {
     const float4* triUV;          // per scene triangle: (u0, v0, u1, v1), (u2, v2, -, -)
     const float4* alphaTris;      // per alpha record (LeafTri::alpha): the same two float4 + the alpha texture index
     const float* texTexels;       // texels of the image textures, 3 floats each: (r, g, b), spectral mode (u, v, s)
+    // The tables k_shade / k_tail stage in LDS, packed by slrhip_upload_scene into ONE array in the order of ShadeLds'
+    // segments — RGB: materials, lights, light PMF, light CDF; spectral: materials, spectra, sample pool, lights, PMF, CDF — each
+    // padded to whole float4; tableEnd[k] = end of segment k in float4 (cumulative).  nullptr when the scene exceeds the LDS limits.
+    const float4* shadeTables;
+    uint32_t tableEnd[6];
     const float4* instances;      // DevInstance as 9 x float4, or nullptr: the scene has no instanced mesh
     uint32_t numInstances;
     uint32_t numTextures;

@@ -12,8 +12,7 @@ void launchResetSlots(const PathBuffers& pb, const RenderParams& rp, bool clearA
     else hipLaunchKernelGGL(k_reset_slots<RGB>, grid, block, 0, stream, pb, rp, clearAcc ? 1u : 0u);
 }
 void launchShade(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, hipStream_t stream) {
-    const bool ldsTables = sc.numMaterials <= (uint32_t)kLdsMaterials && sc.numLights <= (uint32_t)kLdsLights &&
-                           (!rp.spectral || (sc.numSpectra <= (uint32_t)kLdsSpectra && sc.numSpectrumData <= (uint32_t)kLdsPoolFloats));
+    const bool ldsTables = sc.shadeTables != nullptr;      // slrhip_upload_scene packs them when the scene fits the LDS limits (shadeTablesFit)
     // The microfacet (GGX) code costs ~45 VGPRs, so scenes without such lobes get kernels without it.
     const bool glossy = sc.hasMicrofacet != 0;
     if (sc.hasMulti || sc.numTextures) {

@@ -54,10 +54,6 @@ enum : uint32_t {
     ((state) | ((len) << 3) | ((wl) << 16) | ((wlsel) << 12) | ((delta) << 13) | ((shadow) << 14))
 
 static const int kShadeBlock = 256;
-static const int kLdsMaterials = 32;
-static const int kLdsLights = 16;
-static const int kLdsSpectra = 96;
-static const int kLdsPoolFloats = 6144;     // 24 KiB: the spectrum sample tables of a scene (spectral mode), staged per workgroup
 
 // Spectrum-valued path state in HBM.  RGB: one float4 per slot, the scalar that travels with it in .w.
 // Spectral: four float4 planes per array (plane p of slot i at [p * numSlots + i], so every plane is a coalesced
@@ -391,8 +387,48 @@ struct ShadeLds {
     float4 mats[SPECTRAL ? kLdsMaterials * 2 + kLdsSpectra * 2 + kLdsPoolFloats / 4 : kLdsMaterials * 5];
     float4 lights[kLdsLights * 9];         // LightTri   = 9 x float4
     float lightPMF[kLdsLights];
-    float lightCDF[kLdsLights + 1];
+    float lightCDF[kLdsLights + 4];        // kLdsLights + 1 entries, padded to whole float4
 };
+static_assert(kLdsLights % 4 == 0, "the light PMF is staged as whole float4");
+
+// Stage the shading tables of the scene (DevScene::shadeTables: one packed array, segments in the order of ShadeLds' members) in
+// LDS.  One flat copy: every thread requests its (up to four) float4 first and writes them afterwards, so the whole table costs
+// ONE memory round trip — the per-table loops this replaces waited for each table in turn, four to six dependent round trips at
+// the top of every workgroup.  The caller's barrier publishes the tables.
+template <bool SPECTRAL>
+__device__ __forceinline__ void stageShadeTables(const DevScene& sc, ShadeLds<SPECTRAL>& lds) {
+    constexpr uint32_t kSegments = SPECTRAL ? 6u : 4u;
+    // float4 index of every segment's first element inside ShadeLds
+    constexpr uint32_t matsF4 = SPECTRAL ? kLdsMaterials * 2 + kLdsSpectra * 2 + kLdsPoolFloats / 4 : kLdsMaterials * 5;
+    const uint32_t dst[6] = {0u,
+                             SPECTRAL ? (uint32_t)(kLdsMaterials * 2) : matsF4,
+                             SPECTRAL ? (uint32_t)(kLdsMaterials * 2 + kLdsSpectra * 2) : matsF4 + kLdsLights * 9,
+                             SPECTRAL ? matsF4 : matsF4 + kLdsLights * 9 + kLdsLights / 4,
+                             matsF4 + kLdsLights * 9,
+                             matsF4 + kLdsLights * 9 + kLdsLights / 4};
+    float4* out = reinterpret_cast<float4*>(&lds);
+    const uint32_t total = sc.tableEnd[kSegments - 1];
+    for (uint32_t base = threadIdx.x; base < total; base += 4 * kShadeBlock) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t i = base + u * kShadeBlock;
+            v[u] = sc.shadeTables[min(i, total - 1u)];      // unconditional (clamped), so that the four requests leave back to back
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(v[u].x), "+v"(v[u].y), "+v"(v[u].z), "+v"(v[u].w));      // ... and are not sunk into the guarded writes below
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t i = base + u * kShadeBlock;
+            if (i >= total) continue;
+            uint32_t begin = 0, to = dst[0];
+#pragma unroll
+            for (uint32_t k = 0; k + 1 < kSegments; ++k)
+                if (i >= sc.tableEnd[k]) { begin = sc.tableEnd[k]; to = dst[k + 1]; }
+            out[to + (i - begin)] = v[u];
+        }
+    }
+}
 
 // Occupancy floor of k_logic (waves per SIMD): the register allocator spills to scratch to stay under 512 / N registers.
 // Measured on the spectral GGX scene: the 330-register allocation (1 wave per SIMD, 63 % of its cycles waiting on memory,
@@ -452,25 +488,47 @@ __device__ __forceinline__ int32_t texturizeMat(const DevScene& sc, Mat<S>& mm, 
 // FUSED (k_shade): a path that ends here is accumulated and restarted by the caller in the same launch — the slot's flags and
 // radiance sum are handed back (`flags`, `radiance`; RGB keeps the sum in registers) instead of being stored.  Not FUSED
 // (k_tail): the slot is left in ST_REGEN with bit 15 set and its sum in HBM, for the lane's next turn.
+// The records of a slot that a visit reads whatever the slot's state is.  k_shade requests them at the very top of the kernel,
+// together with the slot's flags and the tables it stages in LDS, so that they travel in ONE memory round trip before the
+// workgroup's barrier instead of in three dependent ones (flags -> tables -> state); the tail kernel requests them just before
+// its visit.
+template <class S>
+struct SlotLoads {
+    uint4 r4;                  // xorshift128 state
+    S alpha;                   // path throughput
+    float pdfPrev;
+    float4 h, o4, d4;          // hit record, ray origin, ray direction
+    int32_t hitInstance;       // instanced scenes: the TransformedSurfaceObject of the hit
+    float wlOffset;            // spectral mode: the sample's wavelength offset (sample header)
+    __device__ __forceinline__ void issue(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t slot) {
+        r4 = pb.rng[(size_t)slot * pb.hdrStride];
+        SpecIO<S>::load(pb.alpha, pb.pdfPrev, slot, rp.numSlots, alpha, pdfPrev);
+        h = pb.hit[slot];
+        hitInstance = sc.instances ? pb.hitInstance[slot] : -1;
+        o4 = pb.rayOrg[(size_t)slot * pb.rayStride];
+        d4 = pb.rayDir[(size_t)slot * pb.rayStride];
+        wlOffset = S::N == 3 ? 0.0f : __uint_as_float(pb.hdr[(size_t)slot * pb.hdrStride].z);
+    }
+};
+
 template <class S, bool LDS_TABLES, bool MF, bool MULTI, bool TEX, bool FUSED>
 __device__ __forceinline__ void logicSlot(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, const ShadeLds<S::N != 3>& lds,
-                                          const float* lightPMF, const float* lightCDF, uint32_t slot, uint32_t& flags, uint32_t vis, S& radiance,
-                                          bool& emitExt, bool& emitShadow, bool& emitRegen) {
+                                          const float* lightPMF, const float* lightCDF, uint32_t slot, const SlotLoads<S>& in, uint32_t& flags, uint32_t vis,
+                                          S& radiance, bool& emitExt, bool& emitShadow, bool& emitRegen) {
     constexpr bool leader = true;
-    // ---- all state loads up front: one memory round trip instead of a dependent chain (flags: read above) -----------
-    const uint4 r4 = pb.rng[(size_t)slot * pb.hdrStride];
+    // ---- the state loads that depend on the flags; the others were requested by the caller (SlotLoads) -----------
+    const uint4 r4 = in.r4;
     // The path's radiance sum (Kahan pair) and the pending light sample: RGB keeps them in registers (3 x 16 B,
     // requested with everything else); in spectral mode they are 3 x 64 B that most visits never touch, so they
     // stay in HBM and SpAcc updates them in place when a contribution actually arrives.
-    S alpha;
+    S alpha = in.alpha;
     SpAcc<S> sp;
-    float bsdfPDFprev;
-    SpecIO<S>::load(pb.alpha, pb.pdfPrev, slot, rp.numSlots, alpha, bsdfPDFprev);
+    float bsdfPDFprev = in.pdfPrev;
     sp.begin(pb, slot, rp.numSlots, flags, F_SHADOW(flags) && vis);
-    const float4 h = pb.hit[slot];
-    const int32_t hitInstance = sc.instances ? pb.hitInstance[slot] : -1;      // instanced scenes: the TransformedSurfaceObject of the hit
-    const float4 o4 = pb.rayOrg[(size_t)slot * pb.rayStride], d4 = pb.rayDir[(size_t)slot * pb.rayStride];
-    const float wlOffset = S::N == 3 ? 0.0f : __uint_as_float(pb.hdr[(size_t)slot * pb.hdrStride].z);
+    const float4 h = in.h;
+    const int32_t hitInstance = in.hitInstance;
+    const float4 o4 = in.o4, d4 = in.d4;
+    const float wlOffset = in.wlOffset;
 
     const uint32_t state = F_STATE(flags);
     if (state == ST_FIRST_HIT || state == ST_NEXT_HIT || state == ST_FINISH) {
@@ -917,6 +975,9 @@ struct StartLds {
     uint32_t waveBase[kShadeBlock / 64 + 1];
 };
 
+#ifndef SLR_SHADE_EARLY
+#define SLR_SHADE_EARLY 1          // 0 (variant builds): the slot's state records are requested after the table barrier
+#endif
 #ifndef SLR_STATIC_PASSES
 #define SLR_STATIC_PASSES 0        // 1 (variant builds): no sample pool, stripe s renders the passes s, s + K, s + 2K, ...
 #endif
@@ -931,11 +992,25 @@ __attribute__((amdgpu_waves_per_eu(S::N == 3 ? SLR_WAVES_RGB : (MF ? SLR_WAVES_S
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 
     // ---- the end of a render: nothing left anywhere / nothing left in this block ------------------------------------------
-    if (pb.activeSlots[0] == 0 || pb.tailMode[0]) return;                 // every slot is out of passes / the tail kernel takes over (uniform)
-    if (pb.blockDead[blockIdx.x]) return;
+    {
+        // every slot is out of passes / the tail kernel takes over / this block is finished (all uniform); the three words are
+        // requested together: evaluated one after the other they were three dependent scalar-cache round trips
+        const uint32_t liveSlots = pb.activeSlots[0], tailMode = pb.tailMode[0], dead = pb.blockDead[blockIdx.x];
+        if ((liveSlots == 0u) | (tailMode != 0u) | (dead != 0u)) return;
+    }
+    // ONE round trip for everything the visit needs that does not depend on the slot's state: flags, visibility word, the pixel's
+    // pool counter, the state records (SlotLoads) and the tables staged below; ONE barrier publishes the tables and decides
+    // whether the block has any work left.  (SLR_SHADE_EARLY 0, variant builds: the state records are requested after the barrier.)
     uint32_t flags = pb.flags[slot];                                      // numSlots = 256 x workgroups: always in range
-    const uint32_t vis = pb.visible[slot];                                // with the flags: both are known before the state loads are issued
+    const uint32_t vis = pb.visible[slot];
+    const SlotAddr at = slotAddr(rp, slot);
+    const uint32_t nextOfPixel = at.valid ? pb.nextSample[at.pix] : 0u;   // read by every stripe of the pixel before the barrier below, advanced after it
+    SlotLoads<S> in;
+    if (SLR_SHADE_EARLY) in.issue(sc, pb, rp, slot);
     const uint32_t state0 = F_STATE(flags);
+    start.poolMask[threadIdx.x] = 0ull;
+    if (threadIdx.x == 0) start.waveBase[kShadeBlock / 64] = 0u;
+    if (LDS_TABLES) stageShadeTables<S::N != 3>(sc, lds);
     {
         const int anyWork = __syncthreads_or(state0 != ST_IDLE);
         if (!anyWork) {
@@ -945,36 +1020,14 @@ __attribute__((amdgpu_waves_per_eu(S::N == 3 ? SLR_WAVES_RGB : (MF ? SLR_WAVES_S
             return;
         }
     }
-    const SlotAddr at = slotAddr(rp, slot);
-    const uint32_t nextOfPixel = at.valid ? pb.nextSample[at.pix] : 0u;   // read by every stripe of the pixel before the barrier below, advanced after it
-    start.poolMask[threadIdx.x] = 0ull;
-    if (threadIdx.x == 0) start.waveBase[kShadeBlock / 64] = 0u;
-    if (LDS_TABLES) {
-        if (S::N == 3) {
-            const float4* gm = reinterpret_cast<const float4*>(sc.materials);
-            for (uint32_t i = threadIdx.x; i < sc.numMaterials * 5; i += kShadeBlock) lds.mats[i] = gm[i];
-        }
-        else {
-            const float4* gm = reinterpret_cast<const float4*>(sc.materialsS);
-            const float4* gs = reinterpret_cast<const float4*>(sc.spectra);
-            for (uint32_t i = threadIdx.x; i < sc.numMaterials * 2; i += kShadeBlock) lds.mats[i] = gm[i];
-            for (uint32_t i = threadIdx.x; i < sc.numSpectra * 2; i += kShadeBlock) lds.mats[2 * kLdsMaterials + i] = gs[i];
-            const float4* gp = reinterpret_cast<const float4*>(sc.spectrumPool);
-            for (uint32_t i = threadIdx.x; i < (sc.numSpectrumData + 3) / 4; i += kShadeBlock) lds.mats[2 * kLdsMaterials + 2 * kLdsSpectra + i] = gp[i];
-        }
-        const float4* gl = reinterpret_cast<const float4*>(sc.lightTris);
-        for (uint32_t i = threadIdx.x; i < sc.numLights * 9; i += kShadeBlock) lds.lights[i] = gl[i];
-        if (threadIdx.x < sc.numLights) lds.lightPMF[threadIdx.x] = sc.lightPMF[threadIdx.x];
-        if (threadIdx.x <= sc.numLights) lds.lightCDF[threadIdx.x] = sc.lightCDF[threadIdx.x];
-    }
-    __syncthreads();
+    if (!SLR_SHADE_EARLY) in.issue(sc, pb, rp, slot);
     const float* lightPMF = LDS_TABLES ? lds.lightPMF : sc.lightPMF;
     const float* lightCDF = LDS_TABLES ? lds.lightCDF : sc.lightCDF;
 
     bool emitExt = false, emitShadow = false, pathEnded = false;
     S radiance;
     if (state0 == ST_FIRST_HIT || state0 == ST_NEXT_HIT || state0 == ST_FINISH)
-        logicSlot<S, LDS_TABLES, MF, MULTI, TEX, true>(sc, pb, rp, lds, lightPMF, lightCDF, slot, flags, vis, radiance, emitExt, emitShadow, pathEnded);
+        logicSlot<S, LDS_TABLES, MF, MULTI, TEX, true>(sc, pb, rp, lds, lightPMF, lightCDF, slot, in, flags, vis, radiance, emitExt, emitShadow, pathEnded);
 
     // ---- a path that ended: sensor->add, in the same launch --------------------------------------------------------------------
     uint32_t samplesDone = 0;

@@ -45,8 +45,7 @@ void launchTail(const DevScene& sc, const PathBuffers& pb, const RenderParams& r
     hipLaunchKernelGGL(k_tail_collect, dim3(rp.numSlots / kShadeBlock), dim3(kShadeBlock), 0, stream, pb, rp);
     // one lane per listed slot; lanes take further slots from the list when theirs goes idle, so a grid smaller than the list is fine
     const uint32_t blocks = std::min<uint32_t>((liveSlots + kShadeBlock - 1) / kShadeBlock, (uint32_t)numCUs * 4u);
-    const bool ldsTables = sc.numMaterials <= (uint32_t)kLdsMaterials && sc.numLights <= (uint32_t)kLdsLights &&
-                           (!rp.spectral || (sc.numSpectra <= (uint32_t)kLdsSpectra && sc.numSpectrumData <= (uint32_t)kLdsPoolFloats));
+    const bool ldsTables = sc.shadeTables != nullptr;      // slrhip_upload_scene packs them when the scene fits the LDS limits (shadeTablesFit)
     const bool glossy = sc.hasMicrofacet != 0;
     if (sc.numTextures) { if (rp.spectral) launchTailTexSpec(sc, pb, rp, blocks, stream); else launchTailTexRGB(sc, pb, rp, blocks, stream); }
     else if (sc.hasMulti) { if (rp.spectral) launchTailMultiSpec(sc, pb, rp, blocks, stream); else launchTailMultiRGB(sc, pb, rp, blocks, stream); }

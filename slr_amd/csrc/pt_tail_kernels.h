@@ -37,24 +37,7 @@ __global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(SLR
     __shared__ ShadeLds<S::N != 3> lds;
     __shared__ TraceLds tlds;
     __shared__ uint32_t red[4];
-    if (LDS_TABLES) {
-        if (S::N == 3) {
-            const float4* gm = reinterpret_cast<const float4*>(sc.materials);
-            for (uint32_t i = threadIdx.x; i < sc.numMaterials * 5; i += kShadeBlock) lds.mats[i] = gm[i];
-        }
-        else {
-            const float4* gm = reinterpret_cast<const float4*>(sc.materialsS);
-            const float4* gs = reinterpret_cast<const float4*>(sc.spectra);
-            for (uint32_t i = threadIdx.x; i < sc.numMaterials * 2; i += kShadeBlock) lds.mats[i] = gm[i];
-            for (uint32_t i = threadIdx.x; i < sc.numSpectra * 2; i += kShadeBlock) lds.mats[2 * kLdsMaterials + i] = gs[i];
-            const float4* gp = reinterpret_cast<const float4*>(sc.spectrumPool);
-            for (uint32_t i = threadIdx.x; i < (sc.numSpectrumData + 3) / 4; i += kShadeBlock) lds.mats[2 * kLdsMaterials + 2 * kLdsSpectra + i] = gp[i];
-        }
-        const float4* gl = reinterpret_cast<const float4*>(sc.lightTris);
-        for (uint32_t i = threadIdx.x; i < sc.numLights * 9; i += kShadeBlock) lds.lights[i] = gl[i];
-        if (threadIdx.x < sc.numLights) lds.lightPMF[threadIdx.x] = sc.lightPMF[threadIdx.x];
-        if (threadIdx.x <= sc.numLights) lds.lightCDF[threadIdx.x] = sc.lightCDF[threadIdx.x];
-    }
+    if (LDS_TABLES) stageShadeTables<S::N != 3>(sc, lds);
     const uint32_t numTop = stageTopNodes(sc, tlds);          // ends with the barrier that also covers the tables above
     const float* lightPMF = LDS_TABLES ? lds.lightPMF : sc.lightPMF;
     const float* lightCDF = LDS_TABLES ? lds.lightCDF : sc.lightCDF;
@@ -138,7 +121,9 @@ __global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(SLR
         bool emitExt = false, emitShadow = false, emitRegen = false;
         uint32_t fl = flags;
         S unusedSum;
-        logicSlot<S, LDS_TABLES, MF, MULTI, TEX, false>(sc, pb, rp, lds, lightPMF, lightCDF, slot, fl, pb.visible[slot], unusedSum, emitExt, emitShadow, emitRegen);
+        SlotLoads<S> in;
+        in.issue(sc, pb, rp, slot);
+        logicSlot<S, LDS_TABLES, MF, MULTI, TEX, false>(sc, pb, rp, lds, lightPMF, lightCDF, slot, in, fl, pb.visible[slot], unusedSum, emitExt, emitShadow, emitRegen);
         // a finished path is in ST_REGEN now: accumulated at the next turn of this loop
     }
     if (slot != kTailNone) atomicOr(pb.errorWord, ERR_CONSUMER_IDLE);      // the bound was hit: never expected, fails the render loudly

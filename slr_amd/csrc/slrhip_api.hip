@@ -130,6 +130,8 @@ struct slrhip_ctx {
     DevArray<DevSpectrum> spectra;
     DevArray<float> spectrumPool;
     DevArray<float> lightPMF, lightCDF;
+    DevArray<float4> shadeTables;
+    std::vector<float> hostSpectrumPool;      // the padded pool as uploaded (goes into the packed shade tables)
     DevArray<float> envTexels, envTopPDF, envTopCDF, envRowPDF, envRowCDF;
     DevArray<uint8_t> gridCells;
     DevArray<float> pointUV, pointSpectrum;
@@ -702,10 +704,39 @@ int slrhip_upload_scene(slrhip_ctx* ctx, const slrhip_scene_desc* d) {
         while (pool.size() % 4) pool.push_back(0.0f);          // the shade kernel stages the pool into LDS 16 bytes at a time
         ctx->scene.numSpectrumData = (uint32_t)pool.size();
         HIP_TRY(ctx->spectrumPool.upload(pool));
+        ctx->hostSpectrumPool.swap(pool);
     }
     HIP_TRY(ctx->spectra.upload(devSpectra));
     HIP_TRY(ctx->lightPMF.upload(pmf));
     HIP_TRY(ctx->lightCDF.upload(cdf));
+    {
+        // the tables the shade kernels stage in LDS, packed in the order of ShadeLds' segments (DevScene::shadeTables)
+        const bool fits = mats.size() <= (size_t)kLdsMaterials && lights.size() <= (size_t)kLdsLights &&
+                          (!spectral || (devSpectra.size() <= (size_t)kLdsSpectra && ctx->scene.numSpectrumData <= (uint32_t)kLdsPoolFloats));
+        std::vector<float4> blob;
+        uint32_t seg = 0;
+        for (uint32_t k = 0; k < 6; ++k) ctx->scene.tableEnd[k] = 0;
+        const auto append = [&](const void* src, size_t bytes) {
+            const size_t n = (bytes + 15) / 16, at = blob.size();
+            blob.resize(at + n, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+            if (bytes) std::memcpy(blob.data() + at, src, bytes);
+            ctx->scene.tableEnd[seg++] = (uint32_t)blob.size();
+        };
+        if (fits) {
+            if (spectral) {
+                append(matsS.data(), matsS.size() * sizeof(DevMaterialS));
+                append(devSpectra.data(), devSpectra.size() * sizeof(DevSpectrum));
+                append(ctx->hostSpectrumPool.data(), ctx->hostSpectrumPool.size() * sizeof(float));
+            }
+            else append(mats.data(), mats.size() * sizeof(DevMaterial));
+            append(lights.data(), lights.size() * sizeof(LightTri));
+            append(pmf.data(), pmf.size() * sizeof(float));
+            append(cdf.data(), cdf.size() * sizeof(float));
+            while (seg < 6) { ctx->scene.tableEnd[seg] = (uint32_t)blob.size(); ++seg; }
+        }
+        HIP_TRY(ctx->shadeTables.upload(blob));
+        ctx->scene.shadeTables = fits ? ctx->shadeTables.ptr : nullptr;
+    }
     HIP_TRY(ctx->envTexels.upload(envTexels));
     HIP_TRY(ctx->envTopPDF.upload(envTopPDF)); HIP_TRY(ctx->envTopCDF.upload(envTopCDF));
     HIP_TRY(ctx->envRowPDF.upload(envRowPDF)); HIP_TRY(ctx->envRowCDF.upload(envRowCDF));
