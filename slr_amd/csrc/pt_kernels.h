@@ -96,10 +96,11 @@ enum : uint32_t { ERR_RING_SPACE = 1u, ERR_RING_RELEASE = 2u, ERR_CONSUMER_IDLE 
 static const uint32_t kTotalStride = 16;                   // 64-bit words: one 128-byte line
 __host__ __device__ inline uint32_t totalIndex(uint32_t kind, uint32_t shard) { return (kind * kShards + shard) * kTotalStride; }
 
-// Path state, SoA, one record per slot.  Slot layout (slotAddr below): workgroup-local and pixel-major — the 256 slots of
-// shade workgroup b are the K stripes of pixelsPerBlock = 256 / K consecutive pixels of the shard, stripe fastest, so that the
-// stripes of a pixel sit in ONE workgroup: the pixel's sample pool (which stripe renders which pass) is settled inside k_shade
-// with an LDS mask and a barrier, in the same launch in which the paths end.
+// Path state, SoA, one record per slot.  A slot is a path in flight, NOT a place in the image: whenever its path ends it takes the
+// next sample — a (pixel, pass) pair — from the work queue of its shade workgroup (WorkItem below) and writes the finished
+// sample's contribution to the result window; the sensor's per-pixel Kahan sum (ImageSensor::add, in pass order) is done by
+// k_fold once the window's passes are complete.  The image therefore does not depend on the number of slots, on which slot
+// rendered which sample or on the shard size, and the slots stay busy until the LAST sample of the call has been handed out.
 struct PathBuffers {
     uint4* rng;                   // xorshift128 state
     float4* rayOrg;               // extension / shadow ray origin, w = distMin
@@ -110,26 +111,36 @@ struct PathBuffers {
     float4* alpha;                // path throughput (+ pdf of the sampled direction)
     float4* spR;                  // path radiance Kahan sum (sp) (+ camera weight)
     float4* spC;                  // its compensation
-    float4* accR;                 // pixel accumulator Kahan sum (the ImageSensor pixel)
-    float4* accC;
+    // Result window of the render call: one entry per (pass of the window, pixel of the shard), pass-major — RGB one float4,
+    // spectral four (the sixteen bins of SpectrumStorage) — written once by the slot whose path was that sample; then the
+    // sensor itself: per pixel the Kahan sum and its compensation (CompensatedSum, BasicTypes/CompensatedSum.h:24-30), kept
+    // across the render calls of one slrhip_render_begin.
+    float4* results;
+    float4* fbSum;
+    float4* fbComp;
     float4* nee;                  // pending next-event contribution
     float4* shadowDir;            // shadow ray direction, w = distMax
     float* pdfPrev;               // spectral mode only: the scalar that rides in alpha.w in RGB mode
-    // per-slot sample header, written when a sample starts: x = samples of this slot finished so far, y = the current sample's
-    // camera weight (bits), z = its wavelength offset (bits; lambda_i = 360 + 470 (i + offset) / 16, spectral mode)
+    // per-slot sample header, written when a sample starts: x = the sample's pixel (index into the shard's pixel list), y = its
+    // camera weight (bits), z = its wavelength offset (bits; lambda_i = 360 + 470 (i + offset) / 16, spectral mode), w = its pass
+    // relative to the first pass of the window
     uint4* hdr;
     uint32_t* flags;
-    // Per-pixel sample pool: the stripes of a pixel draw their next pass from one counter, so that they all run out of
-    // passes at about the same iteration.  The stripes whose path ends in a k_shade launch set their bit in a 64-bit mask
-    // in LDS (the stripes of a pixel share a workgroup); after a barrier each of them takes the pass
-    // nextSample[pixel] + rank-in-mask and the lowest advances the counter.  Deterministic: which stripe renders which pass
-    // depends on path lengths only.
-    uint32_t* nextSample;
+    // Work queues (WorkItem below): per shade workgroup the number of samples it has taken from its queue so far.  Read and
+    // advanced by that workgroup alone in k_shade (no atomics); by atomics in the tail kernel, where lanes of several workgroups
+    // hold a block's slots.
+    uint32_t* cursor;
     uint32_t* visible;            // result of the shadow ray
     uint32_t* shadowQueue;        // kShards regions of shardCapacity slot indices: shadow rays of this iteration
     uint32_t* tailList;           // tail mode: the live slots, listed by k_tail_collect (numSlots entries)
     uint32_t* queueCount;         // [parity][kind][shard], see queueCounterIndex
-    uint32_t* activeSlots;        // slots that still have samples to do
+    // Live slots.  A slot that finds its queue exhausted goes idle; k_shade counts them per workgroup and adds the count to one of
+    // kShards words on separate lines (idleShards: the queues run out at about the same iteration everywhere, and ~10^5 atomics
+    // per launch on ONE word would cost a millisecond each time).  Every workgroup of the traversal launch that follows sums the
+    // shards (liveSlots below) for the tail-mode decision; its first workgroup publishes the sum in activeSlots[0] for the next
+    // k_shade launch (which only asks "is anything left?") and for the host.
+    uint32_t* activeSlots;
+    uint32_t* idleShards;         // [kShards] x kCounterStride words
     // one word per block of 256 consecutive slots: set by k_shade once every slot of the block has run out of passes (a slot
     // never leaves ST_IDLE within a render call), cleared by k_reset_slots; the scanning kernels skip such blocks without
     // touching their state — the last iterations of a render, in which a few long paths are left, then cost launch overhead
@@ -142,6 +153,7 @@ struct PathBuffers {
     // have to hand out — to the end in one launch.  tailWords = {list length, list cursor}.
     uint32_t* tailMode;
     uint32_t* tailWords;
+    uint32_t* tailIdled;          // slots the tail kernel left idle: the host checks it against the list length (every listed slot must end idle)
     uint64_t* totals;             // [kind][shard], see totalIndex
     const uint32_t* pixelXY;      // pixel-of-shard -> x | y << 16
     // Records that the same kernels touch at the same slots share a 32-byte sector when these strides are 2 (rayDir = rayOrg + 1,
@@ -151,11 +163,12 @@ struct PathBuffers {
 };
 
 struct RenderParams {
-    uint32_t numSlots;            // 256 x shade workgroups (the last lanes of a workgroup are padding when 256 % stripes != 0)
-    uint32_t numPixels, stripes;
-    uint32_t pixelsPerBlock;      // 256 / stripes
-    uint32_t stripesRecip;        // ceil(65536 / stripes): lane / stripes = (lane * stripesRecip) >> 16 for lane < 256 (exact: 256 x 64 < 65536)
-    uint32_t sppBegin, sppCount;
+    uint32_t numSlots;            // 256 x shade workgroups
+    uint32_t numBlocks;           // numSlots / 256
+    uint32_t numPixels, stripes;  // stripes: slots per pixel the slot count was sized for (slrhip_config::stripes or the automatic choice)
+    uint32_t sppBegin, sppCount;  // the passes of the current window
+    uint32_t workItems;           // numPixels x sppCount (< 2^32: slrhip_render sizes the windows)
+    uint32_t numChunks;           // ceil(workItems / kWorkChunk)
     int32_t rngSeed;
     float timeStart, timeEnd;
     uint32_t imageWidth, imageHeight;
@@ -166,36 +179,65 @@ struct RenderParams {
     uint32_t tailSlots;           // enter tail mode once at most this many slots are live; 0 = never
 };
 
-// Where a slot sits: pixel of the shard, stripe, and whether the lane is a real slot (padding lanes are idle for ever).
-struct SlotAddr {
-    uint32_t pix, stripe, localPix;
-    bool valid;
+// Work distribution.  An item is one sample: id = pass-of-window x numPixels + pixel, so 64 consecutive ids are one 8 x 8 tile
+// of one pass (the shard's pixel list is tile-major).  Ids are dealt to the shade workgroups in chunks of kWorkChunk: the j-th
+// chunk of workgroup b is chunk j x numBlocks + (b + j x kWorkRotate) mod numBlocks — every chunk belongs to exactly one
+// workgroup, a workgroup's chunks lie one per "round" of numBlocks chunks, and the rotation walks each workgroup over the
+// image, so that every queue is a sample of the whole frame (queue lengths differ by at most one chunk; their work, the sum of
+// ~(workItems / numBlocks) path lengths drawn all over the image, by a per cent or two).  Static queues need no global counter:
+// one word that every workgroup bumps saturates near 88 atomics per microsecond (above).  Lanes that restart in the same
+// launch take consecutive items, i.e. neighbouring pixels of one pass.
+static const uint32_t kWorkChunk = 64;
+static const uint32_t kWorkRotate = 40503u;
+struct WorkItem {
+    uint32_t pix, pass;           // pass relative to RenderParams::sppBegin
+    bool valid;                   // false: the queue is exhausted (every later item of this queue is invalid too)
 };
-__host__ __device__ inline SlotAddr slotAddr(const RenderParams& rp, uint32_t slot) {
-    const uint32_t lane = slot & 255u;
-    SlotAddr a;
-    a.localPix = (lane * rp.stripesRecip) >> 16;
-    a.stripe = lane - a.localPix * rp.stripes;
-    a.pix = (slot >> 8) * rp.pixelsPerBlock + a.localPix;
-    a.valid = a.localPix < rp.pixelsPerBlock && a.pix < rp.numPixels;
-    return a;
+__host__ __device__ inline WorkItem workItemOf(const RenderParams& rp, uint32_t block, uint32_t taken) {
+    const uint32_t j = taken / kWorkChunk;
+    WorkItem w;
+    w.pix = 0; w.pass = 0; w.valid = false;
+    if (j > rp.numChunks / rp.numBlocks) return w;                                   // (also keeps j x numBlocks inside 32 bits)
+    const uint32_t chunk = j * rp.numBlocks + (uint32_t)(((uint64_t)block + (uint64_t)j * kWorkRotate) % rp.numBlocks);
+    if (chunk >= rp.numChunks) return w;
+    const uint64_t id = (uint64_t)chunk * kWorkChunk + (taken % kWorkChunk);
+    if (id >= rp.workItems) return w;
+    w.pass = (uint32_t)(id / rp.numPixels);
+    w.pix = (uint32_t)(id - (uint64_t)w.pass * rp.numPixels);
+    w.valid = true;
+    return w;
 }
-__host__ __device__ inline uint32_t slotOf(const RenderParams& rp, uint32_t pix, uint32_t stripe) {
-    const uint32_t b = pix / rp.pixelsPerBlock;
-    return b * 256u + (pix - b * rp.pixelsPerBlock) * rp.stripes + stripe;
+// Items in the queue of a workgroup (what its cursor can usefully reach).
+__host__ __device__ inline uint32_t workQueueLength(const RenderParams& rp, uint32_t block) {
+    uint32_t n = 0;
+    for (uint32_t j = 0; j <= rp.numChunks / rp.numBlocks; ++j) {
+        const uint32_t chunk = j * rp.numBlocks + (uint32_t)(((uint64_t)block + (uint64_t)j * kWorkRotate) % rp.numBlocks);
+        if (chunk >= rp.numChunks) continue;
+        const uint64_t first = (uint64_t)chunk * kWorkChunk;
+        n += (uint32_t)((rp.workItems - first) < kWorkChunk ? (rp.workItems - first) : kWorkChunk);
+    }
+    return n;
 }
 
 // Evaluated by every workgroup of the traversal launch of an iteration: its input is stable during that launch (activeSlots
 // is written by k_shade only), so all workgroups agree; the first one records the decision for the kernels that follow.
-__device__ __forceinline__ bool tailModeBegins(const PathBuffers& pb, uint32_t tailSlots, uint32_t parity) {
+__device__ __forceinline__ uint32_t liveSlots(const PathBuffers& pb, uint32_t numSlots) {
+    uint32_t idle = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kShards; ++k) idle += pb.idleShards[k * kCounterStride];
+    return numSlots - idle;
+}
+__device__ __forceinline__ bool tailModeBegins(const PathBuffers& pb, uint32_t live, uint32_t tailSlots, uint32_t parity) {
     if (tailSlots == 0u) return false;
     if (pb.tailMode[0]) return true;
-    if (pb.activeSlots[0] > tailSlots) return false;
+    if (live > tailSlots) return false;
     if (blockIdx.x == 0 && threadIdx.x == 0) pb.tailMode[0] = 1u + parity;
     return true;
 }
 
-void launchResetSlots(const PathBuffers& pb, const RenderParams& rp, bool clearAccumulators, hipStream_t stream);
+void launchResetSlots(const PathBuffers& pb, const RenderParams& rp, bool clearSensor, hipStream_t stream);
+// ImageSensor::add for the window's passes, in pass order: the result window folded into the per-pixel Kahan sums
+void launchFold(const PathBuffers& pb, const RenderParams& rp, hipStream_t stream);
 // one wavefront iteration = launchShade(parity) then launchTraceWs(parity)
 void launchShade(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t parity, hipStream_t stream);
 void launchCountSamples(const PathBuffers& pb, const RenderParams& rp, hipStream_t stream);

@@ -897,13 +897,13 @@ __device__ __forceinline__ Spec16 storageAddend(const Spec16& val, float wlOffse
 // order and leaves the slot with a camera ray in flight; writes the slot's sample header (k_shade's compacted start lanes;
 // the tail kernel for the passes left when it takes over).
 template <class S>
-__device__ __forceinline__ void startSample(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t slot, uint32_t pix, uint32_t pass,
-                                            uint32_t samplesDone) {
+__device__ __forceinline__ void startSample(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t slot, uint32_t pix,
+                                            uint32_t passOfWindow) {
     // Job::kernel PathTracingRenderer.cpp:100-120, draws in source (left-to-right) order
     const uint32_t xy = pb.pixelXY[pix];
     const uint32_t px = xy & 0xFFFFu, py = xy >> 16;
     Rng rng;
-    rng.seed(sampleSeed(rp.rngSeed, px, py, pass));
+    rng.seed(sampleSeed(rp.rngSeed, px, py, rp.sppBegin + passOfWindow));
     float v = rng.nextFloat();
     float time = rp.timeStart * (1 - v) + rp.timeEnd * v;
     (void)time;
@@ -939,49 +939,47 @@ __device__ __forceinline__ void startSample(const DevScene& sc, const PathBuffer
     pb.flags[slot] = F_MAKE((uint32_t)ST_FIRST_HIT, 0u, wl, 0u, 0u, 0u);
     pb.rng[(size_t)slot * pb.hdrStride] = make_uint4(rng.s0, rng.s1, rng.s2, rng.s3);
     // alpha = 1, pdfPrev = 0 and sp = 0 are implied by ST_FIRST_HIT (see SpAcc): 48 B (RGB) / 196 B (spectral) not written
-    pb.hdr[(size_t)slot * pb.hdrStride] = make_uint4(samplesDone, __float_as_uint(camWeight), __float_as_uint(wlOffset), 0u);
+    pb.hdr[(size_t)slot * pb.hdrStride] = make_uint4(pix, __float_as_uint(camWeight), __float_as_uint(wlOffset), passOfWindow);
     pb.rayOrg[(size_t)slot * pb.rayStride] = make_float4(lensP.x, lensP.y, lensP.z, 0.0f);
     pb.rayDir[(size_t)slot * pb.rayStride] = make_float4(rayDir.x, rayDir.y, rayDir.z, INFINITY);
 }
 
-// sensor->add(p.x, p.y, wls, weight * C)  PathTracingRenderer.cpp:126-130: the finished path's radiance sum, times the camera
-// weight of its sample, Kahan-added to the slot's pixel accumulator.  `inRegisters`: C is handed over by the caller (RGB in
-// k_shade); else it is read from the slot's radiance sum in HBM, if the path ever wrote it (flag bit 10).
+// The finished sample's contribution, weight * C of sensor->add(p.x, p.y, wls, weight * C) (PathTracingRenderer.cpp:126-130) as
+// the sensor's storage takes it (ImageSensor::add -> SpectrumStorage::add: RGB as it is, spectral spread over the 16 bins),
+// written to the sample's entry of the result window; k_fold adds the entries of a pixel in pass order.  `inRegisters`: C is
+// handed over by the caller (RGB in k_shade); else it is read from the slot's radiance sum in HBM, if the path ever wrote it
+// (flag bit 10).
+__device__ __forceinline__ void storeResult(float4* results, size_t entry, const RGB& v) { results[entry] = make_float4(v.r, v.g, v.b, 0.0f); }
+__device__ __forceinline__ void storeResult(float4* results, size_t entry, const Spec16& v) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) results[entry * 4 + k] = make_float4(v.c[4 * k], v.c[4 * k + 1], v.c[4 * k + 2], v.c[4 * k + 3]);
+}
 template <class S>
-__device__ __forceinline__ void accumulateSample(const PathBuffers& pb, const RenderParams& rp, uint32_t slot, uint32_t flags, const uint4& hdr,
-                                                 bool inRegisters, S C) {
-    S accR, accC;
+__device__ __forceinline__ void writeResult(const PathBuffers& pb, const RenderParams& rp, uint32_t slot, uint32_t flags, const uint4& hdr,
+                                            bool inRegisters, S C) {
     float unusedW;
     const float camW = __uint_as_float(hdr.y);
     if (!inRegisters) {
         C = S();
         if (F_SPVALID(flags)) SpecIO<S>::load(pb.spR, nullptr, slot * pb.spStride, rp.numSlots * pb.spStride, C, unusedW);     // else the path gathered nothing: C = 0
     }
-    // accR / accC interleave (pb.accC = pb.accR + 1, element stride 2): the pair is one 32-byte sector per slot
-    SpecIO<S>::load(pb.accR, nullptr, 2 * slot, 2 * rp.numSlots, accR, unusedW);
-    SpecIO<S>::load(pb.accC, nullptr, 2 * slot, 2 * rp.numSlots, accC, unusedW);
     const S weight = (S(1.0f) * S(1.0f)) * camW;
-    kahanAdd(accR, accC, storageAddend(weight * C, S::N == 3 ? 0.0f : __uint_as_float(hdr.z)));
-    SpecIO<S>::store(pb.accR, nullptr, 2 * slot, 2 * rp.numSlots, accR, 0.0f);
-    SpecIO<S>::store(pb.accC, nullptr, 2 * slot, 2 * rp.numSlots, accC, 0.0f);
+    storeResult(pb.results, (size_t)hdr.w * rp.numPixels + hdr.x, storageAddend(weight * C, S::N == 3 ? 0.0f : __uint_as_float(hdr.z)));
 }
 
 // What the finishing lanes of a k_shade workgroup hand to its first lanes: the samples to start.
 struct StartLds {
-    unsigned long long poolMask[kShadeBlock];   // per pixel of the workgroup: stripes whose path ended in this launch
-    uint32_t lane[kShadeBlock];                 // compacted: slot = workgroup base + lane
+    uint32_t lane[kShadeBlock];                 // compacted: slot = workgroup base + lane; kNoStart = the queue had nothing left for it
+    uint32_t pix[kShadeBlock];
     uint32_t pass[kShadeBlock];
-    uint32_t samplesDone[kShadeBlock];
     uint32_t waveBase[kShadeBlock / 64 + 1];
+    uint32_t wentIdle;                          // lanes of the workgroup that found the queue exhausted in this launch
 };
+static const uint32_t kNoStart = 0xFFFFFFFFu;
 
 #ifndef SLR_SHADE_EARLY
 #define SLR_SHADE_EARLY 1          // 0 (variant builds): the slot's state records are requested after the table barrier
 #endif
-#ifndef SLR_STATIC_PASSES
-#define SLR_STATIC_PASSES 0        // 1 (variant builds): no sample pool, stripe s renders the passes s, s + K, s + 2K, ...
-#endif
-
 template <class S, bool LDS_TABLES, bool MF, bool MULTI = false, bool TEX = false>
 __global__ __launch_bounds__(kShadeBlock)
 __attribute__((amdgpu_waves_per_eu(S::N == 3 ? SLR_WAVES_RGB : (MF ? SLR_WAVES_SPECTRAL_GLOSSY : SLR_WAVES_SPECTRAL)))) void k_shade(DevScene sc, PathBuffers pb, RenderParams rp, uint32_t parity) {
@@ -998,24 +996,22 @@ __attribute__((amdgpu_waves_per_eu(S::N == 3 ? SLR_WAVES_RGB : (MF ? SLR_WAVES_S
         const uint32_t liveSlots = pb.activeSlots[0], tailMode = pb.tailMode[0], dead = pb.blockDead[blockIdx.x];
         if ((liveSlots == 0u) | (tailMode != 0u) | (dead != 0u)) return;
     }
+    const uint32_t taken = pb.cursor[blockIdx.x];                         // samples this workgroup has taken from its queue (uniform)
     // ONE round trip for everything the visit needs that does not depend on the slot's state: flags, visibility word, the pixel's
     // pool counter, the state records (SlotLoads) and the tables staged below; ONE barrier publishes the tables and decides
     // whether the block has any work left.  (SLR_SHADE_EARLY 0, variant builds: the state records are requested after the barrier.)
     uint32_t flags = pb.flags[slot];                                      // numSlots = 256 x workgroups: always in range
     const uint32_t vis = pb.visible[slot];
-    const SlotAddr at = slotAddr(rp, slot);
-    const uint32_t nextOfPixel = at.valid ? pb.nextSample[at.pix] : 0u;   // read by every stripe of the pixel before the barrier below, advanced after it
     SlotLoads<S> in;
     if (SLR_SHADE_EARLY) in.issue(sc, pb, rp, slot);
     const uint32_t state0 = F_STATE(flags);
-    start.poolMask[threadIdx.x] = 0ull;
-    if (threadIdx.x == 0) start.waveBase[kShadeBlock / 64] = 0u;
+    if (threadIdx.x == 0) start.wentIdle = 0u;
     if (LDS_TABLES) stageShadeTables<S::N != 3>(sc, lds);
     {
         const int anyWork = __syncthreads_or(state0 != ST_IDLE);
         if (!anyWork) {
-            // every slot here has run out of passes (a slot never leaves ST_IDLE within a render call): the block is finished
-            // for the rest of this call; say so, and the scanning kernels stop reading its state
+            // every slot here is idle — its queue is exhausted and a slot never leaves ST_IDLE within a window: the block is
+            // finished for the rest of the window; say so, and the scanning kernels stop reading its state
             if (threadIdx.x == 0) pb.blockDead[blockIdx.x] = 1u;
             return;
         }
@@ -1029,109 +1025,97 @@ __attribute__((amdgpu_waves_per_eu(S::N == 3 ? SLR_WAVES_RGB : (MF ? SLR_WAVES_S
     if (state0 == ST_FIRST_HIT || state0 == ST_NEXT_HIT || state0 == ST_FINISH)
         logicSlot<S, LDS_TABLES, MF, MULTI, TEX, true>(sc, pb, rp, lds, lightPMF, lightCDF, slot, in, flags, vis, radiance, emitExt, emitShadow, pathEnded);
 
-    // ---- a path that ended: sensor->add, in the same launch --------------------------------------------------------------------
-    uint32_t samplesDone = 0;
+    // ---- a path that ended: its contribution goes to the result window, in the same launch ------------------------------------
     if (pathEnded) {
         const uint4 hdr = pb.hdr[(size_t)slot * pb.hdrStride];
-        accumulateSample<S>(pb, rp, slot, flags, hdr, S::N == 3, radiance);
-        samplesDone = hdr.x + 1u;
-        if (!SLR_STATIC_PASSES) atomicOr(&start.poolMask[at.localPix], 1ull << at.stripe);
+        writeResult<S>(pb, rp, slot, flags, hdr, S::N == 3, radiance);
     }
     // ---- stream compaction of the shadow rays (extension rays need no queue: the traversal kernel reads the state flag) ----------
-    blockPush(pushLds, emitShadow, slot, pb.shadowQueue, pb.queueCount + parity * kQueueSetWords, rp.shardCapacity, pb.errorWord);      // two barriers: the pool masks are complete
+    blockPush(pushLds, emitShadow, slot, pb.shadowQueue, pb.queueCount + parity * kQueueSetWords, rp.shardCapacity, pb.errorWord);
     if (rp.countSlots) {
         const uint64_t ma = __ballot(emitExt || emitShadow || pathEnded);
         if (lane == 0 && ma) atomicAdd((unsigned long long*)&pb.totals[totalIndex(T_SLOT_VISITS, blockIdx.x % kShards)], (unsigned long long)__popcll(ma));
     }
 
-    // ---- the next pass of every slot that needs one: the first sample of a stripe is its own index (ST_REGEN after
-    //      k_reset_slots), later ones come from the pixel's pool in stripe order ----------------------------------------------------
-    const bool wantsPass = pathEnded || (state0 == ST_REGEN && at.valid);
-    uint32_t pass = at.stripe;
-    if (pathEnded) {
-        if (SLR_STATIC_PASSES) pass = at.stripe + rp.stripes * samplesDone;
-        else {
-            const unsigned long long m = start.poolMask[at.localPix];
-            pass = nextOfPixel + (uint32_t)__popcll(m & ((1ull << at.stripe) - 1ull));
-            if ((m & ((1ull << at.stripe) - 1ull)) == 0ull) pb.nextSample[at.pix] = nextOfPixel + (uint32_t)__popcll(m);      // the lowest finishing stripe advances the pool
-        }
-    }
-    const bool starts = wantsPass && pass < rp.sppCount;
-    const bool becameIdle = wantsPass && !starts;
-    if (becameIdle) {
-        pb.flags[slot] = F_MAKE((uint32_t)ST_IDLE, 0u, 0u, 0u, 0u, 0u);
-        pb.hdr[(size_t)slot * pb.hdrStride] = make_uint4(samplesDone, 0u, 0u, 0u);
-    }
+    // ---- the next sample of every slot that needs one (its path ended, or it has not started yet: ST_REGEN after k_reset_slots):
+    //      the wanting lanes, in lane order, take the next items of the workgroup's queue (pt_kernels.h WorkItem) ---------------------
+    const bool wants = pathEnded || state0 == ST_REGEN;
     {
-        // compaction of the samples to start over the workgroup: wave counts in LDS, then lanes 0 .. n-1 run startSample,
-        // so that the 50-draw seeding of the stream (the seeding contract, ~400 integer operations) and the camera
-        // arithmetic run on full waves instead of on the fifth of the lanes whose path has just ended
-        const uint64_t ms = __ballot(starts);
-        if (lane == 0) start.waveBase[wave] = (uint32_t)__popcll(ms);
+        // compaction over the workgroup: wave counts in LDS, then lanes 0 .. n-1 run startSample, so that the 50-draw seeding
+        // of the stream (the seeding contract, ~400 integer operations) and the camera arithmetic run on full waves instead of
+        // on the quarter of the lanes whose path has just ended
+        const uint64_t mw = __ballot(wants);
+        if (lane == 0) start.waveBase[wave] = (uint32_t)__popcll(mw);
         __syncthreads();
         uint32_t base = 0;
         for (uint32_t w = 0; w < wave; ++w) base += start.waveBase[w];
-        if (starts) {
-            const uint32_t i = base + (uint32_t)__popcll(ms & ((1ull << lane) - 1ull));
-            start.lane[i] = threadIdx.x;
-            start.pass[i] = pass;
-            start.samplesDone[i] = samplesDone;
-        }
-        __syncthreads();
         const uint32_t n = start.waveBase[0] + start.waveBase[1] + start.waveBase[2] + start.waveBase[3];
-        if (threadIdx.x < n) {
-            const uint32_t s2 = blockIdx.x * kShadeBlock + start.lane[threadIdx.x];
-            startSample<S>(sc, pb, rp, s2, slotAddr(rp, s2).pix, rp.sppBegin + start.pass[threadIdx.x], start.samplesDone[threadIdx.x]);
+        bool becameIdle = false;
+        if (wants) {
+            const uint32_t i = base + (uint32_t)__popcll(mw & ((1ull << lane) - 1ull));
+            const WorkItem w = workItemOf(rp, blockIdx.x, taken + i);
+            start.lane[i] = w.valid ? threadIdx.x : kNoStart;
+            start.pix[i] = w.pix;
+            start.pass[i] = w.pass;
+            becameIdle = !w.valid;
         }
+        if (becameIdle) pb.flags[slot] = F_MAKE((uint32_t)ST_IDLE, 0u, 0u, 0u, 0u, 0u);
+        const uint64_t mi = __ballot(becameIdle);
+        if (lane == 0 && mi) atomicAdd(&start.wentIdle, (uint32_t)__popcll(mi));
+        if (threadIdx.x == 0 && n) pb.cursor[blockIdx.x] = taken + n;
+        __syncthreads();
+        // the live count: one atomic per workgroup and launch, on one of kShards lines (PathBuffers::idleShards)
+        if (threadIdx.x == 0 && start.wentIdle) atomicAdd(&pb.idleShards[(blockIdx.x % kShards) * kCounterStride], start.wentIdle);
+        if (threadIdx.x < n && start.lane[threadIdx.x] != kNoStart)
+            startSample<S>(sc, pb, rp, blockIdx.x * kShadeBlock + start.lane[threadIdx.x], start.pix[threadIdx.x], start.pass[threadIdx.x]);
     }
-    // slots run out of passes only at the very end of a render() call, so this atomic is rare
-    const uint64_t mi = __ballot(becameIdle);
-    if (lane == 0 && mi) atomicAdd(&pb.activeSlots[0], (uint32_t)(0u - (uint32_t)__popcll(mi)));
 }
 
-// Start of a render() call: every slot of the shard is set to start its first sample with sample counter 0
-// (accumulators are kept unless asked: render() continues the image begun by render_begin()).
+// Start of a render window: every slot wants a sample (ST_REGEN), the queues are at their beginning.  `clearSensor`: the first
+// window after slrhip_render_begin also zeroes the sensor (later calls continue the image, like ImageSensor::add does).
 template <class S>
-__global__ void k_reset_slots(PathBuffers pb, RenderParams rp, uint32_t clearAccumulators) {
+__global__ void k_reset_slots(PathBuffers pb, RenderParams rp, uint32_t clearSensor) {
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;     // blockDim == kShadeBlock, numSlots = 256 x gridDim
-    const SlotAddr at = slotAddr(rp, slot);
-    pb.flags[slot] = F_MAKE((uint32_t)(at.valid ? ST_REGEN : ST_IDLE), 0u, 0u, 0u, 0u, 0u);
+    pb.flags[slot] = F_MAKE((uint32_t)ST_REGEN, 0u, 0u, 0u, 0u, 0u);
     pb.hdr[(size_t)slot * pb.hdrStride] = make_uint4(0u, 0u, 0u, 0u);
-    if (at.valid && at.stripe == 0) pb.nextSample[at.pix] = rp.stripes;
     pb.visible[slot] = 0;
-    if (threadIdx.x == 0) pb.blockDead[blockIdx.x] = 0u;
-    if (clearAccumulators) {
-        SpecIO<S>::store(pb.accR, nullptr, 2 * slot, 2 * rp.numSlots, S(), 0.0f);
-        SpecIO<S>::store(pb.accC, nullptr, 2 * slot, 2 * rp.numSlots, S(), 0.0f);
+    if (threadIdx.x == 0) { pb.blockDead[blockIdx.x] = 0u; pb.cursor[blockIdx.x] = 0u; }
+    if (clearSensor) {
+        constexpr uint32_t planes = S::N == 3 ? 1u : 4u;
+        for (size_t e = slot; e < (size_t)rp.numPixels * planes; e += (size_t)gridDim.x * blockDim.x) {
+            pb.fbSum[e] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            pb.fbComp[e] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
     }
     if (blockIdx.x == 0) {
         for (uint32_t k = threadIdx.x; k < 2 * kQueueSetWords; k += blockDim.x) pb.queueCount[k] = 0;
+        if (threadIdx.x < kShards) pb.idleShards[threadIdx.x * kCounterStride] = 0u;
         if (threadIdx.x == 0) {
-            pb.activeSlots[0] = rp.numPixels * rp.stripes; pb.errorWord[0] = rp.injectError ? ERR_QUEUE_OVERFLOW : 0u;
-            pb.tailMode[0] = 0u; pb.tailWords[0] = 0u; pb.tailWords[1] = 0u;
+            pb.activeSlots[0] = rp.numSlots; pb.errorWord[0] = rp.injectError ? ERR_QUEUE_OVERFLOW : 0u;
+            pb.tailMode[0] = 0u; pb.tailWords[0] = 0u; pb.tailWords[1] = 0u; pb.tailIdled[0] = 0u;
         }
     }
 }
 
-// ImageSensor read-out: [H][W][N] linear sums; stripes of one pixel are added in stripe order.
+// ImageSensor read-out: [H][W][N] linear sums.
 template <class S>
 __global__ void k_resolve(PathBuffers pb, RenderParams rp, float* dst) {
     const uint32_t pix = blockIdx.x * blockDim.x + threadIdx.x;
     if (pix >= rp.numPixels) return;
     const uint32_t xy = pb.pixelXY[pix];
     const uint32_t px = xy & 0xFFFFu, py = xy >> 16;
-    const uint32_t first = slotOf(rp, pix, 0u);
-    S sum;
-    float unusedW;
-    SpecIO<S>::load(pb.accR, nullptr, 2 * first, 2 * rp.numSlots, sum, unusedW);
-    for (uint32_t st = 1; st < rp.stripes; ++st) {
-        S b;
-        SpecIO<S>::load(pb.accR, nullptr, 2 * (first + st), 2 * rp.numSlots, b, unusedW);
-        sum = sum + b;
-    }
     float* o = dst + ((size_t)py * rp.imageWidth + px) * S::N;
+    if (S::N == 3) {
+        const float4 v = pb.fbSum[pix];
+        o[0] = v.x; o[1] = v.y; o[2] = v.z;
+    }
+    else {
 #pragma unroll
-    for (int i = 0; i < S::N; ++i) o[i] = sum.comp(i);
+        for (int k = 0; k < 4; ++k) {
+            const float4 v = pb.fbSum[(size_t)pix * 4 + k];
+            o[4 * k] = v.x; o[4 * k + 1] = v.y; o[4 * k + 2] = v.z; o[4 * k + 3] = v.w;
+        }
+    }
 }
 
 // ---- host-callable launchers -----------------------------------------------------------------------------------

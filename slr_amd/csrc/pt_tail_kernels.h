@@ -1,26 +1,18 @@
-// pt_tail_kernels.h — the end of a render call in ONE launch (gfx950, wave64).
+// pt_tail_kernels.h — the end of a render window in ONE launch (gfx950, wave64).
 //
-// Why: pixels whose paths are long hand out their passes more slowly than the others, and the longest single paths run ~100
-// bounces beyond the average, so the second half of the iterations of a frame advances an ever smaller number of live slots
-// (per-iteration logs, profiles/r02_g_iter_*.txt: 22 M slots, 7.7 M live after iteration 104 of 208, 0.9 M after 112, 4 600 after
-// 160), and each of those iterations still costs three launches that scan or skip every slot block: 38 of 394 ms at N = 1 and
-// 11 of 56 ms at the N = 8 shard size.
+// Why: the longest single paths run ~100 bounces beyond the average, so once the work queues are exhausted the last iterations of
+// a window advance an ever smaller number of live slots, and each of those iterations still costs two launches that scan or
+// skip every slot block.
 //
 // What: once at most RenderParams::tailSlots slots are live the wavefront stops (PathBuffers::tailMode) and
 //   k_tail_collect  lists the live slots (one atomic per workgroup);
 //   k_tail          gives every lane one listed slot and runs it until the slot has nothing left to do: per bounce the extension
 //                   ray and the pending shadow ray through the one-lane-per-ray traversal of pt_traverse.h, then logicSlot —
-//                   the very function k_shade calls; when the path ends, accumulateSample and, if the pixel has passes left,
-//                   startSample — what k_shade does for a finished path.  A lane whose slot went idle takes the next listed
-//                   one (one atomic per wave and refill).
-// Passes in the tail: a slot goes idle only when its pixel has run out of passes, so a pixel that still has some has all its K
-// stripes alive; stripe s takes the passes next + s, next + s + K, ... of its pixel (next = the pixel's counter when the tail
-// took over).  Which stripe renders which pass therefore still depends on path lengths only: frames stay reproducible, every
-// pass is rendered once, and the image differs from the pure wavefront schedule only in the grouping of a pixel's float sum
-// over its stripes — not at all with one stripe.  But when the tail takes over depends on the number of live slots, hence on
-// the shard size: with it the sum of the shards of a frame no longer equals the unsharded frame to the last bit at a fixed
-// stripe count (tests/test_gpu_parity.py::test_eight_tile_shards_...): with a fixed stripe count it is opt-in
-// (SLRHIP_FLAG_TAIL_KERNEL); with the automatic one — which itself depends on the shard size — it is always on.
+//                   the very function k_shade calls; when the path ends, writeResult and, if the queue of the slot's workgroup
+//                   has a sample left, startSample — what k_shade does for a finished path.  A lane whose slot went idle takes
+//                   the next listed one (one atomic per wave and refill).
+// A sample's contribution is a function of (pixel, pass) alone and the sensor adds the contributions in pass order (k_fold), so
+// the image is the same to the last bit whether the tail kernel or the wavefront kernels finish the window, at any slot count.
 #pragma once
 #include "pt_shade_kernels.h"
 #include "pt_traverse.h"
@@ -47,15 +39,14 @@ __global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(SLR
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t below = (1ull << lane) - 1ull;
     uint32_t slot = kTailNone;
-    uint32_t taken = 0;                                        // passes this lane's slot has started in the tail
     uint32_t extRays = 0, shadowRays = 0, wentIdle = 0;
     bool listDrained = false;                                  // wave-uniform: the cursor is past the end of the list
     TravCount cnt = {0, 0};
     uint32_t* stack = tlds.stack + threadIdx.x;
 
-    // <= 102 turns per sample; the passes a lane can still be handed are bounded by the call's pass count (a constant
+    // <= 102 turns per sample; the samples a lane can still be handed are bounded by the longest queue (a constant
     // bound failed one-lane renders of very many passes)
-    const uint64_t guardTurns = 104ull * ((uint64_t)rp.sppCount + 2ull) + 1024ull;
+    const uint64_t guardTurns = 104ull * ((uint64_t)(rp.numChunks / rp.numBlocks + 2u) * kWorkChunk + 2ull) + 1024ull;
     for (uint64_t guard = 0; guard < guardTurns; ++guard) {
         // ---- lanes without a path take the next listed ones: one atomic per wave and refill --------------------------------
         const uint64_t idle = __ballot(slot == kTailNone);
@@ -66,7 +57,7 @@ __global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(SLR
             start = __shfl(start, __ffsll((long long)idle) - 1);
             if (slot == kTailNone) {
                 const uint32_t i = start + (uint32_t)__popcll(idle & below);
-                if (i < n) { slot = list[i]; taken = 0; }
+                if (i < n) slot = list[i];
             }
             listDrained = start + want >= n;
         }
@@ -77,26 +68,21 @@ __global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(SLR
         const uint32_t state = F_STATE(flags);
         if (state == ST_IDLE) { slot = kTailNone; continue; }    // not expected (the list holds live slots): nothing to do
         if (state == ST_REGEN) {
-            // the path ended at this lane's last turn, or the slot has not started its first sample yet: sensor->add, next pass
-            uint32_t samplesDone = 0;
+            // the path ended at this lane's last turn, or the slot has not started a sample yet: the finished sample's result,
+            // then the next item of the queue of the slot's workgroup (by atomic: the lanes holding a workgroup's slots may be
+            // in different waves here)
             if (F_HASPATH(flags)) {
                 const uint4 hdr = pb.hdr[(size_t)slot * pb.hdrStride];
-                accumulateSample<S>(pb, rp, slot, flags, hdr, false, S());
-                samplesDone = hdr.x + 1u;
+                writeResult<S>(pb, rp, slot, flags, hdr, false, S());
             }
-            const SlotAddr at = slotAddr(rp, slot);
-            // a slot that has not started yet (possible only when the tail takes over at the first iteration) owns pass `stripe`
-            const uint32_t pass = F_HASPATH(flags) ? pb.nextSample[at.pix] + at.stripe + rp.stripes * taken : at.stripe;      // relative to sppBegin
-            if (pass >= rp.sppCount) {
+            const uint32_t block = slot / (uint32_t)kShadeBlock;
+            const WorkItem w = workItemOf(rp, block, atomicAdd(&pb.cursor[block], 1u));
+            if (!w.valid) {
                 pb.flags[slot] = F_MAKE((uint32_t)ST_IDLE, 0u, 0u, 0u, 0u, 0u);
                 ++wentIdle;
-                pb.hdr[(size_t)slot * pb.hdrStride] = make_uint4(samplesDone, 0u, 0u, 0u);
                 slot = kTailNone;
             }
-            else {
-                startSample<S>(sc, pb, rp, slot, at.pix, rp.sppBegin + pass, samplesDone);
-                if (F_HASPATH(flags)) ++taken;
-            }
+            else startSample<S>(sc, pb, rp, slot, w.pix, w.pass);
             continue;
         }
         // ---- one bounce: the two rays of this slot, then the logic visit -----------------------------------------------------
@@ -140,7 +126,7 @@ __global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(SLR
     if (threadIdx.x == 0) {
         if (e) atomicAdd((unsigned long long*)&pb.totals[totalIndex(T_EXT_RAYS, blockIdx.x % kShards)], (unsigned long long)e);
         if (sh) atomicAdd((unsigned long long*)&pb.totals[totalIndex(T_SHADOW_RAYS, blockIdx.x % kShards)], (unsigned long long)sh);
-        if (idleNow) atomicAdd(&pb.activeSlots[0], 0u - idleNow);
+        if (idleNow) atomicAdd(&pb.tailIdled[0], idleNow);      // the host checks it against the list length, then clears the live count
     }
 }
 

@@ -649,8 +649,10 @@ template <bool COUNT, int NC, bool QUANT, bool WIDE8 = false, bool INST = false>
 __global__ __launch_bounds__(64 * (NC + 1)) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_trace_ws(DevScene sc, PathBuffers pb, uint32_t numSlots, uint32_t shardCapacity, uint32_t parity, uint32_t refill,
                                                                                                               uint32_t tailSlots) {
     __shared__ WsLds<NC> lds;
-    if (pb.activeSlots[0] == 0) return;            // every slot is out of passes (uniform): nothing to trace
-    if (tailModeBegins(pb, tailSlots, parity)) return;      // the last paths go to the tail kernel (uniform over the grid, pt_kernels.h)
+    const uint32_t live = liveSlots(pb, numSlots);                                   // as of the end of the k_shade launch before this one (uniform)
+    if (blockIdx.x == 0 && threadIdx.x == 0) pb.activeSlots[0] = live;               // for the next k_shade launch and the host
+    if (live == 0) return;                         // every slot is idle: nothing to trace
+    if (tailModeBegins(pb, live, tailSlots, parity)) return;      // the last paths go to the tail kernel (uniform over the grid, pt_kernels.h)
     if (blockIdx.x == 0 && threadIdx.x < Q_KINDS * kShards) {
         // clear the counter set the logic kernel of this iteration fills
         pb.queueCount[queueCounterIndex(parity ^ 1, threadIdx.x / kShards, threadIdx.x % kShards)] = 0;

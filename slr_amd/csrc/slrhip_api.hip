@@ -146,10 +146,11 @@ struct slrhip_ctx {
     RenderParams params;
     DevArray<uint32_t> pixelXY;
     DevArray<uint4> rng;
-    DevArray<float4> rayOrg, rayDir, hit, alpha, spR, spC, accR, accC, nee, shadowDir;
+    DevArray<float4> rayOrg, rayDir, hit, alpha, spR, spC, nee, shadowDir;
+    DevArray<float4> results, fbSum, fbComp;      // result window of the current render call; the sensor (per-pixel Kahan sums)
+    DevArray<uint32_t> cursor, idleShards;
     DevArray<float> pdfPrev;
     DevArray<uint4> hdr;
-    DevArray<uint32_t> nextSample;
     DevArray<int32_t> hitInstance;
     DevArray<uint32_t> flags, visible, shadowQueue, tailList, queueCount, activeSlots, blockDead;
     DevArray<uint64_t> totals;
@@ -841,10 +842,8 @@ int slrhip_render_begin(slrhip_ctx* ctx, const slrhip_render_settings* st, slrhi
         if (numPixels == 0) stripes = 1u;
         if (envStripes >= 1 && envStripes <= 64) stripes = (uint32_t)envStripes;
     }
-    // Slot layout (pt_kernels.h, slotAddr): shade workgroup b holds the `stripes` slots of each of its 256 / stripes pixels
-    const uint32_t pixelsPerBlock = 256u / stripes;
-    const size_t numBlocksLayout = ((size_t)numPixels + pixelsPerBlock - 1) / pixelsPerBlock;
-    const size_t numSlots = std::max<size_t>(numBlocksLayout, 1) * 256u;
+    // Slots are paths in flight, not places in the image (pt_kernels.h): `stripes` only sizes their number
+    const size_t numSlots = std::max<size_t>(((size_t)numPixels * stripes + 255u) / 256u, 1) * 256u;
     if (numSlots > 0x7FFFFFFFull) return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_render_begin: too many path slots");
 
     const bool spectral = ctx->config.mode == SLRHIP_MODE_SPECTRAL;
@@ -856,11 +855,12 @@ int slrhip_render_begin(slrhip_ctx* ctx, const slrhip_render_settings* st, slrhi
     const uint32_t rayStride = (envPairs & 1) ? 2u : 1u, spStride = (envPairs & 2) ? 2u : 1u, hdrStride = (envPairs & 4) ? 2u : 1u;
     HIP_TRY(ctx->rayOrg.alloc(numSlots * rayStride, true)); HIP_TRY(ctx->rayDir.alloc(rayStride == 2 ? 1 : numSlots, true)); HIP_TRY(ctx->hit.alloc(numSlots, true));
     HIP_TRY(ctx->alpha.alloc(numSlots * planes, true)); HIP_TRY(ctx->spR.alloc(numSlots * planes * spStride, true)); HIP_TRY(ctx->spC.alloc(spStride == 2 ? 1 : numSlots * planes, true));
-    HIP_TRY(ctx->accR.alloc(2 * numSlots * planes, true));      /* accR and accC interleaved */ HIP_TRY(ctx->nee.alloc(numSlots * planes, true));
+    HIP_TRY(ctx->fbSum.alloc((size_t)std::max(numPixels, 1u) * planes, true)); HIP_TRY(ctx->fbComp.alloc((size_t)std::max(numPixels, 1u) * planes, true));
+    HIP_TRY(ctx->nee.alloc(numSlots * planes, true));
     HIP_TRY(ctx->shadowDir.alloc(numSlots, true));
     HIP_TRY(ctx->pdfPrev.alloc(spectral ? numSlots : 1, true));
     HIP_TRY(ctx->hdr.alloc(numSlots * hdrStride, true)); HIP_TRY(ctx->rng.alloc(hdrStride == 2 ? 1 : numSlots, true));
-    HIP_TRY(ctx->nextSample.alloc((size_t)numPixels + 1, true));
+    HIP_TRY(ctx->cursor.alloc(numSlots / 256u)); HIP_TRY(ctx->idleShards.alloc(kShards * kCounterStride));
     HIP_TRY(ctx->flags.alloc(numSlots, true)); HIP_TRY(ctx->visible.alloc(numSlots, true));
     if (ctx->scene.instances) HIP_TRY(ctx->hitInstance.alloc(numSlots, true));
     // queue regions: slot block b appends to region b % kShards, so a region holds at most ceil(numBlocks / kShards) blocks
@@ -883,18 +883,17 @@ int slrhip_render_begin(slrhip_ctx* ctx, const slrhip_render_settings* st, slrhi
     PathBuffers& pb = ctx->buffers;
     pb.rng = hdrStride == 2 ? ctx->hdr.ptr + 1 : ctx->rng.ptr; pb.hdrStride = hdrStride; pb.rayOrg = ctx->rayOrg.ptr; pb.rayDir = rayStride == 2 ? ctx->rayOrg.ptr + 1 : ctx->rayDir.ptr; pb.hit = ctx->hit.ptr;
     pb.rayStride = rayStride; pb.spStride = spStride;
-    pb.alpha = ctx->alpha.ptr; pb.spR = ctx->spR.ptr; pb.spC = spStride == 2 ? ctx->spR.ptr + 1 : ctx->spC.ptr; pb.accR = ctx->accR.ptr; pb.accC = ctx->accR.ptr + 1;
+    pb.alpha = ctx->alpha.ptr; pb.spR = ctx->spR.ptr; pb.spC = spStride == 2 ? ctx->spR.ptr + 1 : ctx->spC.ptr; pb.fbSum = ctx->fbSum.ptr; pb.fbComp = ctx->fbComp.ptr; pb.results = ctx->results.ptr; pb.cursor = ctx->cursor.ptr;
     pb.nee = ctx->nee.ptr;
-    pb.pdfPrev = spectral ? ctx->pdfPrev.ptr : nullptr; pb.hdr = ctx->hdr.ptr; pb.nextSample = ctx->nextSample.ptr; pb.shadowDir = ctx->shadowDir.ptr; pb.flags = ctx->flags.ptr;
+    pb.pdfPrev = spectral ? ctx->pdfPrev.ptr : nullptr; pb.hdr = ctx->hdr.ptr; pb.shadowDir = ctx->shadowDir.ptr; pb.flags = ctx->flags.ptr;
     pb.hitInstance = ctx->scene.instances ? ctx->hitInstance.ptr : nullptr;
     pb.visible = ctx->visible.ptr; pb.shadowQueue = ctx->shadowQueue.ptr; pb.tailList = ctx->tailList.ptr;
-    pb.queueCount = ctx->queueCount.ptr; pb.activeSlots = ctx->activeSlots.ptr; pb.errorWord = ctx->activeSlots.ptr + 1; pb.tailMode = ctx->activeSlots.ptr + 3; pb.tailWords = ctx->activeSlots.ptr + 4; pb.blockDead = ctx->blockDead.ptr; pb.totals = ctx->totals.ptr;
+    pb.queueCount = ctx->queueCount.ptr; pb.activeSlots = ctx->activeSlots.ptr; pb.errorWord = ctx->activeSlots.ptr + 1; pb.tailMode = ctx->activeSlots.ptr + 3; pb.tailWords = ctx->activeSlots.ptr + 4; pb.tailIdled = ctx->activeSlots.ptr + 2; pb.idleShards = ctx->idleShards.ptr; pb.blockDead = ctx->blockDead.ptr; pb.totals = ctx->totals.ptr;
     pb.pixelXY = ctx->pixelXY.ptr;
 
     RenderParams& rp = ctx->params;
-    rp.numSlots = numPixels ? (uint32_t)numSlots : 0u; rp.numPixels = numPixels; rp.stripes = stripes;
-    rp.pixelsPerBlock = pixelsPerBlock; rp.stripesRecip = (65536u + stripes - 1u) / stripes;
-    rp.sppBegin = 0; rp.sppCount = 0;
+    rp.numSlots = numPixels ? (uint32_t)numSlots : 0u; rp.numBlocks = rp.numSlots / 256u; rp.numPixels = numPixels; rp.stripes = stripes;
+    rp.sppBegin = 0; rp.sppCount = 0; rp.workItems = 0; rp.numChunks = 0;
     rp.rngSeed = st->rng_seed; rp.timeStart = st->time_start; rp.timeEnd = st->time_end;
     rp.imageWidth = W; rp.imageHeight = H;
     rp.countSlots = (ctx->config.flags & SLRHIP_FLAG_COUNT_TRAVERSAL) ? 1u : 0u;
@@ -909,34 +908,32 @@ int slrhip_render_begin(slrhip_ctx* ctx, const slrhip_render_settings* st, slrhi
     return SLRHIP_OK;
 }
 
-int slrhip_render(slrhip_ctx* ctx, uint32_t sppBegin, uint32_t sppCount, void* streamPtr) {
-    if (!ctx) return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_render: null context");
-    if (!ctx->haveRender) return fail(SLRHIP_ERR_NO_SCENE, "slrhip_render: call slrhip_render_begin first");
-    HIP_TRY(hipSetDevice(ctx->device));
-    hipStream_t stream = (hipStream_t)streamPtr;
+// One window of passes [sppBegin, sppBegin + sppCount): every sample of the window rendered into the result window, then folded
+// into the sensor in pass order.  slrhip_render sizes the windows.
+static int renderWindow(slrhip_ctx* ctx, uint32_t sppBegin, uint32_t sppCount, hipStream_t stream) {
     RenderParams& rp = ctx->params;
     rp.sppBegin = sppBegin;
     rp.sppCount = sppCount;
-    if (rp.numSlots == 0) { ctx->firstRenderCall = false; return SLRHIP_OK; }
+    rp.workItems = rp.numPixels * sppCount;                        // < 2^32: slrhip_render
+    rp.numChunks = (uint32_t)(((uint64_t)rp.workItems + kWorkChunk - 1) / kWorkChunk);
 
-    // the first call after render_begin also clears the pixel accumulators (the buffers are reused across render_begin calls),
-    // even when it is asked for zero passes
+    // the first window after render_begin also clears the sensor (the buffers are reused across render_begin calls), even when
+    // it is asked for zero passes
     launchResetSlots(ctx->buffers, rp, ctx->firstRenderCall, stream);
     ctx->firstRenderCall = false;
     if (sppCount == 0) return SLRHIP_OK;
     // persistent traversal workgroups of the wave-specialised kernel (pt_trace_ws.hip): a fixed number per CU
     const uint32_t traceBlocks = (uint32_t)ctx->numCUs * (uint32_t)traceWsBlocksPerCU(ctx->scene.nodesQ != nullptr);
 
-    uint32_t active = rp.numPixels * rp.stripes;
-    uint32_t status[4] = {active, 0u, 0u, 0u};       // device words: live slots, error bits, -, tail mode (PathBuffers)
-    // The end of the call (pt_tail_kernels.h): once at most tailSlots slots are alive the traversal kernel raises the tail-mode
+    uint32_t active = rp.numSlots;
+    uint32_t status[4] = {active, 0u, 0u, 0u};       // device words: live slots, error bits, slots idled by the tail kernel, tail mode (PathBuffers)
+    // The end of the window (pt_tail_kernels.h): once at most tailSlots slots are alive the traversal kernel raises the tail-mode
     // word instead of tracing, the rest of the block of iterations is no-ops, and the tail kernel finishes every remaining path
-    // and pass in one launch.  ON when the stripe count is automatic (slrhip_config::stripes = 0: the grouping of a pixel's float
-    // sum over its stripes then depends on the shard size anyway), on request otherwise (SLRHIP_FLAG_TAIL_KERNEL,
-    // SLRHIP_TAIL_SLOTS=n): a caller who fixes the stripe count keeps the property that the shards of a frame sum to the
-    // unsharded frame bit for bit.  Never for more than an eighth of the slots (the wavefront kernels are the efficient way to
-    // advance many paths; with fewer than 8 slots the tail stays off) and not in the counting build (its per-ray figures come
-    // from the wavefront kernels).  SLRHIP_TAIL_SLOTS=0 turns it off.
+    // and sample in one launch.  The image does not depend on who finishes a sample (the sensor adds in pass order).  On with
+    // the automatic slot count (slrhip_config::stripes = 0) and on request (SLRHIP_FLAG_TAIL_KERNEL, SLRHIP_TAIL_SLOTS=n); a
+    // caller who fixes the slot count gets the pure wavefront schedule unless he asks (the parity tests compare the two).  Never
+    // for more than an eighth of the slots (the wavefront kernels are the efficient way to advance many paths) and not in the
+    // counting build (its per-ray figures come from the wavefront kernels).  SLRHIP_TAIL_SLOTS=0 turns it off.
     static const long envTail = [] { const char* e = getenv("SLRHIP_TAIL_SLOTS"); return e ? atol(e) : -1L; }();
     {
         const bool asked = (ctx->config.flags & SLRHIP_FLAG_TAIL_KERNEL) != 0 || envTail > 0 || ctx->config.stripes == 0;
@@ -964,9 +961,12 @@ int slrhip_render(slrhip_ctx* ctx, uint32_t sppBegin, uint32_t sppCount, void* s
             (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
         }
         if (status[1]) return deviceError(status[1]);
-        if (status[0] != 0)
-            return fail(SLRHIP_ERR_HIP, "slrhip_render: the tail kernel left " + std::to_string(status[0]) + " live slots of " + std::to_string(liveBefore) +
-                                            " (listed " + std::to_string(words[4]) + ", cursor " + std::to_string(words[5]) + "; internal error)");
+        if (words[2] != words[4])
+            return fail(SLRHIP_ERR_HIP, "slrhip_render: the tail kernel left " + std::to_string(words[4] - words[2]) + " of " + std::to_string(words[4]) +
+                                            " listed slots live (live count before: " + std::to_string(liveBefore) + ", cursor " + std::to_string(words[5]) + "; internal error)");
+        // every listed slot ended idle and the wavefront kernels are off (tail mode): nothing is live any more
+        HIP_TRY(hipMemsetAsync(ctx->activeSlots.ptr, 0, sizeof(uint32_t), s));
+        status[0] = 0;
         return SLRHIP_OK;
     };
     // One wavefront iteration = k_shade (advance every live path by one vertex; finish and restart the paths that end) then
@@ -980,7 +980,7 @@ int slrhip_render(slrhip_ctx* ctx, uint32_t sppBegin, uint32_t sppCount, void* s
         ctx->events.resize((size_t)kCheckEvery * kEv);
         for (hipEvent_t& e : ctx->events) HIP_TRY(hipEventCreate(&e));
     }
-    const uint64_t maxIterations = (uint64_t)(sppCount / rp.stripes + 2) * 128 + 1024;   // paths are <= 100 vertices long
+    const uint64_t maxIterations = ((uint64_t)rp.workItems / rp.numSlots + 2) * 128 + 1024;   // paths are <= 100 vertices long
     uint64_t it = 0;
 
     // The block of kCheckEvery iterations is the same sequence of launches every time (the parity alternates inside it and is
@@ -1026,7 +1026,8 @@ int slrhip_render(slrhip_ctx* ctx, uint32_t sppBegin, uint32_t sppCount, void* s
         (void)hipGraphDestroy(graph);
         if (rc != SLRHIP_OK) return rc;
         ctx->iterations += it;
-        launchCountSamples(ctx->buffers, rp, ws);      // samples accumulated by this call, counted on the device (T_SAMPLES)
+        launchCountSamples(ctx->buffers, rp, ws);      // samples rendered in this window, counted on the device (T_SAMPLES)
+        launchFold(ctx->buffers, rp, ws);              // sensor->add, in pass order
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(ws));
         return SLRHIP_OK;
@@ -1076,7 +1077,8 @@ int slrhip_render(slrhip_ctx* ctx, uint32_t sppBegin, uint32_t sppCount, void* s
         if (it > maxIterations) return fail(SLRHIP_ERR_HIP, "slrhip_render: iteration bound exceeded (internal error)");
     }
     ctx->iterations += it;
-    launchCountSamples(ctx->buffers, rp, stream);       // samples accumulated by this call, counted on the device (T_SAMPLES)
+    launchCountSamples(ctx->buffers, rp, stream);       // samples rendered in this window, counted on the device (T_SAMPLES)
+    launchFold(ctx->buffers, rp, stream);               // sensor->add, in pass order
     HIP_TRY(hipGetLastError());
     if (iterLog && timeKernels && !iterActive.empty()) {
         if (FILE* f = fopen(iterLog, "a")) {
@@ -1089,6 +1091,31 @@ int slrhip_render(slrhip_ctx* ctx, uint32_t sppBegin, uint32_t sppCount, void* s
             }
             fclose(f);
         }
+    }
+    return SLRHIP_OK;
+}
+
+int slrhip_render(slrhip_ctx* ctx, uint32_t sppBegin, uint32_t sppCount, void* streamPtr) {
+    if (!ctx) return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_render: null context");
+    if (!ctx->haveRender) return fail(SLRHIP_ERR_NO_SCENE, "slrhip_render: call slrhip_render_begin first");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t stream = (hipStream_t)streamPtr;
+    RenderParams& rp = ctx->params;
+    if (rp.numSlots == 0) { ctx->firstRenderCall = false; return SLRHIP_OK; }
+    // The result window (PathBuffers::results) holds one entry per pixel and pass: 16 B (RGB) / 64 B (spectral).  A call of more
+    // passes than fit the budget — 16 GiB by default, SLRHIP_RESULT_WINDOW_MB overrides — or than 2^32 samples is rendered as
+    // several windows, one after the other; the sensor adds in pass order either way, so the image does not depend on the split.
+    const uint64_t entryBytes = (rp.spectral ? 4u : 1u) * sizeof(float4);
+    uint64_t budget = 16ull << 30;
+    if (const char* e = getenv("SLRHIP_RESULT_WINDOW_MB")) { const long mb = atol(e); if (mb > 0) budget = (uint64_t)mb << 20; }
+    const uint64_t maxPasses = std::max<uint64_t>(1, std::min<uint64_t>(budget / ((uint64_t)rp.numPixels * entryBytes), 0xFFFFFFFFull / rp.numPixels));
+    const uint32_t window = (uint32_t)std::min<uint64_t>(maxPasses, std::max<uint32_t>(sppCount, 1u));
+    HIP_TRY(ctx->results.alloc((size_t)window * rp.numPixels * (rp.spectral ? 4u : 1u)));
+    ctx->buffers.results = ctx->results.ptr;
+    if (sppCount == 0) return renderWindow(ctx, sppBegin, 0, stream);
+    for (uint32_t done = 0; done < sppCount; done += window) {
+        const int rc = renderWindow(ctx, sppBegin + done, std::min(window, sppCount - done), stream);
+        if (rc != SLRHIP_OK) return rc;
     }
     return SLRHIP_OK;
 }
