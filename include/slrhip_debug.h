@@ -23,6 +23,14 @@ extern "C" {
 int slrhip_bsdf_queries(slrhip_ctx* ctx, uint32_t material, uint32_t n, const float* queries,
                         float wl_offset, float u_lambda, float* out);
 
+/* The work distribution of a render window (slr_amd/csrc/pt_kernels.h, WorkItem), evaluated on the HOST with the very function
+ * the kernels call: the samples (pixel, pass) of a window of `num_passes` passes over `num_pixels` pixels are dealt to the
+ * `num_slots / 64` wave queues in runs of `run_length` passes of a pixel.  counts[pass * num_pixels + pixel] receives how many
+ * times the sample comes up over all queues (the caller checks: exactly once); queue_lengths[wave] the samples of each queue.
+ * No GPU is touched.  Returns SLRHIP_OK, or SLRHIP_ERR_INVALID_ARGUMENT when run_length does not divide num_passes.            */
+int slrhip_debug_work_distribution(uint32_t num_pixels, uint32_t num_slots, uint32_t num_passes, uint32_t run_length,
+                                   uint32_t* counts, uint32_t* queue_lengths);
+
 #ifdef __cplusplus
 }
 #endif

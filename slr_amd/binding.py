@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(CSRC, "libslrhip.so")
 
 EXPORTS = ["slrhip_create", "slrhip_destroy", "slrhip_upload_scene", "slrhip_render_begin", "slrhip_render",
            "slrhip_resolve_framebuffer", "slrhip_reduce_framebuffer", "slrhip_read_framebuffer", "slrhip_synchronize", "slrhip_get_counters",
-           "slrhip_components", "slrhip_get_profile", "slrhip_trace_rays", "slrhip_bsdf_queries", "slrhip_sample_seed", "slrhip_upsample", "slrhip_resolve_upsampled", "slrhip_spectrum_to_rgb", "slrhip_tonemap_bgr8", "slrhip_save_bmp",
+           "slrhip_components", "slrhip_get_profile", "slrhip_trace_rays", "slrhip_bsdf_queries", "slrhip_debug_work_distribution", "slrhip_sample_seed", "slrhip_upsample", "slrhip_resolve_upsampled", "slrhip_spectrum_to_rgb", "slrhip_tonemap_bgr8", "slrhip_save_bmp",
            "slrhip_last_error_string", "slrhip_version"]
 
 

@@ -97,7 +97,7 @@ static const uint32_t kTotalStride = 16;                   // 64-bit words: one 
 __host__ __device__ inline uint32_t totalIndex(uint32_t kind, uint32_t shard) { return (kind * kShards + shard) * kTotalStride; }
 
 // Path state, SoA, one record per slot.  A slot is a path in flight, NOT a place in the image: whenever its path ends it takes the
-// next sample — a (pixel, pass) pair — from the work queue of its shade workgroup (WorkItem below) and writes the finished
+// next sample — a (pixel, pass) pair — from the work queue of its wave of the shade kernel (WorkItem below) and writes the finished
 // sample's contribution to the result window; the sensor's per-pixel Kahan sum (ImageSensor::add, in pass order) is done by
 // k_fold once the window's passes are complete.  The image therefore does not depend on the number of slots, on which slot
 // rendered which sample or on the shard size, and the slots stay busy until the LAST sample of the call has been handed out.
@@ -126,9 +126,9 @@ struct PathBuffers {
     // relative to the first pass of the window
     uint4* hdr;
     uint32_t* flags;
-    // Work queues (WorkItem below): per shade workgroup the number of samples it has taken from its queue so far.  Read and
-    // advanced by that workgroup alone in k_shade (no atomics); by atomics in the tail kernel, where lanes of several workgroups
-    // hold a block's slots.
+    // Work queues (WorkItem below): per wave of the shade kernel (64 slots) the number of samples it has taken from its queue so
+    // far.  Read and advanced by that wave alone in k_shade (no atomics); by atomics in the tail kernel, where the slots of a
+    // wave may be held by lanes of several waves.
     uint32_t* cursor;
     uint32_t* visible;            // result of the shadow ray
     uint32_t* shadowQueue;        // kShards regions of shardCapacity slot indices: shadow rays of this iteration
@@ -168,7 +168,9 @@ struct RenderParams {
     uint32_t numPixels, stripes;  // stripes: slots per pixel the slot count was sized for (slrhip_config::stripes or the automatic choice)
     uint32_t sppBegin, sppCount;  // the passes of the current window
     uint32_t workItems;           // numPixels x sppCount (< 2^32: slrhip_render sizes the windows)
-    uint32_t numChunks;           // ceil(workItems / kWorkChunk)
+    uint32_t numWaves;            // numSlots / 64: the owners of the work queues
+    uint32_t runLength;           // passes per run (divides sppCount)
+    uint32_t numRuns;             // runs of the window = numPixels x sppCount / runLength
     int32_t rngSeed;
     float timeStart, timeEnd;
     uint32_t imageWidth, imageHeight;
@@ -179,44 +181,43 @@ struct RenderParams {
     uint32_t tailSlots;           // enter tail mode once at most this many slots are live; 0 = never
 };
 
-// Work distribution.  An item is one sample: id = pass-of-window x numPixels + pixel, so 64 consecutive ids are one 8 x 8 tile
-// of one pass (the shard's pixel list is tile-major).  Ids are dealt to the shade workgroups in chunks of kWorkChunk: the j-th
-// chunk of workgroup b is chunk j x numBlocks + (b + j x kWorkRotate) mod numBlocks — every chunk belongs to exactly one
-// workgroup, a workgroup's chunks lie one per "round" of numBlocks chunks, and the rotation walks each workgroup over the
-// image, so that every queue is a sample of the whole frame (queue lengths differ by at most one chunk; their work, the sum of
-// ~(workItems / numBlocks) path lengths drawn all over the image, by a per cent or two).  Static queues need no global counter:
-// one word that every workgroup bumps saturates near 88 atomics per microsecond (above).  Lanes that restart in the same
-// launch take consecutive items, i.e. neighbouring pixels of one pass.
-static const uint32_t kWorkChunk = 64;
+// Work distribution.  An item is one sample, a (pixel, pass) pair.  The unit that is dealt out is a RUN: runLength consecutive
+// passes of ONE pixel.  Run r = (pass group, pixel) with the pixel fastest; queues belong to WAVES of the shade kernel (64
+// consecutive slots): the j-th run of wave w is run j x numWaves + (w + j x kWorkRotate) mod numWaves — every run belongs to
+// exactly one wave, and the rotation walks each wave over the image, so that its queue is a sample of the whole frame and the
+// queues carry the same work to within a few per cent.  The lanes of a wave that need a sample take the next items of the
+// wave's queue in lane order, so the 64 slots of a wave hold passes of one pixel (two while it moves on): their camera rays are
+// all but identical and their first bounces start in the same place, which is what keeps the lanes of a traversal wave in step
+// (measured: with the slots of a wave spread over an 8 x 8 tile the traversal launch took 2.1 ms instead of 1.76).  Static
+// queues need no global counter: one word that every wave bumps saturates near 88 atomics per microsecond (above).
 static const uint32_t kWorkRotate = 40503u;
 struct WorkItem {
     uint32_t pix, pass;           // pass relative to RenderParams::sppBegin
     bool valid;                   // false: the queue is exhausted (every later item of this queue is invalid too)
 };
-__host__ __device__ inline WorkItem workItemOf(const RenderParams& rp, uint32_t block, uint32_t taken) {
-    const uint32_t j = taken / kWorkChunk;
+__host__ __device__ inline uint32_t workRun(const RenderParams& rp, uint32_t wave, uint32_t j) {
+    return j * rp.numWaves + (uint32_t)(((uint64_t)wave + (uint64_t)j * kWorkRotate) % rp.numWaves);
+}
+__host__ __device__ inline WorkItem workItemOf(const RenderParams& rp, uint32_t wave, uint32_t taken) {
+    const uint32_t j = taken / rp.runLength, r = taken - j * rp.runLength;
     WorkItem w;
     w.pix = 0; w.pass = 0; w.valid = false;
-    if (j > rp.numChunks / rp.numBlocks) return w;                                   // (also keeps j x numBlocks inside 32 bits)
-    const uint32_t chunk = j * rp.numBlocks + (uint32_t)(((uint64_t)block + (uint64_t)j * kWorkRotate) % rp.numBlocks);
-    if (chunk >= rp.numChunks) return w;
-    const uint64_t id = (uint64_t)chunk * kWorkChunk + (taken % kWorkChunk);
-    if (id >= rp.workItems) return w;
-    w.pass = (uint32_t)(id / rp.numPixels);
-    w.pix = (uint32_t)(id - (uint64_t)w.pass * rp.numPixels);
+    if (j > rp.numRuns / rp.numWaves) return w;                                      // (also keeps j x numWaves inside 32 bits)
+    const uint32_t run = workRun(rp, wave, j);
+    if (run >= rp.numRuns) return w;
+    const uint32_t group = run / rp.numPixels;
+    w.pix = run - group * rp.numPixels;
+    w.pass = group * rp.runLength + r;
     w.valid = true;
     return w;
 }
-// Items in the queue of a workgroup (what its cursor can usefully reach).
-__host__ __device__ inline uint32_t workQueueLength(const RenderParams& rp, uint32_t block) {
-    uint32_t n = 0;
-    for (uint32_t j = 0; j <= rp.numChunks / rp.numBlocks; ++j) {
-        const uint32_t chunk = j * rp.numBlocks + (uint32_t)(((uint64_t)block + (uint64_t)j * kWorkRotate) % rp.numBlocks);
-        if (chunk >= rp.numChunks) continue;
-        const uint64_t first = (uint64_t)chunk * kWorkChunk;
-        n += (uint32_t)((rp.workItems - first) < kWorkChunk ? (rp.workItems - first) : kWorkChunk);
-    }
-    return n;
+// Samples among the first `taken` items of a wave's queue (what k_count_samples adds up: a cursor runs past the end of its
+// queue by the lanes that found nothing).
+__host__ __device__ inline uint32_t workSamplesTaken(const RenderParams& rp, uint32_t wave, uint32_t taken) {
+    uint32_t runs = 0;
+    for (uint32_t j = 0; j <= rp.numRuns / rp.numWaves; ++j) if (workRun(rp, wave, j) < rp.numRuns) ++runs;
+    const uint32_t length = runs * rp.runLength;
+    return taken < length ? taken : length;
 }
 
 // Evaluated by every workgroup of the traversal launch of an iteration: its input is stable during that launch (activeSlots

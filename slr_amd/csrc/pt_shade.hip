@@ -29,13 +29,13 @@ void launchBsdfQueries(const DevScene& sc, bool spectral, uint32_t material, uin
     if (spectral) hipLaunchKernelGGL(k_bsdf_queries<Spec16>, grid, block, 0, stream, sc, material, n, in, wlOffset, wl, geo, misc, fsSample, fsEval);
     else hipLaunchKernelGGL(k_bsdf_queries<RGB>, grid, block, 0, stream, sc, material, n, in, wlOffset, wl, geo, misc, fsSample, fsEval);
 }
-// Samples rendered in the window that just ended = what the workgroups took from their queues (PathBuffers::cursor, capped at
+// Samples rendered in the window that just ended = what the waves took from their queues (PathBuffers::cursor, capped at
 // the queue's length: a cursor runs past the end by the lanes that found nothing).  This is the device's own account of the
 // work handed out — the host's numPixels x passes would be a tautology.  One atomic per workgroup on the sharded totals.
 __global__ __launch_bounds__(kShadeBlock) void k_count_samples(PathBuffers pb, RenderParams rp) {
     __shared__ uint32_t red[kShadeBlock / 64];
     uint32_t n = 0;
-    for (uint32_t b = blockIdx.x * kShadeBlock + threadIdx.x; b < rp.numBlocks; b += gridDim.x * kShadeBlock) n += min(pb.cursor[b], workQueueLength(rp, b));
+    for (uint32_t w = blockIdx.x * kShadeBlock + threadIdx.x; w < rp.numWaves; w += gridDim.x * kShadeBlock) n += workSamplesTaken(rp, w, pb.cursor[w]);
     for (int off = 32; off > 0; off >>= 1) n += __shfl_down(n, off);
     if ((threadIdx.x & 63u) == 0) red[threadIdx.x >> 6] = n;
     __syncthreads();
@@ -80,7 +80,7 @@ void launchFold(const PathBuffers& pb, const RenderParams& rp, hipStream_t strea
 }
 void launchCountSamples(const PathBuffers& pb, const RenderParams& rp, hipStream_t stream) {
     if (rp.numSlots == 0) return;
-    const uint32_t blocks = std::min<uint32_t>((rp.numBlocks + kShadeBlock - 1) / kShadeBlock, 2048u);
+    const uint32_t blocks = std::min<uint32_t>((rp.numWaves + kShadeBlock - 1) / kShadeBlock, 2048u);
     hipLaunchKernelGGL(k_count_samples, dim3(blocks), dim3(kShadeBlock), 0, stream, pb, rp);
 }
 void launchResolve(const PathBuffers& pb, const RenderParams& rp, float* dst, hipStream_t stream) {

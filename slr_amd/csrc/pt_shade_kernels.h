@@ -969,13 +969,12 @@ __device__ __forceinline__ void writeResult(const PathBuffers& pb, const RenderP
 
 // What the finishing lanes of a k_shade workgroup hand to its first lanes: the samples to start.
 struct StartLds {
-    uint32_t lane[kShadeBlock];                 // compacted: slot = workgroup base + lane; kNoStart = the queue had nothing left for it
+    uint32_t lane[kShadeBlock];                 // compacted: slot = workgroup base + lane
     uint32_t pix[kShadeBlock];
     uint32_t pass[kShadeBlock];
     uint32_t waveBase[kShadeBlock / 64 + 1];
     uint32_t wentIdle;                          // lanes of the workgroup that found the queue exhausted in this launch
 };
-static const uint32_t kNoStart = 0xFFFFFFFFu;
 
 #ifndef SLR_SHADE_EARLY
 #define SLR_SHADE_EARLY 1          // 0 (variant builds): the slot's state records are requested after the table barrier
@@ -996,7 +995,7 @@ __attribute__((amdgpu_waves_per_eu(S::N == 3 ? SLR_WAVES_RGB : (MF ? SLR_WAVES_S
         const uint32_t liveSlots = pb.activeSlots[0], tailMode = pb.tailMode[0], dead = pb.blockDead[blockIdx.x];
         if ((liveSlots == 0u) | (tailMode != 0u) | (dead != 0u)) return;
     }
-    const uint32_t taken = pb.cursor[blockIdx.x];                         // samples this workgroup has taken from its queue (uniform)
+
     // ONE round trip for everything the visit needs that does not depend on the slot's state: flags, visibility word, the pixel's
     // pool counter, the state records (SlotLoads) and the tables staged below; ONE barrier publishes the tables and decides
     // whether the block has any work left.  (SLR_SHADE_EARLY 0, variant builds: the state records are requested after the barrier.)
@@ -1005,6 +1004,8 @@ __attribute__((amdgpu_waves_per_eu(S::N == 3 ? SLR_WAVES_RGB : (MF ? SLR_WAVES_S
     SlotLoads<S> in;
     if (SLR_SHADE_EARLY) in.issue(sc, pb, rp, slot);
     const uint32_t state0 = F_STATE(flags);
+    const uint32_t globalWave = blockIdx.x * (kShadeBlock / 64) + wave;
+    const uint32_t taken = pb.cursor[globalWave];                         // samples this wave has taken from its queue (wave-uniform)
     if (threadIdx.x == 0) start.wentIdle = 0u;
     if (LDS_TABLES) stageShadeTables<S::N != 3>(sc, lds);
     {
@@ -1038,35 +1039,38 @@ __attribute__((amdgpu_waves_per_eu(S::N == 3 ? SLR_WAVES_RGB : (MF ? SLR_WAVES_S
     }
 
     // ---- the next sample of every slot that needs one (its path ended, or it has not started yet: ST_REGEN after k_reset_slots):
-    //      the wanting lanes, in lane order, take the next items of the workgroup's queue (pt_kernels.h WorkItem) ---------------------
+    //      the wanting lanes of a wave, in lane order, take the next items of the wave's queue (pt_kernels.h WorkItem) --------------
     const bool wants = pathEnded || state0 == ST_REGEN;
     {
-        // compaction over the workgroup: wave counts in LDS, then lanes 0 .. n-1 run startSample, so that the 50-draw seeding
-        // of the stream (the seeding contract, ~400 integer operations) and the camera arithmetic run on full waves instead of
-        // on the quarter of the lanes whose path has just ended
         const uint64_t mw = __ballot(wants);
-        if (lane == 0) start.waveBase[wave] = (uint32_t)__popcll(mw);
-        __syncthreads();
-        uint32_t base = 0;
-        for (uint32_t w = 0; w < wave; ++w) base += start.waveBase[w];
-        const uint32_t n = start.waveBase[0] + start.waveBase[1] + start.waveBase[2] + start.waveBase[3];
-        bool becameIdle = false;
-        if (wants) {
-            const uint32_t i = base + (uint32_t)__popcll(mw & ((1ull << lane) - 1ull));
-            const WorkItem w = workItemOf(rp, blockIdx.x, taken + i);
-            start.lane[i] = w.valid ? threadIdx.x : kNoStart;
-            start.pix[i] = w.pix;
-            start.pass[i] = w.pass;
-            becameIdle = !w.valid;
-        }
+        WorkItem w;
+        w.valid = false;
+        if (wants) w = workItemOf(rp, globalWave, taken + (uint32_t)__popcll(mw & ((1ull << lane) - 1ull)));
+        if (lane == 0 && mw) pb.cursor[globalWave] = taken + (uint32_t)__popcll(mw);
+        const bool becameIdle = wants && !w.valid;
         if (becameIdle) pb.flags[slot] = F_MAKE((uint32_t)ST_IDLE, 0u, 0u, 0u, 0u, 0u);
         const uint64_t mi = __ballot(becameIdle);
         if (lane == 0 && mi) atomicAdd(&start.wentIdle, (uint32_t)__popcll(mi));
-        if (threadIdx.x == 0 && n) pb.cursor[blockIdx.x] = taken + n;
+        // compaction of the samples to start over the workgroup: wave counts in LDS, then lanes 0 .. n-1 run startSample, so
+        // that the 50-draw seeding of the stream (the seeding contract, ~400 integer operations) and the camera arithmetic run
+        // on full waves instead of on the quarter of the lanes whose path has just ended
+        const bool starts = wants && w.valid;
+        const uint64_t ms = __ballot(starts);
+        if (lane == 0) start.waveBase[wave] = (uint32_t)__popcll(ms);
+        __syncthreads();
+        uint32_t base = 0;
+        for (uint32_t k = 0; k < wave; ++k) base += start.waveBase[k];
+        if (starts) {
+            const uint32_t i = base + (uint32_t)__popcll(ms & ((1ull << lane) - 1ull));
+            start.lane[i] = threadIdx.x;
+            start.pix[i] = w.pix;
+            start.pass[i] = w.pass;
+        }
         __syncthreads();
         // the live count: one atomic per workgroup and launch, on one of kShards lines (PathBuffers::idleShards)
         if (threadIdx.x == 0 && start.wentIdle) atomicAdd(&pb.idleShards[(blockIdx.x % kShards) * kCounterStride], start.wentIdle);
-        if (threadIdx.x < n && start.lane[threadIdx.x] != kNoStart)
+        const uint32_t n = start.waveBase[0] + start.waveBase[1] + start.waveBase[2] + start.waveBase[3];
+        if (threadIdx.x < n)
             startSample<S>(sc, pb, rp, blockIdx.x * kShadeBlock + start.lane[threadIdx.x], start.pix[threadIdx.x], start.pass[threadIdx.x]);
     }
 }
@@ -1079,7 +1083,8 @@ __global__ void k_reset_slots(PathBuffers pb, RenderParams rp, uint32_t clearSen
     pb.flags[slot] = F_MAKE((uint32_t)ST_REGEN, 0u, 0u, 0u, 0u, 0u);
     pb.hdr[(size_t)slot * pb.hdrStride] = make_uint4(0u, 0u, 0u, 0u);
     pb.visible[slot] = 0;
-    if (threadIdx.x == 0) { pb.blockDead[blockIdx.x] = 0u; pb.cursor[blockIdx.x] = 0u; }
+    if (threadIdx.x == 0) pb.blockDead[blockIdx.x] = 0u;
+    if ((threadIdx.x & 63u) == 0u) pb.cursor[slot >> 6] = 0u;
     if (clearSensor) {
         constexpr uint32_t planes = S::N == 3 ? 1u : 4u;
         for (size_t e = slot; e < (size_t)rp.numPixels * planes; e += (size_t)gridDim.x * blockDim.x) {

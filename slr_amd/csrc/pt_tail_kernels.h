@@ -8,8 +8,8 @@
 //   k_tail_collect  lists the live slots (one atomic per workgroup);
 //   k_tail          gives every lane one listed slot and runs it until the slot has nothing left to do: per bounce the extension
 //                   ray and the pending shadow ray through the one-lane-per-ray traversal of pt_traverse.h, then logicSlot —
-//                   the very function k_shade calls; when the path ends, writeResult and, if the queue of the slot's workgroup
-//                   has a sample left, startSample — what k_shade does for a finished path.  A lane whose slot went idle takes
+//                   the very function k_shade calls; when the path ends, writeResult and, if the queue of the slot's wave has
+//                   a sample left, startSample — what k_shade does for a finished path.  A lane whose slot went idle takes
 //                   the next listed one (one atomic per wave and refill).
 // A sample's contribution is a function of (pixel, pass) alone and the sensor adds the contributions in pass order (k_fold), so
 // the image is the same to the last bit whether the tail kernel or the wavefront kernels finish the window, at any slot count.
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(SLR
 
     // <= 102 turns per sample; the samples a lane can still be handed are bounded by the longest queue (a constant
     // bound failed one-lane renders of very many passes)
-    const uint64_t guardTurns = 104ull * ((uint64_t)(rp.numChunks / rp.numBlocks + 2u) * kWorkChunk + 2ull) + 1024ull;
+    const uint64_t guardTurns = 104ull * ((uint64_t)(rp.numRuns / rp.numWaves + 2u) * rp.runLength + 2ull) + 1024ull;
     for (uint64_t guard = 0; guard < guardTurns; ++guard) {
         // ---- lanes without a path take the next listed ones: one atomic per wave and refill --------------------------------
         const uint64_t idle = __ballot(slot == kTailNone);
@@ -69,14 +69,13 @@ __global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(SLR
         if (state == ST_IDLE) { slot = kTailNone; continue; }    // not expected (the list holds live slots): nothing to do
         if (state == ST_REGEN) {
             // the path ended at this lane's last turn, or the slot has not started a sample yet: the finished sample's result,
-            // then the next item of the queue of the slot's workgroup (by atomic: the lanes holding a workgroup's slots may be
-            // in different waves here)
+            // then the next item of the queue of the slot's wave (by atomic: the slots of a wave may be held by
+            // lanes of different waves here)
             if (F_HASPATH(flags)) {
                 const uint4 hdr = pb.hdr[(size_t)slot * pb.hdrStride];
                 writeResult<S>(pb, rp, slot, flags, hdr, false, S());
             }
-            const uint32_t block = slot / (uint32_t)kShadeBlock;
-            const WorkItem w = workItemOf(rp, block, atomicAdd(&pb.cursor[block], 1u));
+            const WorkItem w = workItemOf(rp, slot >> 6, atomicAdd(&pb.cursor[slot >> 6], 1u));
             if (!w.valid) {
                 pb.flags[slot] = F_MAKE((uint32_t)ST_IDLE, 0u, 0u, 0u, 0u, 0u);
                 ++wentIdle;

@@ -28,6 +28,7 @@ namespace {
 
 const int kDefaultPairs = 1;                   // SLRHIP_PAIRS: the ray pair pays, the radiance-sum pair does not
 const uint32_t kStatusWords = 8;               // PathBuffers::activeSlots .. tailWords: one small array, read back in one copy
+const uint32_t kDefaultRunLength = 64;         // SLRHIP_RUN_LENGTH: passes of a pixel a wave takes in a row (pt_kernels.h WorkItem; measured: DESIGN.md)
 const uint32_t kDefaultTailSlots = 1u << 18;   // SLRHIP_TAIL_SLOTS: measured on the headline frame and its N = 8 shard
 
 thread_local std::string g_lastError;
@@ -860,7 +861,7 @@ int slrhip_render_begin(slrhip_ctx* ctx, const slrhip_render_settings* st, slrhi
     HIP_TRY(ctx->shadowDir.alloc(numSlots, true));
     HIP_TRY(ctx->pdfPrev.alloc(spectral ? numSlots : 1, true));
     HIP_TRY(ctx->hdr.alloc(numSlots * hdrStride, true)); HIP_TRY(ctx->rng.alloc(hdrStride == 2 ? 1 : numSlots, true));
-    HIP_TRY(ctx->cursor.alloc(numSlots / 256u)); HIP_TRY(ctx->idleShards.alloc(kShards * kCounterStride));
+    HIP_TRY(ctx->cursor.alloc(numSlots / 64u)); HIP_TRY(ctx->idleShards.alloc(kShards * kCounterStride));
     HIP_TRY(ctx->flags.alloc(numSlots, true)); HIP_TRY(ctx->visible.alloc(numSlots, true));
     if (ctx->scene.instances) HIP_TRY(ctx->hitInstance.alloc(numSlots, true));
     // queue regions: slot block b appends to region b % kShards, so a region holds at most ceil(numBlocks / kShards) blocks
@@ -893,7 +894,7 @@ int slrhip_render_begin(slrhip_ctx* ctx, const slrhip_render_settings* st, slrhi
 
     RenderParams& rp = ctx->params;
     rp.numSlots = numPixels ? (uint32_t)numSlots : 0u; rp.numBlocks = rp.numSlots / 256u; rp.numPixels = numPixels; rp.stripes = stripes;
-    rp.sppBegin = 0; rp.sppCount = 0; rp.workItems = 0; rp.numChunks = 0;
+    rp.sppBegin = 0; rp.sppCount = 0; rp.workItems = 0; rp.numWaves = rp.numSlots / 64u; rp.runLength = 1; rp.numRuns = 0;
     rp.rngSeed = st->rng_seed; rp.timeStart = st->time_start; rp.timeEnd = st->time_end;
     rp.imageWidth = W; rp.imageHeight = H;
     rp.countSlots = (ctx->config.flags & SLRHIP_FLAG_COUNT_TRAVERSAL) ? 1u : 0u;
@@ -915,7 +916,12 @@ static int renderWindow(slrhip_ctx* ctx, uint32_t sppBegin, uint32_t sppCount, h
     rp.sppBegin = sppBegin;
     rp.sppCount = sppCount;
     rp.workItems = rp.numPixels * sppCount;                        // < 2^32: slrhip_render
-    rp.numChunks = (uint32_t)(((uint64_t)rp.workItems + kWorkChunk - 1) / kWorkChunk);
+    // passes per run (pt_kernels.h WorkItem): the largest power of two <= the default that divides the window's pass count
+    static const uint32_t envRun = [] { const char* e = getenv("SLRHIP_RUN_LENGTH"); const long v = e ? atol(e) : 0L; return v >= 1 && v <= 4096 ? (uint32_t)v : 0u; }();
+    rp.runLength = envRun ? envRun : kDefaultRunLength;
+    while (rp.runLength > 1 && (sppCount % rp.runLength) != 0) rp.runLength /= 2;
+    if (sppCount && sppCount % rp.runLength) rp.runLength = 1;
+    rp.numRuns = rp.numPixels * (sppCount / std::max(rp.runLength, 1u));
 
     // the first window after render_begin also clears the sensor (the buffers are reused across render_begin calls), even when
     // it is asked for zero passes
@@ -1109,7 +1115,10 @@ int slrhip_render(slrhip_ctx* ctx, uint32_t sppBegin, uint32_t sppCount, void* s
     uint64_t budget = 16ull << 30;
     if (const char* e = getenv("SLRHIP_RESULT_WINDOW_MB")) { const long mb = atol(e); if (mb > 0) budget = (uint64_t)mb << 20; }
     const uint64_t maxPasses = std::max<uint64_t>(1, std::min<uint64_t>(budget / ((uint64_t)rp.numPixels * entryBytes), 0xFFFFFFFFull / rp.numPixels));
-    const uint32_t window = (uint32_t)std::min<uint64_t>(maxPasses, std::max<uint32_t>(sppCount, 1u));
+    // whole runs (RenderParams::runLength passes of a pixel in a row, pt_kernels.h) wherever the call is long enough: a window of
+    // an odd number of passes would fall back to runs of one pass and lose the coherence of a wave's slots
+    uint32_t window = (uint32_t)std::min<uint64_t>(maxPasses, std::max<uint32_t>(sppCount, 1u));
+    if (window >= kDefaultRunLength) window -= window % kDefaultRunLength;
     HIP_TRY(ctx->results.alloc((size_t)window * rp.numPixels * (rp.spectral ? 4u : 1u)));
     ctx->buffers.results = ctx->results.ptr;
     if (sppCount == 0) return renderWindow(ctx, sppBegin, 0, stream);
@@ -1249,6 +1258,28 @@ int slrhip_trace_rays(slrhip_ctx* ctx, const float* rays, uint32_t n, float* hit
 }
 
 // Diagnostic (include/slrhip_debug.h): function-level BSDF queries through the device functions the shade kernel calls.
+int slrhip_debug_work_distribution(uint32_t numPixels, uint32_t numSlots, uint32_t numPasses, uint32_t runLength, uint32_t* counts,
+                                   uint32_t* queueLengths) {
+    if (!counts || !queueLengths || numPixels == 0 || numSlots < 64 || numSlots % 64 || runLength == 0 || numPasses % runLength ||
+        (uint64_t)numPixels * numPasses > 0xFFFFFFFFull)
+        return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_debug_work_distribution: bad arguments");
+    RenderParams rp;
+    std::memset(&rp, 0, sizeof(rp));
+    rp.numSlots = numSlots; rp.numWaves = numSlots / 64u; rp.numPixels = numPixels; rp.sppCount = numPasses;
+    rp.workItems = numPixels * numPasses; rp.runLength = runLength; rp.numRuns = numPixels * (numPasses / runLength);
+    for (uint32_t w = 0; w < rp.numWaves; ++w) {
+        uint32_t taken = 0;
+        for (;; ++taken) {
+            const WorkItem it = workItemOf(rp, w, taken);
+            if (!it.valid) break;
+            ++counts[(size_t)it.pass * numPixels + it.pix];
+        }
+        queueLengths[w] = taken;
+        if (workSamplesTaken(rp, w, taken + 7u) != taken) return fail(SLRHIP_ERR_HIP, "slrhip_debug_work_distribution: workSamplesTaken disagrees with the queue");
+    }
+    return SLRHIP_OK;
+}
+
 int slrhip_bsdf_queries(slrhip_ctx* ctx, uint32_t material, uint32_t n, const float* queries, float wl_offset, float u_lambda, float* out) {
     if (!ctx || !queries || !out) return fail(SLRHIP_ERR_INVALID_ARGUMENT, "slrhip_bsdf_queries: null argument");
     if (!ctx->haveScene) return fail(SLRHIP_ERR_NO_SCENE, "slrhip_bsdf_queries: no scene uploaded");

@@ -36,6 +36,28 @@ def test_every_declared_symbol_is_exported(lib):
     assert sorted(binding.EXPORTS) == names
 
 
+@pytest.mark.parametrize("num_pixels, num_slots, num_passes, run_length",
+                         [(64 * 48, 64 * 48 * 8 // 256 * 256, 40, 8),      # the usual case: many runs per queue
+                          (1000, 256, 12, 4),                              # few queues, a pixel count that is no multiple of anything
+                          (37, 1024, 3, 1),                                # more slots than samples: most queues are empty
+                          (640 * 360, 640 * 360 * 4, 64, 64),              # one run per pixel, four slots per pixel
+                          (513, 64, 6, 2)])                                # a single queue
+def test_work_queues_hand_out_every_sample_exactly_once(lib, num_pixels, num_slots, num_passes, run_length):
+    """The sample scheduling of the render path (pt_kernels.h WorkItem), evaluated on the host by the function the kernels call:
+    the (pixel, pass) samples of a window are dealt to per-wave queues in runs of `run_length` passes of one pixel.  Every sample
+    must come up exactly once, the queues must be of equal length to within one run, and a queue walks over the image (its runs
+    are not all the same pixel), which is what balances the work of the queues."""
+    f = lib.slrhip_debug_work_distribution
+    f.argtypes = [C.c_uint32] * 4 + [C.c_void_p, C.c_void_p]
+    counts = np.zeros(num_pixels * num_passes, np.uint32)
+    lengths = np.zeros(num_slots // 64, np.uint32)
+    assert f(num_pixels, num_slots, num_passes, run_length, counts.ctypes.data, lengths.ctypes.data) == 0
+    assert (counts == 1).all()
+    assert int(lengths.sum()) == num_pixels * num_passes
+    assert int(lengths.max()) - int(lengths.min()) <= run_length
+    assert f(num_pixels, num_slots, num_passes, num_passes + 1, counts.ctypes.data, lengths.ctypes.data) != 0      # the run length must divide the passes
+
+
 def test_version(lib):
     text = open(os.path.join(ROOT, "include", "slrhip.h")).read()
     assert lib.slrhip_version() == int(re.search(r"#define SLRHIP_VERSION (\d+)", text).group(1)) == 7

@@ -94,14 +94,29 @@ def test_full_cornell_against_oracle(ctx, oracle_rgb, right):
 
 
 def test_stripes_do_not_change_the_image(oracle_rgb):
-    """More paths in flight (sample stripes) only reorders the per-pixel float sum."""
+    """More paths in flight (slrhip_config::stripes sizes the number of slots) change nothing: a sample is a function of
+    (pixel, pass) and the sensor adds a pixel's samples in pass order (k_fold), whichever slot rendered them.  Also with the
+    result window cut into pieces of a few passes (SLRHIP_RESULT_WINDOW_MB)."""
     sc = scenes.cornell_box_spheres(1.0, 24, 12, "glass")
     st = ob.settings(64, 64, seed=5)
     want, _ = oracle_rgb.scene(sc).render(st, 32)
-    c = Context(stripes=8)
-    fb = c.render_image(sc, st, 32)
-    c.close()
-    assert np.allclose(fb, want, rtol=2e-6, atol=1e-9)
+    frames = {}
+    for stripes in (1, 3, 8, 64, 0):
+        c = Context(stripes=stripes)
+        frames[stripes] = c.render_image(sc, st, 32)
+        assert c.counters().samples == 64 * 64 * 32
+        c.close()
+    for stripes in (3, 8, 64, 0):
+        assert_bit_equal(frames[stripes], frames[1], "stripes %d vs 1" % stripes)
+    assert np.allclose(frames[1], want, rtol=2e-6, atol=1e-9)
+    os.environ["SLRHIP_RESULT_WINDOW_MB"] = "1"           # 64 x 64 pixels x 16 B = 64 KiB per pass: windows of 16 passes
+    try:
+        c = Context(stripes=8)
+        windows = c.render_image(sc, st, 32)
+        c.close()
+    finally:
+        del os.environ["SLRHIP_RESULT_WINDOW_MB"]
+    assert_bit_equal(windows, frames[1], "two result windows vs one")
 
 
 def test_shards_sum_to_full_image(ctx, oracle_rgb):
@@ -123,7 +138,7 @@ def test_shards_sum_to_full_image(ctx, oracle_rgb):
 @pytest.mark.parametrize("size,spp,stripes", [((1, 1), 7, 1), ((3, 5), 5, 3), ((9, 8), 4, 64), ((37, 21), 3, 0)])
 def test_ragged_sizes_against_oracle(oracle_rgb, size, spp, stripes):
     """Images smaller than a tile, not a multiple of 8, fewer samples than stripes, stripes that do not divide spp, and the
-    automatic stripe choice: every pixel still gets exactly its passes (stripes only reorder the per-pixel float sum)."""
+    automatic stripe choice: every pixel still gets exactly its passes, added in pass order (bit-exact at any slot count)."""
     sc = scenes.tiny_box(size[0] / size[1])
     st = ob.settings(size[0], size[1], seed=21)
     want, ctr = oracle_rgb.scene(sc).render(st, spp)
@@ -133,10 +148,7 @@ def test_ragged_sizes_against_oracle(oracle_rgb, size, spp, stripes):
     c.close()
     assert k.samples == size[0] * size[1] * spp == ctr.samples
     assert int(k.extension_rays) == int(ctr.extension_rays) and int(k.shadow_rays) == int(ctr.shadow_rays)
-    if stripes == 1:
-        assert_bit_equal(fb, want, "stripes=1")
-    else:
-        assert np.allclose(fb, want, rtol=2e-6, atol=1e-9)
+    assert_bit_equal(fb, want, "stripes=%d" % stripes)
 
 
 def test_large_image_against_oracle(oracle_rgb):
@@ -473,7 +485,7 @@ def test_textured_scene_matches_reference_golden(name):
         k = c.counters()
     finally:
         c.close()
-    assert np.allclose(fb, want, rtol=2e-6, atol=1e-9)
+    assert_bit_equal(fb, want, "automatic slot count vs the oracle")
     assert int(k.extension_rays) == int(ctr.extension_rays) and int(k.shadow_rays) == int(ctr.shadow_rays)
 
 
@@ -502,7 +514,7 @@ def test_image_textured_scene_matches_reference_golden(name):
         k = c.counters()
     finally:
         c.close()
-    assert np.allclose(fb, want, rtol=2e-6, atol=1e-9)
+    assert_bit_equal(fb, want, "automatic slot count vs the oracle")
     assert int(k.extension_rays) == int(ctr.extension_rays) and int(k.shadow_rays) == int(ctr.shadow_rays)
 
 
@@ -538,7 +550,7 @@ def test_instanced_scene_matches_reference_golden(name):
         k = c.counters()
     finally:
         c.close()
-    assert np.allclose(fb, want, rtol=2e-6, atol=1e-9)
+    assert_bit_equal(fb, want, "automatic slot count vs the oracle")
     assert int(k.extension_rays) == int(ctr.extension_rays) and int(k.shadow_rays) == int(ctr.shadow_rays)
 
 
@@ -880,8 +892,8 @@ def test_eight_tile_shards_assemble_the_full_size_frame_exactly():
     unsharded frame bit for bit (per-(pixel, sample) seeding: a pixel's samples do not depend on which rank owns it)."""
     sc = scenes.cornell_box_spheres(1280 / 720, 24, 12, "matte")
     st = ob.settings(1280, 720)
-    # A fixed stripe count: the per-pixel float sum is taken stripe by stripe, so bit-equality across world sizes needs the
-    # same K everywhere (the automatic K grows with the world size; the frames then agree to the last ulp or two, below).
+    # (the sensor adds a pixel's samples in pass order whatever the slot count, so the automatic count — which grows with the
+    # world size — gives the same bits: below)
     c = Context(mode=abi.MODE_RGB, stripes=4)
     try:
         c.upload_scene(sc)
@@ -902,7 +914,7 @@ def test_eight_tile_shards_assemble_the_full_size_frame_exactly():
     finally:
         c.close()
     assert_bit_equal(total, full, "sum of 8 shards vs full frame")
-    # automatic stripe counts (8 for the full frame, 64 for an eighth of it): same samples, another summation order
+    # automatic stripe counts (8 for the full frame, 64 for an eighth of it): same samples, same sums
     a = Context(mode=abi.MODE_RGB)
     try:
         a.upload_scene(sc)
@@ -915,14 +927,14 @@ def test_eight_tile_shards_assemble_the_full_size_frame_exactly():
     finally:
         a.close()
     mask = (part_auto != 0).any(axis=2)
-    assert np.allclose(part_auto[mask], full_auto[mask], rtol=2e-6, atol=1e-9)
-    assert np.allclose(full_auto, full, rtol=2e-6, atol=1e-9)
+    assert_bit_equal(part_auto[mask], full_auto[mask], "a shard with its automatic slot count vs the full frame with its own")
+    assert_bit_equal(full_auto, full, "automatic vs fixed slot count")
 
 
-def test_sample_pool_is_reproducible_and_complete(oracle_rgb):
-    """64 stripes per pixel sharing one sample counter: every pass is rendered exactly once (sample count, image equal to the
-    oracle's up to the summation order of the stripes), the assignment of passes to stripes is the same in every run
-    (bit-identical frames), and a render continued in two calls still covers every pass once."""
+def test_work_queues_are_reproducible_and_complete(oracle_rgb):
+    """64 slots per pixel drawing samples from the wave queues: every (pixel, pass) is rendered exactly once (sample count; the
+    image bit-identical to the one-slot-per-pixel frame and equal to the oracle's), and a render continued in a second call — with
+    fewer passes than slots per pixel in the first — continues the sensor's sums exactly."""
     sc = scenes.cornell_box_spheres(1.0, 16, 8, "glass")
     st = ob.settings(48, 40, seed=9)
     want, _ = oracle_rgb.scene(sc).render(st, 96)
@@ -933,26 +945,30 @@ def test_sample_pool_is_reproducible_and_complete(oracle_rgb):
         assert c.counters().samples == 48 * 40 * 96
         c.close()
     assert_bit_equal(frames[0], frames[1], "two runs with 64 stripes")
-    assert np.allclose(frames[0], want, rtol=5e-6, atol=1e-9)
+    assert np.allclose(frames[0], want, rtol=2e-6, atol=1e-9)
+    c = Context(stripes=1)
+    one = c.render_image(sc, st, 96)
+    c.close()
+    assert_bit_equal(frames[0], one, "64 stripes vs 1")
     c = Context(stripes=64)
     c.upload_scene(sc)
     c.render_begin(st)
-    c.render(0, 40)            # fewer passes than stripes: 24 stripes never start
+    c.render(0, 40)            # fewer passes than slots per pixel: some queues are empty
     c.render(40, 56)
     two = c.read_framebuffer()
     assert c.counters().samples == 48 * 40 * 96      # sample totals run from slrhip_render_begin
     c.close()
-    assert np.allclose(two, want, rtol=5e-6, atol=1e-9)
+    assert_bit_equal(two, one, "a render continued in a second call vs one call")
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", [abi.MODE_RGB, abi.MODE_SPECTRAL])
 def test_tail_kernel_gives_the_frame_of_the_wavefront_iterations(mode):
     """Once few slots are live the rest of a render call is ONE launch (k_tail: each remaining slot taken to its end by one lane,
-    through the same logicSlot / accumulateSample / startSample code as k_shade and the one-lane-per-ray traversal).
-    On request (SLRHIP_FLAG_TAIL_KERNEL).  Against the pure wavefront schedule: the same samples (sample and ray counts equal), with one stripe
-    the same frame bit for bit; with more stripes only the grouping of a pixel's float sum over its stripes may differ.  Also
-    for a render continued in a second call and more stripes than passes; and reproducible."""
+    through the same logicSlot / writeResult / startSample code as k_shade and the one-lane-per-ray traversal).
+    On request with a fixed slot count (SLRHIP_FLAG_TAIL_KERNEL).  Against the pure wavefront schedule: the same samples (sample
+    and ray counts equal) and the same frame bit for bit at any slot count.  Also for a render continued in a second call and
+    more slots per pixel than passes; and reproducible."""
     if os.environ.get("SLRHIP_TAIL_SLOTS") == "0":
         pytest.skip("the tail kernel is switched off in this environment")
     sc = scenes.cornell_box_spheres(1.0, 16, 8, "glass")
@@ -977,10 +993,7 @@ def test_tail_kernel_gives_the_frame_of_the_wavefront_iterations(mode):
         assert counts_g == counts_w == counts_a, (counts_g, counts_w)
         assert counts_g[0] == 64 * 48 * sum(n for _, n in calls)
         assert_bit_equal(got, again, "two runs with the tail kernel (stripes %d)" % stripes)
-        if stripes == 1:
-            assert_bit_equal(got, want, "tail kernel vs wavefront iterations, one stripe")
-        else:
-            assert np.allclose(got, want, rtol=5e-6, atol=1e-9), (stripes, calls)
+        assert_bit_equal(got, want, "tail kernel vs wavefront iterations (stripes %d)" % stripes)
 
 
 @pytest.mark.gpu

@@ -3,7 +3,7 @@
 var=$1; shift
 for round in 1 2; do for v in "$@"; do
   export $var=$v
-  for wl in "cornell" "ibl --spp 512" "grid10m --spp 64"; do
+  for wl in "cornell" "ibl --spp 512" "grid10m --spp 512" "boxes_spectral --spp 256"; do
   timeout -k 10 280 python bench.py --workload $wl --cpu-seconds 0 --steps 1 --warmup 1 2>/dev/null | python -c "
 import json,sys,os
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d['kernels']
