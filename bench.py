@@ -35,11 +35,11 @@ QUANT_NODE_THRESHOLD = 65536
 CLOSEST_RAY_BYTES = 4 + 16 + 16 + 16       # state flag, ray origin, ray direction, hit record written
 SHADOW_RAY_BYTES = 4 + 16 + 16 + 4         # queue entry, origin, direction+distMax, visibility written
 # k_shade per live slot.  RGB: state read 136 (flags 4, rng 16, alpha 16, sp pair 32, nee 16, hit 16, ray 32, visible 4)
-# + ShadeTri 96 + written ~140 + shadow entry ~20 + material 80 (LDS) + per finished path (x 0.44 per visit) accumulator
-# read-modify-write 64 + header 32 + the restarted sample's state 68.  Spectral: read 156 (flags, rng, alpha 64 + pdf 4, hit, ray,
-# visible, hdr) + ShadeTri 96 + written 120 (flags, rng, alpha 68, ray 32) + pending light sample 64 x 0.55 + radiance-sum
-# read-modify-write 256 x 0.3 (only when a contribution arrives)
-SHADE_SLOT_BYTES = {"rgb": 588, "spectral": 484}
+# + ShadeTri 96 + written ~140 + shadow entry ~20 + material 80 (LDS) + per finished path (x 0.44 per visit) the sample's result
+# 16 + header 32 + the restarted sample's state 68 (round 3: the 64-byte accumulator read-modify-write per sample is gone).
+# Spectral: read 156 (flags, rng, alpha 64 + pdf 4, hit, ray, visible, hdr) + ShadeTri 96 + written 120 (flags, rng, alpha 68,
+# ray 32) + pending light sample 64 x 0.55 + radiance-sum read-modify-write 256 x 0.3 (only when a contribution arrives)
+SHADE_SLOT_BYTES = {"rgb": 567, "spectral": 484}
 
 
 def node_bytes(num_nodes):
@@ -308,6 +308,15 @@ def main():
                 roof["modelled_frac"] = round(roof["modelled_achieved"] / HBM_PEAK_GBS, 5)
                 roof["basis"] = "no PMC entry for this exact workload: frac is null; modelled_frac = state records%s / launch time" % (
                     "" if cached or dom == "shade" else " + node/triangle bytes")
+            # every kernel class of an iteration with a PMC entry, not only the dominant one (the two kernels of an iteration take
+            # the same share of the time to within a per cent or two, so which one is "dominant" changes from run to run)
+            if ent:
+                roof["per_kernel"] = {}
+                for k in kernels:
+                    if k in ent and kernels[k]["launches"]:
+                        a = ent[k]["traffic_bytes_per_launch"] / (kernels[k]["ms_total"] / kernels[k]["launches"] * 1e-3) / 1e9
+                        roof["per_kernel"][k] = {"traffic": round(ent[k]["traffic_bytes_per_launch"]), "avg_launch_us": kernels[k]["avg_us"],
+                                                 "achieved": round(a, 1), "frac": round(a / HBM_PEAK_GBS, 5)}
             # whole-sample algorithmic bytes (SURVEY 8d formula) for reference
             sample_bytes = (ext_per_sample * per_ray["closest"] + shd_per_sample * per_ray["shadow"] + ext_per_sample * slot_bytes)
             roof["algorithmic_bytes_per_sample"] = round(sample_bytes, 1)
@@ -357,7 +366,7 @@ def main():
             else:
                 out["cpu_baseline_port"] = port
             if not args.no_parity:
-                # the TIMED configuration (automatic stripe count + sample pool): stripes only reorder a pixel's float sum
+                # the TIMED configuration (automatic slot count): the sensor adds in pass order, so the slot count changes no bit
                 pctx = Context(device=local_rank, mode=mode, stripes=args.stripes, flags=build_flag)
                 got = pctx.render_image(scene, settings, n)
                 pc = pctx.counters()
@@ -366,7 +375,7 @@ def main():
                 d = (got.astype(np.float64) - want) / n * sens
                 nz = np.abs(want) > 1e-9
                 rel = np.abs(got.astype(np.float64) - want)[nz] / np.abs(want[nz])
-                out["parity"] = {"spp": n, "configuration": "as timed (stripes = %d: automatic, sample pool)" % args.stripes if args.stripes == 0
+                out["parity"] = {"spp": n, "configuration": "as timed (stripes = %d: automatic slot count, wave work queues)" % args.stripes if args.stripes == 0
                                                             else "as timed (stripes = %d)" % args.stripes,
                                  "rmse_vs_cpu_matched_seeds": float(np.sqrt(np.mean(d * d))),
                                  "max_rel_err": float(rel.max()) if rel.size else 0.0,
@@ -374,12 +383,13 @@ def main():
                                  "bit_exact_fraction": float(((got.view(np.uint32) == want.view(np.uint32)) | ((got == 0) & (want == 0))).mean()),
                                  "ray_counts_equal": bool(int(pc.extension_rays) == int(octr.extension_rays) and int(pc.shadow_rays) == int(octr.shadow_rays)),
                                  "mean_radiance": float(want.mean() / n * sens)}
-                # and with ONE stripe, which keeps the sensor's accumulation order: expected bit for bit where no float libm is on the path
+                # and with ONE slot per pixel: the same frame to the last bit (kept as a cross-check of that claim)
                 pctx = Context(device=local_rank, mode=mode, stripes=1, flags=build_flag)
                 got1 = pctx.render_image(scene, settings, n)
                 pctx.close()
                 exact = (got1.view(np.uint32) == want.view(np.uint32)) | ((got1 == 0) & (want == 0))
                 out["parity"]["stripes1_bit_exact_fraction"] = float(exact.mean())
+                out["parity"]["stripes1_equals_timed_configuration"] = bool(np.array_equal(got1.view(np.uint32), got.view(np.uint32)))
                 if comps == 16:
                     # spectral RMSE on the 16 bins (above) and after DiscretizedSpectrum::getRGB (SpectrumTypes.h:702-721)
                     from slr_amd import spectra

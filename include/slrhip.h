@@ -310,16 +310,17 @@ typedef struct slrhip_shard {
 typedef struct slrhip_config {
     int32_t device;            /* HIP device ordinal                                         */
     int32_t mode;              /* SLRHIP_MODE_*                                              */
-    uint32_t stripes;          /* sample stripes per pixel kept in flight: 0 = auto, else 1 .. SLRHIP_MAX_STRIPES
-                                * (the per-pixel sample pool tracks stripes in a 64-bit mask); larger values are
-                                * rejected by slrhip_create with SLRHIP_ERR_INVALID_ARGUMENT                      */
+    uint32_t stripes;          /* paths kept in flight PER PIXEL of the shard (the number of path slots = pixels x stripes):
+                                * 0 = auto, else 1 .. SLRHIP_MAX_STRIPES; larger values are rejected by slrhip_create with
+                                * SLRHIP_ERR_INVALID_ARGUMENT.  It sizes memory and parallelism only: a slot is not bound to
+                                * a pixel, and the image is the same to the last bit for every value                      */
     uint32_t flags;            /* SLRHIP_FLAG_*                                              */
 } slrhip_config;
 
 /* ---- counters --------------------------------------------------------------------- */
 typedef struct slrhip_counters {
-    uint64_t samples;            /* finished (pixel, sample) pairs accumulated into pixels since slrhip_render_begin,
-                                  * counted on the device (sum of the per-slot sample counters)              */
+    uint64_t samples;            /* (pixel, sample) pairs rendered since slrhip_render_begin, counted on the device
+                                  * (what the wave queues handed out)                                       */
     uint64_t extension_rays;     /* Scene::intersect calls         PathTracingRenderer.cpp:147,225 */
     uint64_t shadow_rays;        /* Scene::testVisibility calls    PathTracingRenderer.cpp:180     */
     uint64_t iterations;         /* wavefront iterations launched                            */
@@ -334,9 +335,9 @@ typedef struct slrhip_counters {
 enum {
     SLRHIP_KERNEL_TRACE = 0,           /* k_trace_ws: Scene::intersect and Scene::testVisibility of an iteration, one launch */
     SLRHIP_KERNEL_SHADE = 1,           /* k_shade: getSurfacePoint .. bsdf->sample (PathTracingRenderer.cpp:149-258) and, for a path that
-                                        * ends, sensor->add + Job::kernel's camera ray of the slot's next pass (:100-130)               */
-    SLRHIP_KERNEL_TAIL = 2,            /* k_tail: the last paths of a render call, each taken to its end by one lane (all of the above
-                                        * in one launch, once no pixel has a pass left to hand out)      */
+                                        * ends, its sample's contribution + Job::kernel's camera ray of the slot's next sample (:100-130) */
+    SLRHIP_KERNEL_TAIL = 2,            /* k_tail: the last paths of a render window, each taken to its end by one lane (all of the above
+                                        * in one launch, once few slots are live)                        */
     SLRHIP_KERNEL_COUNT = 3
 };
 typedef struct slrhip_profile {
@@ -349,13 +350,11 @@ typedef struct slrhip_profile {
 } slrhip_profile;
 
 /* config.flags */
-#define SLRHIP_FLAG_TAIL_KERNEL 128u    /* with a FIXED stripe count (slrhip_config::stripes > 0): also hand the last <= 2^18 live slots of a render
-                                         * call (never more than an eighth of the slots) to the tail kernel — one launch instead of the last
-                                         * ~80 wavefront iterations, 1 % (2.5 % at an eighth of the frame) faster.  Same samples, same frame
-                                         * with one stripe; with more stripes the passes the tail hands out go to other stripes than the
-                                         * wavefront schedule would pick, so the grouping of a pixel's float sum — the last ulp — then depends
-                                         * on the shard size.  With the AUTOMATIC stripe count (stripes = 0) that grouping depends on the shard
-                                         * size anyway, and the tail kernel is always on                                                    */
+#define SLRHIP_FLAG_TAIL_KERNEL 128u    /* with a FIXED slot count (slrhip_config::stripes > 0): also hand the last <= 2^18 live slots of a render
+                                         * window (never more than an eighth of the slots) to the tail kernel — one launch instead of the
+                                         * last wavefront iterations.  Same samples, same frame to the last bit (the sensor adds a pixel's
+                                         * samples in pass order whoever rendered them).  Always on with the automatic slot count
+                                         * (stripes = 0); a caller who fixes the count gets the pure wavefront schedule unless he asks      */
 #define SLRHIP_FLAG_BVH_SPATIAL_SPLITS 64u /* build the tree with spatial splits (sbvh.cpp; the reference's SBVH, Accelerator/SBVH.h:57-348):
                                          * a triangle straddling a split plane is referenced from both sides with clipped boxes.
                                          * Same hits; fewer triangle tests, more node visits: measured slower with these kernels on
@@ -387,8 +386,12 @@ int slrhip_render_begin(slrhip_ctx* ctx, const slrhip_render_settings* settings,
 
 /* Replaces: the pass loop PathTracingRenderer.cpp:72-81 for passes
  * [spp_begin, spp_begin+spp_count).  Sample s of pixel (x,y) draws from the xorshift128
- * stream seeded with slrhip_sample_seed(rng_seed, x, y, s), so the image does not depend
- * on the shard layout or on scheduling.  The work is ORDERED on `stream` (a hipStream_t, or
+ * stream seeded with slrhip_sample_seed(rng_seed, x, y, s), and the sensor adds the samples
+ * of a pixel in pass order (ImageSensor::add's order for one thread), so the image does not
+ * depend on the shard layout, the slot count or scheduling — not even in the last bit.  Every
+ * sample's contribution is kept until its window of passes is complete (16 B per pixel and
+ * pass, 64 B in spectral mode; windows of at most 16 GiB, SLRHIP_RESULT_WINDOW_MB overrides;
+ * longer calls are rendered window after window).  The work is ORDERED on `stream` (a hipStream_t, or
  * NULL for the default stream): it starts after what the caller queued there before.  The
  * call itself BLOCKS the host until the passes are done — the number of wavefront iterations
  * is data dependent, so the host polls a device-side "live slots" word between blocks of

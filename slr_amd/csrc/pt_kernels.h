@@ -32,7 +32,7 @@ struct DevScene {
     uint32_t numLights;
     uint32_t lightPow2;           // prevPowerOf2(numLights)
     uint32_t hasMicrofacet;       // any SLRHIP_MATERIAL_MICROFACET_* in the scene
-    uint32_t hasMulti;            // any SLRHIP_MATERIAL_MULTI: k_logic with the MultiBSDF code
+    uint32_t hasMulti;            // any SLRHIP_MATERIAL_MULTI: k_shade with the MultiBSDF code
     // textures: null / 0 when the scene has none
     const DevTexture* textures;
     const DevMatTex* matTex;      // per material

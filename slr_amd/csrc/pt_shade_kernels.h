@@ -1,21 +1,20 @@
 // pt_shade_kernels.h — kernel templates of the shading half of the wavefront path tracer (gfx950, wave64).
 //
-// One path SLOT per (pixel, sample stripe).  A slot carries one light path at a time through the
-// reference's bounce loop (Renderers/PathTracingRenderer.cpp:137-262).  One wavefront iteration is two launches:
+// A path SLOT carries one light path at a time through the reference's bounce loop (Renderers/PathTracingRenderer.cpp:137-262);
+// it is not bound to a pixel: whenever its path ends it takes the next sample of its wave's work queue (pt_kernels.h WorkItem).
+// One wavefront iteration is two launches:
 //
 //   k_shade          every live slot: resolve the pending next-event estimate, shade the hit (getSurfacePoint, emission +
 //                    MIS, Russian roulette), then the next bounce: light sampling + BSDF sampling (:161-221); emits the next
 //                    extension ray in place and a shadow ray (slot index into the shadow queue).  A slot whose path ENDS
-//                    here is finished in the same launch: weight * C is Kahan-added to the slot's pixel accumulator in pass
-//                    order (RGBStorage::add, RGBTypes.h:176-179 — the framebuffer lives in the slot, no atomics), the
-//                    pixel's sample pool hands it its next pass (LDS mask + barrier: the stripes of a pixel share the
-//                    workgroup), and the new samples of the workgroup are started by its FIRST lanes, compacted
+//                    here is finished in the same launch: weight * C goes to the sample's entry of the result window
+//                    (writeResult; sensor->add itself, in pass order, is k_fold's), the wave's queue hands the slot its next
+//                    (pixel, pass), and the new samples of the workgroup are started by its FIRST lanes, compacted
 //                    (Job::kernel's camera half, :100-120: the 50-draw stream seeding runs on full waves).
 //   k_trace_ws       every slot with a ray in flight (state flag) + the shadow-ray queue, one launch (pt_trace_ws.hip)
 //
-// (Rounds 1-2 ran the restart as a third kernel, k_regen, over a queue of finished slots: a second pass over the state of
-// a fifth of the slots, every 16-byte record costing a 32-byte sector, plus the hand-over of flags, radiance sum and queue
-// entry through HBM — 24 % of an iteration.  DESIGN.md has the before / after.)
+// (Rounds 1-2 ran the restart as a third kernel, k_regen, over a queue of finished slots, and kept the pixel's accumulator in
+// the slot; DESIGN.md section 7 has the before / after of both.)
 //
 // The shadow queue is a slot-index list in HBM, 16 regions (one per blockIdx % 16), filled by wave ballot + popcount prefix
 // with ONE atomic per workgroup on a counter that has its own 128-byte line.  All path state is SoA in 16-byte records so a
@@ -281,12 +280,12 @@ __device__ __forceinline__ float envAreaPDF(const DevScene& sc, float phi, float
     return (float)((double)uvPDF / (2 * kPi * kPi * (double)slrSin(theta)));
 }
 
-// SampledSpectrumSum sp of Job::contribution (PathTracingRenderer.cpp:141): see the note at its use in k_logic.
+// SampledSpectrumSum sp of Job::contribution (PathTracingRenderer.cpp:141): see the note at its use in logicSlot.
 template <class S> struct SpAcc;
-// A path starts with sp = 0 (and alpha = 1, no previous PDF): k_regen does not write those records, the first k_logic visit
+// A path starts with sp = 0 (and alpha = 1, no previous PDF): startSample does not write those records, the first visit
 // (state FIRST_HIT) supplies the values instead of what it loaded.  RGB keeps the pair in registers and always stores it,
 // so it is valid from then on; the spectral variants update HBM only when a contribution arrives and track that in `valid`
-// (flag bit 10), which k_regen consults before reading the sum.
+// (flag bit 10), which writeResult consults before reading the sum.
 #ifndef SLR_SP_LAZY
 #define SLR_SP_LAZY 1      // 0 (variant builds): read and write the RGB radiance sum, its compensation and the pending light sample at every visit
 #endif
@@ -430,7 +429,7 @@ __device__ __forceinline__ void stageShadeTables(const DevScene& sc, ShadeLds<SP
     }
 }
 
-// Occupancy floor of k_logic (waves per SIMD): the register allocator spills to scratch to stay under 512 / N registers.
+// Occupancy floor of k_shade (waves per SIMD): the register allocator spills to scratch to stay under 512 / N registers.
 // Measured on the spectral GGX scene: the 330-register allocation (1 wave per SIMD, 63 % of its cycles waiting on memory,
 // PMC) ran at 1 393 us per launch; held to 256 registers (300 B of scratch per lane, 2 waves) it runs at 765 us.
 // A floor of 3 waves costs the same kernel 988 us (more scratch than the extra wave hides), but pays on the variant
@@ -532,7 +531,7 @@ __device__ __forceinline__ void logicSlot(const DevScene& sc, const PathBuffers&
 
     const uint32_t state = F_STATE(flags);
     if (state == ST_FIRST_HIT || state == ST_NEXT_HIT || state == ST_FINISH) {
-        // a path's first visit: throughput 1, no previous PDF, empty radiance sum (k_regen writes none of them)
+        // a path's first visit: throughput 1, no previous PDF, empty radiance sum (startSample writes none of them)
         if (state == ST_FIRST_HIT) { alpha = S(1.0f); bsdfPDFprev = 0.0f; }
         sp.startPath(state == ST_FIRST_HIT, flags);
         Rng rng;
@@ -1124,7 +1123,7 @@ __global__ void k_resolve(PathBuffers pb, RenderParams rp, float* dst) {
 }
 
 // ---- host-callable launchers -----------------------------------------------------------------------------------
-// Diagnostic (slrhip_bsdf_queries): the three BSDF entry points exactly as k_logic calls them, one query per lane.
+// Diagnostic (slrhip_bsdf_queries): the three BSDF entry points exactly as logicSlot calls them, one query per lane.
 // geo[i] = (sampled dir_sn, dirPDF); misc[i] = (dirType, evaluatePDF, 0, 0); fsSample / fsEval in the SpecIO layout.
 template <class S>
 __global__ void __launch_bounds__(64) k_bsdf_queries(DevScene sc, uint32_t material, uint32_t n, const float* __restrict__ in, float wlOffset,

@@ -1,6 +1,6 @@
 // pt_tex.h — the reference's procedural textures on the device (libSLR/Textures/checker_board_textures.{h,cpp}) through a
 // Texture2DMapping (Core/textures.h:16-42), and the texture coordinate of a hit (Triangle::intersect interpolates it from the
-// ORIGINAL barycentrics, Surface/TriangleMesh.cpp:160-161).  Used by k_logic (spectrum textures, bump) and by the traversal
+// ORIGINAL barycentrics, Surface/TriangleMesh.cpp:160-161).  Used by k_shade (spectrum textures, bump) and by the traversal
 // kernels (alpha test).
 #pragma once
 #include <hip/hip_runtime.h>

@@ -560,7 +560,7 @@ __device__ __forceinline__ void wsProduce(const PathBuffers& pb, LDS& lds, uint3
         // The state flags of kAhead chunks are fetched in one round trip, the ray records only for chunks that have a ray:
         // near the end of a render most slots are idle, and a producer that pays one memory round trip per 128 slots
         // whether or not they hold a ray makes an almost empty launch last ~58 us (28 dependent round trips per workgroup).
-        // Blocks of 256 slots whose slots have all run out of passes are marked by k_logic (PathBuffers::blockDead): their
+        // Blocks of 256 slots whose slots have all run out of passes are marked by k_shade (PathBuffers::blockDead): their
         // state is not read at all.  One 64-lane load fetches the marks of this workgroup's next 64 chunks.
         const uint32_t numChunks = (numSlots + chunk - 1) / chunk;
         uint64_t deadMask = 0;

@@ -1114,7 +1114,7 @@ int slrhip_render(slrhip_ctx* ctx, uint32_t sppBegin, uint32_t sppCount, void* s
     const uint64_t entryBytes = (rp.spectral ? 4u : 1u) * sizeof(float4);
     uint64_t budget = 16ull << 30;
     if (const char* e = getenv("SLRHIP_RESULT_WINDOW_MB")) { const long mb = atol(e); if (mb > 0) budget = (uint64_t)mb << 20; }
-    const uint64_t maxPasses = std::max<uint64_t>(1, std::min<uint64_t>(budget / ((uint64_t)rp.numPixels * entryBytes), 0xFFFFFFFFull / rp.numPixels));
+    const uint64_t maxPasses = std::max<uint64_t>(1, std::min<uint64_t>(budget / ((uint64_t)rp.numPixels * entryBytes), 0xF0000000ull / rp.numPixels));      // (run ids + one round of waves stay inside 32 bits)
     // whole runs (RenderParams::runLength passes of a pixel in a row, pt_kernels.h) wherever the call is long enough: a window of
     // an odd number of passes would fall back to runs of one pass and lose the coherence of a wave's slots
     uint32_t window = (uint32_t)std::min<uint64_t>(maxPasses, std::max<uint32_t>(sppCount, 1u));

@@ -1,8 +1,9 @@
-#!/bin/bash
-# paths in flight per pixel (sample stripes) on the headline, the environment-light and the spectral workloads
-for wl in "cornell" "ibl" "boxes_spectral --spp 256"; do for st in 4 8 12 16 24 32; do
-  timeout -k 10 200 python bench.py --workload $wl --stripes $st --cpu-seconds 0 --steps 1 --warmup 1 --no-parity 2>/dev/null | python -c "
+export SLRHIP_TAIL_SLOTS=262144
+for round in 1 2; do for k in 8 16 32 64; do
+  for wl in "cornell" "ibl" ; do
+  timeout -k 10 280 python bench.py --workload $wl --stripes $k --cpu-seconds 0 --no-parity --steps 1 --warmup 1 2>/dev/null | python -c "
 import json,sys,os
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d['kernels']
-print('%-24s stripes %-3s' % ('$wl', '$st'), 'Msamples/s %8.1f' % d['value'], {n:(round(k[n]['avg_us']), k[n]['launches']) for n in k}, flush=True)"
+print('K=%-3s %-10s' % ('$k', '$wl'), 'Msamples/s %8.1f' % d['value'], {n:round(k[n]['avg_us']) for n in k if k[n]['launches']}, flush=True)"
+  done
 done; done
