@@ -36,9 +36,7 @@ void launchTailTexRGB(const DevScene& sc, const PathBuffers& pb, const RenderPar
 void launchTailMultiSpec(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t blocks, hipStream_t stream);
 void launchTailTexSpec(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t blocks, hipStream_t stream);
 
-// every shade-kernel variant has its tail kernel; scenes with instanced meshes finish on the wavefront schedule (the tail kernel's
-// one-lane traversal is not instantiated with the instance steps)
-bool tailKernelAvailable(const DevScene& sc, bool) { return sc.instances == nullptr; }
+bool tailKernelAvailable(const DevScene&, bool) { return true; }      // every shade-kernel variant has its tail kernel
 
 void launchTail(const DevScene& sc, const PathBuffers& pb, const RenderParams& rp, uint32_t liveSlots, int numCUs, hipStream_t stream) {
     if (rp.numSlots == 0 || liveSlots == 0) return;

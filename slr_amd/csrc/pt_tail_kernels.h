@@ -89,16 +89,19 @@ __global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(SLR
         if (state != ST_FINISH) {
             const float4 d = pb.rayDir[(size_t)slot * pb.rayStride];
             HitRec hit;
-            traverse<false, false>(sc, sc.nodes, sc.leafTris, tlds.top, numTop, V3(o.x, o.y, o.z), V3(d.x, d.y, d.z), o.w, d.w, &hit, stack, &cnt,
-                                   pb.errorWord);
+            // (the instance steps are compiled in for every scene: they cost a test per leaf reference here, and the tail kernel is
+            // a third of a per cent of a frame)
+            traverse<false, false, true>(sc, sc.nodes, sc.leafTris, tlds.top, numTop, V3(o.x, o.y, o.z), V3(d.x, d.y, d.z), o.w, d.w, &hit, stack, &cnt,
+                                         pb.errorWord);
             pb.hit[slot] = make_float4(__uint_as_float(hit.tri), hit.t, hit.b1, hit.b2);
+            if (pb.hitInstance) pb.hitInstance[slot] = hit.inst;
             ++extRays;
         }
         if (F_SHADOW(flags)) {
             // Scene::testVisibility (SurfaceObject.cpp:418-430): the shadow ray starts where the extension ray does
             const float4 d = pb.shadowDir[slot];
             HitRec hit;
-            const bool occluded = traverse<true, false>(sc, sc.nodes, sc.leafTris, tlds.top, numTop, V3(o.x, o.y, o.z), V3(d.x, d.y, d.z), kRayEpsilon, d.w,
+            const bool occluded = traverse<true, false, true>(sc, sc.nodes, sc.leafTris, tlds.top, numTop, V3(o.x, o.y, o.z), V3(d.x, d.y, d.z), kRayEpsilon, d.w,
                                                         &hit, stack, &cnt, pb.errorWord);
             pb.visible[slot] = occluded ? 0u : 1u;
             ++shadowRays;

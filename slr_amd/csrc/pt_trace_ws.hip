@@ -50,6 +50,11 @@ static const bool kNoSpill = true;
 static const bool kNoSpill = false;
 #endif
 static const uint32_t kIdle = 0xFFFFFFFFu;
+// SLR_WS_INST_SAVE 1: the world ray of a lane inside an instance is kept in six more registers (under the 64-VGPR cap: in
+// scratch, where the compiler decides) instead of being read again from the slot's record when the lane leaves the instance
+#ifndef SLR_WS_INST_SAVE
+#define SLR_WS_INST_SAVE 1      // measured on the 1 250-instance grid: traversal launch 6 350 -> 5 770 us (+8 % Msamples/s); 0: variant builds
+#endif
 // SLR_WS_TOP (variant builds; 0 = off, the default): the first SLR_WS_TOP nodes of the breadth-first tree — levels 0-3 of a
 // four-wide tree are 85 nodes — are staged in LDS by every workgroup and read from there (north_star's "nodes staged through
 // LDS"; DESIGN.md has the measurement that decided the default).  128-byte nodes in rows of 144 B, 64-byte quantized nodes in
@@ -159,8 +164,9 @@ struct WsCounts {
 // INST: the scene has instanced meshes (DevScene::instances).  A child reference that names an instance (leaf flag, count 0) takes
 // the lane's ray to the mesh's local space — TransformedSurfaceObject::intersect, Core/SurfaceObject.cpp:307-317: origin as a point,
 // direction as a vector and NOT renormalised, so distances stay world distances and tmin / tmax carry over — pushes kPopInstance
-// and goes on at the root of the mesh's tree (same node and leaf arrays).  When kPopInstance comes off the stack the mesh is done:
-// the world ray is read again from the slot's record (two 16-byte loads; keeping it in registers would cost six VGPRs of the 64).
+// and goes on at the root of the mesh's tree (same node and leaf arrays).  When kPopInstance comes off the stack the mesh is done
+// and the world ray comes back from six registers of its own (they fit under the 64-VGPR cap without more scratch; reading it
+// again from the slot's record — two 16-byte loads that miss the caches, the producer streamed them — was 8 % slower).
 template <bool COUNT, int NC, bool QUANT, bool WIDE8, bool INST>
 __device__ __forceinline__ void wsConsume(const DevScene& sc, const PathBuffers& pb, WsLds<NC>& lds, uint32_t refill, uint32_t numTop, WsCounts& cnt, WsDebug& dbg) {
     const uint64_t tStart = COUNT ? __builtin_readcyclecounter() : 0;
@@ -178,6 +184,9 @@ __device__ __forceinline__ void wsConsume(const DevScene& sc, const PathBuffers&
     uint32_t hitTri = 0xFFFFFFFFu;
     float hitT = INFINITY, hitB1 = 0.0f, hitB2 = 0.0f;
     int32_t inst = -1, hitInst = -1;           // INST: the instance the lane is inside / the one its closest hit went through
+#if SLR_WS_INST_SAVE
+    float wox = 0, woy = 0, woz = 0, wdx = 0, wdy = 0, wdz = 0;      // the world ray while the lane is inside an instance
+#endif
     // a reference that is a packet of triangles (INST: not an instance reference, not kPopInstance)
     const auto isTriLeaf = [](uint32_t ref) -> bool {
         if (!INST) return (ref & kLeafFlag) != 0;
@@ -263,11 +272,16 @@ __device__ __forceinline__ void wsConsume(const DevScene& sc, const PathBuffers&
             // one step = entering or leaving an instance
             bool finished = false;
             if (cur == kPopInstance) {
+#if SLR_WS_INST_SAVE
+                ox = wox; oy = woy; oz = woz;
+                dx = wdx; dy = wdy; dz = wdz;
+#else
                 const uint32_t s = slot & ~kShadowBit;
                 const float4 o = pb.rayOrg[(size_t)s * pb.rayStride];
                 const float4 d = (slot & kShadowBit) ? pb.shadowDir[s] : pb.rayDir[(size_t)s * pb.rayStride];
                 ox = o.x; oy = o.y; oz = o.z;
                 dx = d.x; dy = d.y; dz = d.z;
+#endif
                 inst = -1;
                 if (sp == 0) finished = true;
                 else {
@@ -288,6 +302,9 @@ __device__ __forceinline__ void wsConsume(const DevScene& sc, const PathBuffers&
                 const float mx = c0.x * dx + c1.x * dy + c2.x * dz;
                 const float my = c0.y * dx + c1.y * dy + c2.y * dz;
                 const float mz = c0.z * dx + c1.z * dy + c2.z * dz;
+#if SLR_WS_INST_SAVE
+                wox = ox; woy = oy; woz = oz; wdx = dx; wdy = dy; wdz = dz;
+#endif
                 ox = lx; oy = ly; oz = lz;
                 dx = mx; dy = my; dz = mz;
                 if (sp < kWsLdsStack) { stack[sp * 64] = kPopInstance; ++sp; }
@@ -303,7 +320,8 @@ __device__ __forceinline__ void wsConsume(const DevScene& sc, const PathBuffers&
                 slot = kIdle;
             }
         }
-        else if (slot != kIdle) {
+        // (not `else`: a lane that has just entered or left an instance goes on with its node or triangle step in the same turn)
+        if (slot != kIdle && !(INST && (cur & kLeafFlag) != 0 && !isTriLeaf(cur))) {
             bool finished = false;
             const bool leafAtTop = isTriLeaf(cur);
             if (!leafAtTop) {

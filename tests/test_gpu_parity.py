@@ -93,25 +93,27 @@ def test_full_cornell_against_oracle(ctx, oracle_rgb, right):
     assert abs(int(c.shadow_rays) - int(ctr.shadow_rays)) <= ctr.shadow_rays * 1e-4
 
 
-def test_stripes_do_not_change_the_image(oracle_rgb):
+@pytest.mark.parametrize("mode", ["rgb", "spectral"])
+def test_stripes_do_not_change_the_image(request, mode):
     """More paths in flight (slrhip_config::stripes sizes the number of slots) change nothing: a sample is a function of
     (pixel, pass) and the sensor adds a pixel's samples in pass order (k_fold), whichever slot rendered them.  Also with the
     result window cut into pieces of a few passes (SLRHIP_RESULT_WINDOW_MB)."""
     sc = scenes.cornell_box_spheres(1.0, 24, 12, "glass")
     st = ob.settings(64, 64, seed=5)
-    want, _ = oracle_rgb.scene(sc).render(st, 32)
+    want, _ = request.getfixturevalue("oracle_" + mode).scene(sc).render(st, 32)
+    amode = abi.MODE_RGB if mode == "rgb" else abi.MODE_SPECTRAL
     frames = {}
     for stripes in (1, 3, 8, 64, 0):
-        c = Context(stripes=stripes)
+        c = Context(mode=amode, stripes=stripes)
         frames[stripes] = c.render_image(sc, st, 32)
         assert c.counters().samples == 64 * 64 * 32
         c.close()
     for stripes in (3, 8, 64, 0):
         assert_bit_equal(frames[stripes], frames[1], "stripes %d vs 1" % stripes)
     assert np.allclose(frames[1], want, rtol=2e-6, atol=1e-9)
-    os.environ["SLRHIP_RESULT_WINDOW_MB"] = "1"           # 64 x 64 pixels x 16 B = 64 KiB per pass: windows of 16 passes
+    os.environ["SLRHIP_RESULT_WINDOW_MB"] = "1"           # 64 x 64 pixels x 16 B (64 B spectral) per pass: windows of 16 (4) passes
     try:
-        c = Context(stripes=8)
+        c = Context(mode=amode, stripes=8)
         windows = c.render_image(sc, st, 32)
         c.close()
     finally:
@@ -1007,6 +1009,7 @@ def test_tail_kernel_variants_match_the_wavefront_iterations_bit_for_bit():
              ("multi rgb", scenes.cornell_multi(1.0, 10, 5), abi.MODE_RGB), ("multi spectral", scenes.cornell_multi(1.0, 10, 5), abi.MODE_SPECTRAL),
              ("textured rgb", scenes.cornell_textured(1.0, 10, 5), abi.MODE_RGB), ("textured spectral", scenes.cornell_textured(1.0, 10, 5), abi.MODE_SPECTRAL),
              ("ward", scenes.cornell_lobes("ward", segments=8, rings=4), abi.MODE_RGB),
+             ("instanced rgb", scenes.cornell_instanced(1.0, 10, 5), abi.MODE_RGB), ("instanced spectral", scenes.cornell_instanced(1.0, 10, 5), abi.MODE_SPECTRAL),
              ("environment light", scenes.ibl_test_scene(1.0, (64, 32), 8, 4), abi.MODE_RGB)]
     st = ob.settings(48, 36, seed=33)
     for name, sc, mode in cases:
