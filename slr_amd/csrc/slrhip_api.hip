@@ -29,6 +29,9 @@ namespace {
 const int kDefaultPairs = 1;                   // SLRHIP_PAIRS: the ray pair pays, the radiance-sum pair does not
 const uint32_t kStatusWords = 8;               // PathBuffers::activeSlots .. tailWords: one small array, read back in one copy
 const uint32_t kDefaultRunLength = 64;         // SLRHIP_RUN_LENGTH: passes of a pixel a wave takes in a row (pt_kernels.h WorkItem; measured: DESIGN.md)
+#ifndef SLR_TAIL_DIVISOR
+#define SLR_TAIL_DIVISOR 8u      // the tail kernel never takes more than this fraction of the slots (1u in a variant build: the tail kernel as the whole renderer, measured in DESIGN.md)
+#endif
 const uint32_t kDefaultTailSlots = 1u << 18;   // SLRHIP_TAIL_SLOTS: measured on the headline frame and its N = 8 shard
 
 thread_local std::string g_lastError;
@@ -945,7 +948,7 @@ static int renderWindow(slrhip_ctx* ctx, uint32_t sppBegin, uint32_t sppCount, h
         const bool asked = (ctx->config.flags & SLRHIP_FLAG_TAIL_KERNEL) != 0 || envTail > 0 || ctx->config.stripes == 0;
         const uint32_t bound = envTail > 0 ? (uint32_t)std::min<long>(envTail, 0x7FFFFFFFL) : kDefaultTailSlots;
         const bool off = !asked || envTail == 0 || !tailKernelAvailable(ctx->scene, rp.spectral != 0) || (ctx->config.flags & SLRHIP_FLAG_COUNT_TRAVERSAL) != 0;
-        rp.tailSlots = off ? 0u : std::min(bound, active / 8u);
+        rp.tailSlots = off ? 0u : std::min(bound, active / SLR_TAIL_DIVISOR);
     }
     // tail mode seen in the status words: list the live slots, finish them, read the words again (live slots must be 0 then)
     const auto runTail = [&](hipStream_t s, bool timed) -> int {
