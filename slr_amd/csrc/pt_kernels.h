@@ -154,6 +154,7 @@ struct PathBuffers {
     uint32_t* tailMode;
     uint32_t* tailWords;
     uint32_t* tailIdled;          // slots the tail kernel left idle: the host checks it against the list length (every listed slot must end idle)
+    uint32_t* windowSamples;      // samples the queues handed out in this window (k_count_samples): the host checks it against pixels x passes
     uint64_t* totals;             // [kind][shard], see totalIndex
     const uint32_t* pixelXY;      // pixel-of-shard -> x | y << 16
     // Records that the same kernels touch at the same slots share a 32-byte sector when these strides are 2 (rayDir = rayOrg + 1,

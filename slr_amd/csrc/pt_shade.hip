@@ -42,7 +42,10 @@ __global__ __launch_bounds__(kShadeBlock) void k_count_samples(PathBuffers pb, R
     if (threadIdx.x == 0) {
         uint32_t t = 0;
         for (int w = 0; w < kShadeBlock / 64; ++w) t += red[w];
-        if (t) atomicAdd((unsigned long long*)&pb.totals[totalIndex(T_SAMPLES, blockIdx.x % kShards)], (unsigned long long)t);
+        if (t) {
+            atomicAdd((unsigned long long*)&pb.totals[totalIndex(T_SAMPLES, blockIdx.x % kShards)], (unsigned long long)t);
+            atomicAdd(pb.windowSamples, t);
+        }
     }
 }
 

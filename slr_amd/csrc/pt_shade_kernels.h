@@ -1096,7 +1096,7 @@ __global__ void k_reset_slots(PathBuffers pb, RenderParams rp, uint32_t clearSen
         if (threadIdx.x < kShards) pb.idleShards[threadIdx.x * kCounterStride] = 0u;
         if (threadIdx.x == 0) {
             pb.activeSlots[0] = rp.numSlots; pb.errorWord[0] = rp.injectError ? ERR_QUEUE_OVERFLOW : 0u;
-            pb.tailMode[0] = 0u; pb.tailWords[0] = 0u; pb.tailWords[1] = 0u; pb.tailIdled[0] = 0u;
+            pb.tailMode[0] = 0u; pb.tailWords[0] = 0u; pb.tailWords[1] = 0u; pb.tailIdled[0] = 0u; pb.windowSamples[0] = 0u;
         }
     }
 }

@@ -892,7 +892,7 @@ int slrhip_render_begin(slrhip_ctx* ctx, const slrhip_render_settings* st, slrhi
     pb.pdfPrev = spectral ? ctx->pdfPrev.ptr : nullptr; pb.hdr = ctx->hdr.ptr; pb.shadowDir = ctx->shadowDir.ptr; pb.flags = ctx->flags.ptr;
     pb.hitInstance = ctx->scene.instances ? ctx->hitInstance.ptr : nullptr;
     pb.visible = ctx->visible.ptr; pb.shadowQueue = ctx->shadowQueue.ptr; pb.tailList = ctx->tailList.ptr;
-    pb.queueCount = ctx->queueCount.ptr; pb.activeSlots = ctx->activeSlots.ptr; pb.errorWord = ctx->activeSlots.ptr + 1; pb.tailMode = ctx->activeSlots.ptr + 3; pb.tailWords = ctx->activeSlots.ptr + 4; pb.tailIdled = ctx->activeSlots.ptr + 2; pb.idleShards = ctx->idleShards.ptr; pb.blockDead = ctx->blockDead.ptr; pb.totals = ctx->totals.ptr;
+    pb.queueCount = ctx->queueCount.ptr; pb.activeSlots = ctx->activeSlots.ptr; pb.errorWord = ctx->activeSlots.ptr + 1; pb.tailMode = ctx->activeSlots.ptr + 3; pb.tailWords = ctx->activeSlots.ptr + 4; pb.tailIdled = ctx->activeSlots.ptr + 2; pb.windowSamples = ctx->activeSlots.ptr + 6; pb.idleShards = ctx->idleShards.ptr; pb.blockDead = ctx->blockDead.ptr; pb.totals = ctx->totals.ptr;
     pb.pixelXY = ctx->pixelXY.ptr;
 
     RenderParams& rp = ctx->params;
@@ -950,6 +950,19 @@ static int renderWindow(slrhip_ctx* ctx, uint32_t sppBegin, uint32_t sppCount, h
         const bool off = !asked || envTail == 0 || !tailKernelAvailable(ctx->scene, rp.spectral != 0) || (ctx->config.flags & SLRHIP_FLAG_COUNT_TRAVERSAL) != 0;
         rp.tailSlots = off ? 0u : std::min(bound, active / SLR_TAIL_DIVISOR);
     }
+    // The window is complete only if the queues handed out exactly one sample per pixel and pass: the device's own count
+    // (k_count_samples over the queues' cursors) against the host's arithmetic.  A lost or repeated sample would leave a stale
+    // or overwritten entry in the result window — never silent.
+    const auto checkWindow = [&](hipStream_t s) -> int {
+        uint32_t words[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        HIP_TRY(hipMemcpyAsync(words, ctx->activeSlots.ptr, kStatusWords * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (words[1]) return deviceError(words[1]);
+        if (words[6] != rp.workItems)
+            return fail(SLRHIP_ERR_HIP, "slrhip_render: the work queues handed out " + std::to_string(words[6]) + " samples for a window of " +
+                                            std::to_string(rp.workItems) + " (internal error)");
+        return SLRHIP_OK;
+    };
     // tail mode seen in the status words: list the live slots, finish them, read the words again (live slots must be 0 then)
     const auto runTail = [&](hipStream_t s, bool timed) -> int {
         hipEvent_t t0 = nullptr, t1 = nullptr;
@@ -1038,8 +1051,7 @@ static int renderWindow(slrhip_ctx* ctx, uint32_t sppBegin, uint32_t sppCount, h
         launchCountSamples(ctx->buffers, rp, ws);      // samples rendered in this window, counted on the device (T_SAMPLES)
         launchFold(ctx->buffers, rp, ws);              // sensor->add, in pass order
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipStreamSynchronize(ws));
-        return SLRHIP_OK;
+        return checkWindow(ws);
     }
 
     // SLRHIP_ITER_LOG=path (with SLRHIP_FLAG_TIME_KERNELS): per-iteration kernel times of this call, one line per iteration
@@ -1089,6 +1101,10 @@ static int renderWindow(slrhip_ctx* ctx, uint32_t sppBegin, uint32_t sppCount, h
     launchCountSamples(ctx->buffers, rp, stream);       // samples rendered in this window, counted on the device (T_SAMPLES)
     launchFold(ctx->buffers, rp, stream);               // sensor->add, in pass order
     HIP_TRY(hipGetLastError());
+    {
+        const int rc = checkWindow(stream);
+        if (rc != SLRHIP_OK) return rc;
+    }
     if (iterLog && timeKernels && !iterActive.empty()) {
         if (FILE* f = fopen(iterLog, "a")) {
             const size_t per = iterMs.size() / iterActive.size();
