@@ -564,7 +564,33 @@ def test_errors_are_loud(ctx):
         c2.render_begin(ob.settings(8, 8))          # no scene uploaded
     c2.close()
     with pytest.raises(SlrHipError, match="64 sample stripes"):
-        Context(stripes=65)                         # the sample pool's mask is 64 bits wide
+        Context(stripes=65)                         # slrhip_config::stripes is bounded by SLRHIP_MAX_STRIPES
+    # instances the traversal cannot take are refused at upload, with the reason: a transform that is not affine, triangle
+    # ranges that overlap without being equal (nested instancing), an instanced triangle that emits
+    good = scenes.cornell_instanced(1.0, 8, 4)
+    c4 = Context()
+    try:
+        bad = scenes.cornell_instanced(1.0, 8, 4)
+        bad.instances["local_to_world"][0][3] = 0.25                    # bottom row of the matrix (column-major: element 3 of column 0)
+        with pytest.raises(SlrHipError, match="affine"):
+            c4.upload_scene(bad)
+        bad = scenes.cornell_instanced(1.0, 8, 4)
+        bad.instances["first_triangle"][1] += 1
+        bad.instances["num_triangles"][1] -= 1
+        with pytest.raises(SlrHipError, match="equal or disjoint"):
+            c4.upload_scene(bad)
+        bad = scenes.cornell_instanced(1.0, 8, 4)
+        light = int(np.nonzero(bad.materials["emittance"] >= 0)[0][0])
+        bad.triangles["material"][int(bad.instances["first_triangle"][0])] = light
+        with pytest.raises(SlrHipError, match="must not emit"):
+            c4.upload_scene(bad)
+        bad = scenes.cornell_instanced(1.0, 8, 4)
+        bad.instances["num_triangles"][0] = len(bad.triangles) + 5
+        with pytest.raises(SlrHipError, match="out of range"):
+            c4.upload_scene(bad)
+        c4.upload_scene(good)                                           # and the context is still usable
+    finally:
+        c4.close()
     # a kernel that gives up (bounded spin, dropped push) raises the device error word: the render must fail, not return rc 0
     c3 = Context(flags=abi.FLAG_TEST_DEVICE_ERROR)
     try:
